@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Load a fixture written by tests/golden/make_golden.py -> (dict of np arrays, state_dict of torch tensors)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = {k: z[k] for k in z.files}
+    sd = None
+    if "weights" in case:
+        w = np.load(os.path.join(GOLDEN, str(case["weights"]) + ".npz"))
+        sd = {k: torch.from_numpy(w[k]) for k in w.files}
+    if "x_from" in case:
+        case["x"] = np.load(os.path.join(GOLDEN, str(case["x_from"]) + ".npz"))["x"]
+    return case, sd
+
+
+def case_dims(sd):
+    """(D_feat, D_inner, K, C) from a GA state_dict."""
+    di, d = sd["dimreduction.fc1.weight"].shape
+    k = sd["attention.attention_weights.weight"].shape[0]
+    ckey = "Slide_classifier.fc.weight" if "Slide_classifier.fc.weight" in sd else "classifier.fc.weight"
+    return d, di, k, sd[ckey].shape[0]
+
+
+EVAL_CASES = ["ga_eval_n257_d512_k5_c2", "ga_eval_n1_d512_k5_c2", "ga_eval_n33_d512_k5_c2",
+              "ga_eval_n1000_d512_k1_c2", "ga_eval_n1000_d384_k5_c7"]
+TRAIN_CASES = ["ga_train_n7_d512_k5_c2", "ga_train_n640_d512_k5_c2", "ga_train_n2048_d512_k5_c7"]
+
+
+@pytest.fixture(scope="session")
+def have_gpu():
+    return torch.cuda.is_available()
