@@ -1,0 +1,58 @@
+"""ctypes binding of libacmil_hip.so (C ABI: include/acmil_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C acmil_amd/csrc`.  There is NO
+fallback: if the shared object is missing or a call returns an error code, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libacmil_hip.so")
+
+OK = 0
+ERRORS = {-1: "ACMIL_ERR_SHAPE", -2: "ACMIL_ERR_UNSUPPORTED", -3: "ACMIL_ERR_NULL", -4: "ACMIL_ERR_LAUNCH",
+          -5: "ACMIL_ERR_ARCH"}
+MODE_F32, MODE_F16X3, MODE_F16 = 0, 1, 2
+MODES = {"fp32": MODE_F32, "f16x3": MODE_F16X3, "f16": MODE_F16}
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+MAX_TOKENS, MAX_CLASSES = 5, 16
+
+_vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/acmil_hip.h declares
+SIGNATURES = {
+    "acmil_version": (C.c_char_p, []),
+    "acmil_check_device": (_i, []),
+    "acmil_ga_packed_bytes": (_sz, [_i] * 6),
+    "acmil_ga_pack_weights": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp)] + [_vp] * 2 + [_i] * 6 + [_vp, _vp]),
+    "acmil_ga_workspace_bytes": (_sz, [_i] * 6),
+    "acmil_ga_forward": (_i, [_vp, _i, _i, _vp] + [_i] * 6 + [_vp] * 6 + [_i, _vp, _vp]),
+    "acmil_ga_pool": (_i, [_vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _i] + [_vp] * 4 + [_i, _vp, _vp]),
+    "acmil_stkim_workspace_bytes": (_sz, [_i] * 3),
+    "acmil_stkim_select": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libacmil_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C acmil_amd/csrc`; there is no CPU/PyTorch fallback for the aggregation path" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != OK:
+        raise RuntimeError("%s failed: %s (%d)" % (what, ERRORS.get(rc, "unknown"), rc))

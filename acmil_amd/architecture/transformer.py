@@ -1,0 +1,150 @@
+"""Gated-attention aggregators with the reference's interface, computed by libacmil_hip.so.
+
+Mirrors `architecture/transformer.py` of dazhangyu123/ACMIL: `Attention_Gated` (:239-267),
+`ABMIL` (:270-286), `ACMIL_GA` (:291-352) -- same constructor arguments, `forward` /
+`forward_feature` signatures and return shapes, same `state_dict()` keys, masking keyed on
+`self.training`.  The arithmetic is NOT torch: forward (and backward) call the HIP kernels through
+`acmil_amd.ops`; CPU tensors are rejected (no fallback).
+
+Extra, non-reference knobs (keyword-only, defaults keep reference behaviour):
+  precision   'f16x3' (default: fp32-parity split-f16 MFMA), 'fp32' (exact fp32 MFMA) or 'f16' (throughput)
+  and `forward(x, uniforms=...)` to inject the STKIM `torch.rand(K,k)` draw for reproducible tests.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .network import Classifier_1fc, DimReduction
+
+
+class Attention_Gated(nn.Module):
+    """Parameter container with the reference's layout (attention_V.0 / attention_U.0 / attention_weights)."""
+
+    def __init__(self, L=512, D=128, K=1):
+        super().__init__()
+        if D != ops.GA_DA:
+            raise NotImplementedError("acmil_amd: attention hidden width D must be 128 (the reference's fixed default)")
+        self.L, self.D, self.K = L, D, K
+        self.attention_V = nn.Sequential(nn.Linear(L, D), nn.Tanh())
+        self.attention_U = nn.Sequential(nn.Linear(L, D), nn.Sigmoid())
+        self.attention_weights = nn.Linear(D, K)
+
+    def forward(self, x):  # standalone use only (not on the fused hot path): plain library GEMMs
+        a = self.attention_weights(self.attention_V(x) * self.attention_U(x))
+        return torch.transpose(a, 1, 0)
+
+
+class _GatedBase(nn.Module):
+    """Shared plumbing: parameter gathering and the packed-weight cache."""
+
+    precision: str
+
+    def _heads(self):
+        raise NotImplementedError
+
+    def _raw_params(self):
+        wc, bc, ws, bs = self._heads()
+        a = self.attention
+        return [self.dimreduction.fc1.weight, a.attention_V[0].weight, a.attention_V[0].bias,
+                a.attention_U[0].weight, a.attention_U[0].bias, a.attention_weights.weight,
+                a.attention_weights.bias], wc, bc, ws, bs
+
+    def _packed(self):
+        """Packed fragment stream of the current parameter values; re-packed only when a parameter changed
+        (tracked through tensor version counters / storage pointers)."""
+        base, wc, bc, ws, bs = self._raw_params()
+        allp = base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
+        key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in allp)
+        cache = getattr(self, "_pack_cache", None)
+        if cache is None or cache[0] != key:
+            packed, dims = ops.ga_pack_weights(*[p.detach() for p in base], [p.detach() for p in wc],
+                                               [p.detach() for p in bc], None if ws is None else ws.detach(),
+                                               None if bs is None else bs.detach(), self.precision)
+            cache = (key, packed, dims)
+            self._pack_cache = cache
+        return cache[1], cache[2]
+
+    @staticmethod
+    def _bag(x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 3:
+            raise RuntimeError("expected x of shape [1, N, D_feat]")
+        x = x[0]  # B must be 1 (the reference silently takes x[0], transformer.py:306)
+        return x if x.is_contiguous() else x.contiguous()
+
+
+class ABMIL(_GatedBase):
+    def __init__(self, conf, D=128, droprate=0, *, precision="f16x3"):
+        super().__init__()
+        if droprate != 0:
+            raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
+        self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
+        self.attention = Attention_Gated(conf.D_inner, D, 1)
+        self.classifier = Classifier_1fc(conf.D_inner, conf.n_class, droprate)
+        self.precision = precision
+
+    def _heads(self):
+        return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
+
+    def forward(self, x):  # x: [1, N, D_feat] -> logits [1, C]
+        packed, dims = self._packed()
+        out = ops.ga_forward(self._bag(x), packed, dims, self.precision, want_scores=False)
+        return out["sub_preds"]
+
+
+class ACMIL_GA(_GatedBase):
+    def __init__(self, conf, D=128, droprate=0, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3"):
+        super().__init__()
+        if droprate != 0:
+            raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
+        self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
+        self.attention = Attention_Gated(conf.D_inner, D, n_token)
+        self.classifier = nn.ModuleList()
+        for _ in range(n_token):
+            self.classifier.append(Classifier_1fc(conf.D_inner, conf.n_class, droprate))
+        self.n_masked_patch = n_masked_patch
+        self.n_token = conf.n_token
+        self.Slide_classifier = Classifier_1fc(conf.D_inner, conf.n_class, droprate)
+        self.mask_drop = mask_drop
+        self.precision = precision
+
+    def _heads(self):
+        return ([c.fc.weight for c in self.classifier], [c.fc.bias for c in self.classifier],
+                self.Slide_classifier.fc.weight, self.Slide_classifier.fc.bias)
+
+    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False):
+        n = xb.shape[0]
+        k = min(self.n_masked_patch, n)
+        m = int(k * self.mask_drop)
+        A, h = ops.ga_scores(xb, packed, dims, self.precision)
+        if uniforms is None:
+            uniforms = torch.rand(dims.K, k, device=xb.device)
+        topk, midx = ops.stkim_select(A, k, m, uniforms)
+        out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat)
+        out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
+        return out
+
+    def forward(self, x, uniforms: Optional[torch.Tensor] = None):
+        """x [1,N,D_feat] -> (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N])  (transformer.py:305-330)."""
+        packed, dims = self._packed()
+        xb = self._bag(x)
+        if self.n_masked_patch > 0 and self.training:
+            out = self._masked_forward(xb, packed, dims, uniforms)
+        else:
+            out = ops.ga_forward(xb, packed, dims, self.precision)
+        self._last = out
+        return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
+
+    def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
+        """x [1,N,D_feat] -> bag_feat [1,Di]  (transformer.py:332-352)."""
+        packed, dims = self._packed()
+        xb = self._bag(x)
+        if self.n_masked_patch > 0 and use_attention_mask:
+            out = self._masked_forward(xb, packed, dims, uniforms, want_bag_feat=True)
+        else:
+            out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=False, want_preds=False,
+                                 want_bag_feat=True)
+        return out["bag_feat"].unsqueeze(0)

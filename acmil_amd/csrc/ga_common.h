@@ -1,0 +1,78 @@
+// ga_common.h -- shared definitions for the gated-attention (GA) kernels of libacmil_hip.so.
+// gfx950 / CDNA4 only: wave64, v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_f16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "acmil_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define GA_DA 128           // attention hidden width, fixed by the reference (transformer.py:292)
+#define GA_WAVES 4          // waves per workgroup; each wave owns 32 consecutive patches
+#define GA_ROWS_PER_WG 128  // 4 waves x 32 patches
+#define GA_FRAG_ROW 1024    // one "fragment row" of the packed weight stream: 64 lanes x 16 B
+
+// Row index inside a 32x32 MFMA C/D tile held by (register r, lane-half hi): the gfx950 C/D map is
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)   (cdna_hip_programming.md section 3).
+__host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ---------------------------------------------------------------------------------------------------
+// Packed-weight buffer layout (built by ga_pack.hip, consumed by ga_forward.hip).  All offsets in bytes.
+//
+//  g1 : GEMM1 operand stream, (D/64) macro-steps x 8 x ND fragment rows (ND = Di/32 output tiles)
+//  g2 : GEMM2 operand stream, 2 unit-groups x ND x 16 fragment rows   (both: half as many rows in MODE_F16)
+//  tab: bv[128], bu[128], Ww[K][128]  raw fp32 (the C/D register quad (4rq..4rq+3) of tile pair p in lane
+//       half hi covers the 4 CONSECUTIVE units 32p + 8rq + 4hi + {0..3}, so the epilogue reads plain float4s)
+//  bw : 8 floats (bw[K], zero padded)
+//  heads: Wc [K][C][Di], bc [K][C], Ws [C][Di], bs [C]   (raw copies, fp32)
+// ---------------------------------------------------------------------------------------------------
+struct GaLayout {
+    int D, Di, K, C, ND, mode;
+    size_t g1_off, g1_rows, g2_off, g2_rows, tab_off, bw_off, wc_off, bc_off, ws_off, bs_off, total;
+};
+
+__host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C, int mode) {
+    GaLayout L;
+    L.D = D; L.Di = Di; L.K = K; L.C = C; L.mode = mode;
+    L.ND = Di / 32;
+    size_t off = 0;
+    const int half = (mode == ACMIL_MODE_F16) ? 2 : 1;  // single-pass f16 carries no "lo" rows
+    L.g1_off = off; L.g1_rows = (size_t)(D / 64) * 8 * L.ND / half; off += L.g1_rows * GA_FRAG_ROW;
+    L.g2_off = off; L.g2_rows = (size_t)L.ND * 32 / half;            off += L.g2_rows * GA_FRAG_ROW;
+    L.tab_off = off; off += (size_t)(2 + K) * GA_DA * 4;
+    L.bw_off = off;  off += 8 * 4;
+    L.wc_off = off;  off += (size_t)K * C * Di * 4;
+    L.bc_off = off;  off += (size_t)((K * C + 3) / 4) * 16;
+    L.ws_off = off;  off += (size_t)C * Di * 4;
+    L.bs_off = off;  off += (size_t)((C + 3) / 4) * 16;
+    L.total = (off + 255) & ~(size_t)255;
+    return L;
+}
+
+// Workspace layout of the forward: per-workgroup online-softmax partials
+//   part[tile][k][0] = running max m, [1] = sum l, [2 .. 2+Di) = sum_n exp(s-m) h[n][:]
+__host__ __device__ static inline size_t ga_part_stride(int Di) { return (size_t)(2 + Di); }
+__host__ __device__ static inline int ga_num_tiles(int N) { return (N + GA_ROWS_PER_WG - 1) / GA_ROWS_PER_WG; }
+
+static inline int ga_check_dims(int D, int Di, int Da, int K, int C) {
+    if (Da != GA_DA) return ACMIL_ERR_UNSUPPORTED;
+    if (D <= 0 || Di <= 0 || K <= 0 || C <= 0) return ACMIL_ERR_SHAPE;
+    if (D % 64 != 0 || Di % 128 != 0) return ACMIL_ERR_SHAPE;
+    if (K > ACMIL_MAX_TOKENS || C > ACMIL_MAX_CLASSES) return ACMIL_ERR_UNSUPPORTED;
+    return ACMIL_OK;
+}
+
+// fast transcendental forms: one v_exp_f32 + one v_rcp_f32 each; absolute error ~1e-7, which is the
+// fp32 round-off class of the GEMM that feeds them.
+__device__ static inline float ga_sigmoid(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
+__device__ static inline float ga_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }
+
+// merge + heads (ga_forward.hip), shared by the fused forward and the masked pooling pass
+int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
+              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st);

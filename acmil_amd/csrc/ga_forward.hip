@@ -1,0 +1,162 @@
+// ga_forward.hip -- host side of the fused GA forward (C ABI: include/acmil_hip.h) plus the two small
+// kernels that finish it: ga_merge_kernel (fixed-order combine of the per-workgroup online-softmax
+// partials) and ga_heads_kernel (K branch heads + bag head).  The fused kernel itself is
+// ga_forward_kernel.h, instantiated per family in ga_forward_inst.hip.
+#include "ga_forward_kernel.h"
+
+// ------------------------------------------------------------------------------------------------
+// merge: afeat[k][:] = (sum_t e^{m_t-M} acc_t) / (sum_t e^{m_t-M} l_t), fixed summation order.
+// grid (K, Di/64), 256 threads = 4 groups of 64 lanes; lane = feature, group g takes tiles g, g+4, ...
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ga_merge_kernel(const float* __restrict__ part, int tiles, int K, int Di,
+                                                       float* __restrict__ afeat) {
+    __shared__ float red[4][66];
+    __shared__ float smx[4];
+    const int k = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const size_t PS = 2 + Di;
+    const float* base = part + (size_t)k * PS;
+    const size_t tstride = (size_t)K * PS;
+    float m = -INFINITY;
+    for (int t = tid; t < tiles; t += 256) m = fmaxf(m, base[t * tstride]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) smx[g] = m;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    float acc = 0.0f, l = 0.0f;
+    const int di = 64 * c + lane;
+    for (int t = g; t < tiles; t += 4) {
+        const float* p = base + t * tstride;
+        const float f = __expf(p[0] - M);
+        l = fmaf(f, p[1], l);
+        acc = fmaf(f, p[2 + di], acc);
+    }
+    red[g][lane] = acc;
+    if (lane == 0) red[g][64] = l;
+    __syncthreads();
+    if (g == 0) {
+        const float A = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        const float Ls = ((red[0][64] + red[1][64]) + red[2][64]) + red[3][64];
+        afeat[(size_t)k * Di + di] = A / Ls;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// heads: sub_preds[k] = Wc[k] afeat[k] + bc[k]  (transformer.py:325-327, network.py:14-19)
+//        bag_feat = mean_k afeat[k]             (== mm(softmax(A).mean(0), h), transformer.py:328-329)
+//        slide_pred = Ws bag_feat + bs          (transformer.py:330)
+// one workgroup; each wave takes outputs o = wave, wave+4, ...; lanes stride the Di-long dot product.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ga_heads_kernel(const float* __restrict__ afeat, const char* __restrict__ packed,
+                                                       GaLayout L, int has_bag_head, float* __restrict__ sub_preds,
+                                                       float* __restrict__ slide_pred, float* __restrict__ bag_feat) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* af = (float*)smem;               // [K][Di]
+    float* bf = af + (size_t)L.K * L.Di;    // [Di]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = L.K, C = L.C, Di = L.Di;
+    for (int e = tid; e < K * Di; e += 256) af[e] = afeat[e];
+    __syncthreads();
+    for (int di = tid; di < Di; di += 256) {
+        float s = 0.0f;
+        for (int k = 0; k < K; ++k) s += af[k * Di + di];
+        s = s / (float)K;
+        bf[di] = s;
+        if (bag_feat) bag_feat[di] = s;
+    }
+    __syncthreads();
+    const float* wc = (const float*)(packed + L.wc_off);
+    const float* bc = (const float*)(packed + L.bc_off);
+    const float* ws = (const float*)(packed + L.ws_off);
+    const float* bs = (const float*)(packed + L.bs_off);
+    const int nout = K * C + (has_bag_head ? C : 0);
+    for (int o = wave; o < nout; o += 4) {
+        const float* w; const float* v; float b; float* dst;
+        if (o < K * C) { w = wc + (size_t)o * Di; v = af + (size_t)(o / C) * Di; b = bc[o]; dst = sub_preds ? sub_preds + o : nullptr; }
+        else { const int c = o - K * C; w = ws + (size_t)c * Di; v = bf; b = bs[c]; dst = slide_pred ? slide_pred + c : nullptr; }
+        float s = 0.0f;
+        for (int di = lane; di < Di; di += 64) s = fmaf(w[di], v[di], s);
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) s += __shfl_xor(s, o2);
+        if (lane == 0 && dst) *dst = s + b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+#define GA_FAMILY(ND, KP, MODE) int ga_fwd_family_##ND##_##KP##_##MODE(const GaFwdArgs&, int, bool, hipStream_t);
+#include "ga_families.inc"
+#undef GA_FAMILY
+
+static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
+    const int ND = a.L.ND, K = a.L.K;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+#define GA_FAMILY(ND_, KP_, MODE_) \
+    if (ND == ND_ && KP == KP_ && mode == MODE_) return ga_fwd_family_##ND_##_##KP_##_##MODE_(a, x_dtype, pool, st);
+#include "ga_families.inc"
+#undef GA_FAMILY
+    return ACMIL_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode) {
+    (void)D; (void)C; (void)mode;
+    if (N <= 0 || Di <= 0 || K <= 0) return 0;
+    size_t b = (size_t)ga_num_tiles(N) * K * ga_part_stride(Di) * sizeof(float);  // partials
+    b = (b + 255) & ~(size_t)255;
+    b += (size_t)K * Di * sizeof(float);                                          // afeat scratch
+    return (b + 255) & ~(size_t)255;
+}
+
+// merge + heads shared by the fused forward and the masked pooling pass
+int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
+              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st) {
+    const int K = L.K, Di = L.Di;
+    size_t poff = ((size_t)tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
+    float* af = afeat ? afeat : (float*)((char*)workspace + poff);
+    hipLaunchKernelGGL(ga_merge_kernel, dim3(K, Di / 64), dim3(256), 0, st, part, tiles, K, Di, af);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (sub_preds || slide_pred || bag_feat) {
+        const size_t lds = ((size_t)K * Di + Di) * sizeof(float);
+        hipLaunchKernelGGL(ga_heads_kernel, dim3(1), dim3(256), lds, st, af, (const char*)packed, L, has_bag_head,
+                           sub_preds, slide_pred, bag_feat);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
+    return ACMIL_OK;
+}
+
+extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,
+                                int C, int mode, float* A_out, float* sub_preds, float* slide_pred, float* afeat,
+                                float* bag_feat, float* h_save, int has_bag_head, void* workspace, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (N <= 0) return ACMIL_ERR_SHAPE;
+    if (!x || !packed) return ACMIL_ERR_NULL;
+    const bool pool = sub_preds || slide_pred || afeat || bag_feat;
+    if (pool && !workspace) return ACMIL_ERR_NULL;
+    if (pool && h_save) return ACMIL_ERR_UNSUPPORTED;  // score pass (h_save) and pooled outputs are separate calls
+    if (!pool && !h_save && !A_out) return ACMIL_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    GaFwdArgs a;
+    a.x = x; a.packed = (const char*)packed; a.A_out = A_out; a.part = (float*)workspace; a.h_save = h_save; a.N = N;
+    a.L = ga_layout(D, Di, K, C, mode);
+    if (!pool && !h_save) {
+        // scores only: run the pooled variant into the workspace and drop its partials
+        if (!workspace) return ACMIL_ERR_NULL;
+        return ga_dispatch(a, mode, x_dtype, true, st);
+    }
+    rc = ga_dispatch(a, mode, x_dtype, pool, st);
+    if (rc != ACMIL_OK || !pool) return rc;
+    return ga_finish(a.part, ga_num_tiles(N), packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
+                     workspace, st);
+}
+
+extern "C" const char* acmil_version(void) { return "acmil_hip 0.1 (gfx950)"; }
+
+extern "C" int acmil_check_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ACMIL_ERR_ARCH;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_ARCH;
+    const char* n = prop.gcnArchName;
+    return (n[0] == 'g' && n[1] == 'f' && n[2] == 'x' && n[3] == '9' && n[4] == '5' && n[5] == '0') ? ACMIL_OK : ACMIL_ERR_ARCH;
+}

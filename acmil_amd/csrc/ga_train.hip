@@ -1,0 +1,233 @@
+// ga_train.hip -- the pieces of ACMIL_GA.forward that only run in training mode
+//   STKIM top-k + random subset selection     architecture/transformer.py:311-317
+//   mask application                          architecture/transformer.py:318-320
+//   masked softmax + attention-weighted sum   architecture/transformer.py:322-324 (on the saved h)
+// plus their C entry points (include/acmil_hip.h).  All of it is HBM-bound streaming / selection work:
+// coalesced float4 row reads, LDS for the per-tile probabilities, wave shuffles for reductions.
+#include "ga_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// top-k.  Order-preserving key: (monotone uint32 image of the fp32 score) << 32 | (0xFFFFFFFF - index),
+// so a max over keys picks the largest score and, among equal scores, the LOWEST index.
+// ------------------------------------------------------------------------------------------------
+#define STKIM_CHUNK 4096
+#define STKIM_EPT (STKIM_CHUNK / 256)
+
+__device__ static inline unsigned long long stkim_key(float v, unsigned idx) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__device__ static inline unsigned long long block_max_key(unsigned long long key, unsigned long long* red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o);
+        key = other > key ? other : key;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = key;
+    __syncthreads();
+    unsigned long long m = red[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+    return m;
+}
+
+// grid (nchunks, K): each block extracts the k best keys of its chunk of row K -> cand[branch][chunk][k]
+__global__ __launch_bounds__(256) void stkim_local_topk_kernel(const float* __restrict__ scores, int N, int k,
+                                                               unsigned long long* __restrict__ cand) {
+    __shared__ unsigned long long red[4];
+    const int chunk = blockIdx.x, br = blockIdx.y, nch = gridDim.x;
+    const float* row = scores + (size_t)br * N;
+    unsigned long long keys[STKIM_EPT];
+#pragma unroll
+    for (int e = 0; e < STKIM_EPT; ++e) {
+        const unsigned idx = (unsigned)chunk * STKIM_CHUNK + e * 256 + threadIdx.x;
+        keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
+    }
+    unsigned long long* out = cand + ((size_t)br * nch + chunk) * k;
+    for (int j = 0; j < k; ++j) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int e = 0; e < STKIM_EPT; ++e) best = keys[e] > best ? keys[e] : best;
+        const unsigned long long win = block_max_key(best, red);
+        if (threadIdx.x == 0) out[j] = win;
+#pragma unroll
+        for (int e = 0; e < STKIM_EPT; ++e)
+            if (keys[e] == win) keys[e] = 0ull;  // keys are unique (index in the low word); 0 = taken / padding
+    }
+}
+
+// grid (K): merge the per-chunk candidates of one branch into the sorted top-k, then pick the masked subset
+__global__ __launch_bounds__(256) void stkim_merge_select_kernel(const unsigned long long* __restrict__ cand, int ncand,
+                                                                 int k, int m, const float* __restrict__ uniforms,
+                                                                 int64_t* __restrict__ topk_idx,
+                                                                 int64_t* __restrict__ masked_idx) {
+    __shared__ unsigned long long red[4];
+    __shared__ unsigned sel[64];
+    const int br = blockIdx.x;
+    const unsigned long long* c = cand + (size_t)br * ncand;
+    // each thread owns candidates tid, tid+256, ... (ncand = nchunks*k is small: <= 25*64)
+    unsigned long long keys[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int i = e * 256 + threadIdx.x;
+        keys[e] = i < ncand ? c[i] : 0ull;
+    }
+    for (int j = 0; j < k; ++j) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) best = keys[e] > best ? keys[e] : best;
+        const unsigned long long win = block_max_key(best, red);
+        if (threadIdx.x == 0) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(win & 0xFFFFFFFFull);
+            sel[j] = idx;
+            topk_idx[(size_t)br * k + j] = (int64_t)idx;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (keys[e] == win) keys[e] = 0ull;
+    }
+    __syncthreads();
+    // masked subset: the columns with the m smallest uniforms (argsort ascending, first m), in that order
+    if ((int)threadIdx.x < k && m > 0) {
+        const float* u = uniforms + (size_t)br * k;
+        const float mine = u[threadIdx.x];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (u[j] < mine || (u[j] == mine && j < (int)threadIdx.x)) ? 1 : 0;
+        if (rank < m) masked_idx[(size_t)br * m + rank] = (int64_t)sel[threadIdx.x];
+    }
+}
+
+extern "C" size_t acmil_stkim_workspace_bytes(int N, int K, int k) {
+    if (N <= 0 || K <= 0 || k <= 0) return 0;
+    const size_t nch = (size_t)(N + STKIM_CHUNK - 1) / STKIM_CHUNK;
+    return ((size_t)K * nch * k * sizeof(unsigned long long) + 255) & ~(size_t)255;
+}
+
+extern "C" int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
+                                  int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
+    if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
+    if (!scores || !topk_idx || !workspace || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
+    const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
+    if ((size_t)nch * k > 8 * 256) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* cand = (unsigned long long*)workspace;
+    hipLaunchKernelGGL(stkim_local_topk_kernel, dim3(nch, K), dim3(256), 0, st, scores, N, k, cand);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(stkim_merge_select_kernel, dim3(K), dim3(256), 0, st, cand, nch * k, k, m, uniforms, topk_idx,
+                       masked_idx);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask application: A[k, masked_idx[k, j]] = -1e9        (transformer.py:318-320)
+// ------------------------------------------------------------------------------------------------
+__global__ void ga_apply_mask_kernel(float* __restrict__ A, int N, int K, const int64_t* __restrict__ midx, int m) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K * m) {
+        const int br = i / m;
+        const int64_t n = midx[i];
+        if (n >= 0 && n < N) A[(size_t)br * N + n] = -1e9f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pooling over a saved h: per 128-row tile the online-softmax partial (m, l, sum_n e^{s-m} h[n][:]) in
+// the same format the fused forward emits (so ga_merge_kernel / ga_heads_kernel finish both).
+// 256 threads; LPR = Di/4 lanes cover one h row with float4 loads, RPI = 256/LPR rows per iteration.
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ h, const float* __restrict__ A, int N,
+                                                      int K, int Di, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* p_lds = (float*)smem;                     // [128][KP]
+    float* stat = p_lds + 128 * KP;                  // [KP][2] : m, l
+    float* red = stat + 2 * KP;                      // [RPI][KP][Di] cross-row-group reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * GA_ROWS_PER_WG;
+    const int rows = min(GA_ROWS_PER_WG, N - n0);
+    // ---- tile statistics: wave w handles branches w, w+4, ...; 64 lanes x 2 rows each
+    for (int k = wave; k < KP; k += 4) {
+        float s0 = -INFINITY, s1 = -INFINITY;
+        if (k < K) {
+            if (lane < rows) s0 = A[(size_t)k * N + n0 + lane];
+            if (lane + 64 < rows) s1 = A[(size_t)k * N + n0 + lane + 64];
+        }
+        float m = fmaxf(s0, s1);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e0 = (k < K && lane < rows) ? __expf(s0 - m) : 0.0f;
+        const float e1 = (k < K && lane + 64 < rows) ? __expf(s1 - m) : 0.0f;
+        float l = e0 + e1;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+        p_lds[lane * KP + k] = e0;
+        p_lds[(lane + 64) * KP + k] = e1;
+        if (lane == 0) { stat[2 * k] = m; stat[2 * k + 1] = l; }
+    }
+    __syncthreads();
+    const int LPR = Di / 4, RPI = 256 / LPR;
+    const int rsub = tid / LPR, c4 = tid % LPR;
+    float acc[KP][4];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0f;
+    if (rsub < RPI) {
+        const f32x4* hp = (const f32x4*)(h + (size_t)n0 * Di) + c4;
+#pragma unroll 4
+        for (int n = rsub; n < rows; n += RPI) {
+            const f32x4 v = __builtin_nontemporal_load(hp + (size_t)n * LPR);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float p = p_lds[n * KP + k];
+                acc[k][0] = fmaf(p, v[0], acc[k][0]); acc[k][1] = fmaf(p, v[1], acc[k][1]);
+                acc[k][2] = fmaf(p, v[2], acc[k][2]); acc[k][3] = fmaf(p, v[3], acc[k][3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) *(f32x4*)(red + ((size_t)(rsub * KP + k) * Di) + 4 * c4) = f32x4{acc[k][0], acc[k][1], acc[k][2], acc[k][3]};
+    }
+    __syncthreads();
+    const size_t PS = 2 + Di;
+    float* out = part + (size_t)blockIdx.x * K * PS;
+    for (int k = 0; k < K; ++k) {
+        if (tid < 2) out[k * PS + tid] = stat[2 * k + tid];
+        for (int di = tid; di < Di; di += 256) {
+            float s = 0.0f;
+            for (int r = 0; r < RPI; ++r) s += red[(size_t)(r * KP + k) * Di + di];
+            out[k * PS + 2 + di] = s;
+        }
+    }
+}
+
+extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed, int D, int Di, int Da, int K, int C,
+                             int mode, const int64_t* masked_idx, int n_masked, float* sub_preds, float* slide_pred,
+                             float* afeat, float* bag_feat, int has_bag_head, void* workspace, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (N <= 0 || n_masked < 0) return ACMIL_ERR_SHAPE;
+    if (!h || !A || !packed || !workspace || (n_masked > 0 && !masked_idx)) return ACMIL_ERR_NULL;
+    if (Di > 1024) return ACMIL_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_masked > 0) {
+        const int tot = K * n_masked;
+        hipLaunchKernelGGL(ga_apply_mask_kernel, dim3((tot + 63) / 64), dim3(64), 0, st, A, N, K, masked_idx, n_masked);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
+    const GaLayout L = ga_layout(D, Di, K, C, mode);
+    const int tiles = ga_num_tiles(N);
+    float* part = (float*)workspace;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int RPI = 256 / (Di / 4);
+    const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
+    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
+    void (*kern)(const float*, const float*, int, int, int, float*) =
+        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, h, (const float*)A, N, K, Di, part);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    return ga_finish(part, tiles, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head, workspace, st);
+}

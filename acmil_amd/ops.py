@@ -1,0 +1,172 @@
+"""Host-side wrappers of the C ABI (include/acmil_hip.h) on torch CUDA tensors.
+
+PyTorch is plumbing here: it owns device memory (caching allocator) and the stream; every numerical
+step of the aggregation path runs in libacmil_hip.so.  Nothing in this file computes on the CPU and
+there is no fallback: CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+GA_DA = 128
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("acmil_amd: the aggregation path runs only on an MI355X (got a %s tensor); "
+                               "there is no CPU fallback" % t.device)
+
+
+def mode_id(mode) -> int:
+    if isinstance(mode, int):
+        return mode
+    return _lib.MODES[mode]
+
+
+class GaDims:
+    """Shape bundle of one gated-attention aggregator."""
+
+    def __init__(self, D: int, Di: int, K: int, C: int, has_bag_head: bool = True):
+        self.D, self.Di, self.K, self.C, self.has_bag_head = D, Di, K, C, bool(has_bag_head)
+
+    def args(self):
+        return (self.D, self.Di, GA_DA, self.K, self.C)
+
+
+def ga_pack_weights(W1, Wv, bv, Wu, bu, Ww, bw, Wc: Sequence[torch.Tensor], bc: Sequence[torch.Tensor],
+                    Ws: Optional[torch.Tensor], bs: Optional[torch.Tensor], mode) -> Tuple[torch.Tensor, GaDims]:
+    """acmil_ga_pack_weights: parameters (fp32, CUDA, contiguous) -> packed fragment stream (uint8 tensor)."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    ts = [W1, Wv, bv, Wu, bu, Ww, bw] + list(Wc) + list(bc) + [t for t in (Ws, bs) if t is not None]
+    _need_cuda(*ts)
+    ts = [t.detach() for t in ts]
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("acmil_amd: parameters must be contiguous fp32")
+    Di, D = W1.shape
+    K, C = Ww.shape[0], Wc[0].shape[0]
+    if Wv.shape != (GA_DA, Di) or Wu.shape != (GA_DA, Di) or Ww.shape[1] != GA_DA or len(Wc) != K:
+        raise RuntimeError("acmil_amd: unexpected parameter shapes")
+    dims = GaDims(D, Di, K, C, has_bag_head=Ws is not None)
+    nbytes = lib.acmil_ga_packed_bytes(*dims.args(), mode)
+    if nbytes == 0:
+        raise RuntimeError("acmil_amd: unsupported dimensions D=%d Di=%d K=%d C=%d" % (D, Di, K, C))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=W1.device)
+    wc_arr = (ctypes.c_void_p * K)(*[t.data_ptr() for t in Wc])
+    bc_arr = (ctypes.c_void_p * K)(*[t.data_ptr() for t in bc])
+    rc = lib.acmil_ga_pack_weights(W1.data_ptr(), Wv.data_ptr(), bv.data_ptr(), Wu.data_ptr(), bu.data_ptr(),
+                                   Ww.data_ptr(), bw.data_ptr(), wc_arr, bc_arr, _ptr(Ws), _ptr(bs),
+                                   *dims.args(), mode, packed.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_pack_weights")
+    return packed, dims
+
+
+def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
+    n = _lib.load().acmil_ga_workspace_bytes(N, dims.D, dims.Di, dims.K, dims.C, mode)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def _check_x(x: torch.Tensor, dims: GaDims) -> None:
+    _need_cuda(x)
+    if x.dim() != 2 or x.shape[1] != dims.D or x.shape[0] < 1:
+        raise RuntimeError("acmil_amd: bag must be [N>=1, %d], got %s" % (dims.D, tuple(x.shape)))
+    if x.dtype not in _DT or not x.is_contiguous():
+        raise RuntimeError("acmil_amd: bag must be contiguous fp32/fp16/bf16")
+
+
+def ga_forward(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, want_scores: bool = True,
+               want_preds: bool = True, want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, torch.Tensor]:
+    """acmil_ga_forward, fused eval path.  x [N,D] -> dict(A_out [K,N], sub_preds [K,C], slide_pred [C], ...)."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _check_x(x, dims)
+    N, dev = x.shape[0], x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out: Dict[str, torch.Tensor] = {}
+    A = torch.empty(dims.K, N, **f32) if want_scores else None
+    sub = torch.empty(dims.K, dims.C, **f32) if want_preds else None
+    slide = torch.empty(dims.C, **f32) if (want_preds and dims.has_bag_head) else None
+    af = torch.empty(dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(dims.Di, **f32) if want_bag_feat else None
+    ws = _workspace(N, dims, mode, dev)
+    rc = lib.acmil_ga_forward(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), *dims.args(), mode, _ptr(A), _ptr(sub),
+                              _ptr(slide), _ptr(af), _ptr(bf), None, int(dims.has_bag_head), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_forward")
+    for k, v in (("A_out", A), ("sub_preds", sub), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out
+
+
+def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward)."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _check_x(x, dims)
+    N, dev = x.shape[0], x.device
+    A = torch.empty(dims.K, N, dtype=torch.float32, device=dev)
+    h = torch.empty(N, dims.Di, dtype=torch.float32, device=dev)
+    rc = lib.acmil_ga_forward(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), *dims.args(), mode, A.data_ptr(), None,
+                              None, None, None, h.data_ptr(), int(dims.has_bag_head), None, _stream())
+    _lib.check(rc, "acmil_ga_forward(score pass)")
+    return A, h
+
+
+def stkim_select(scores: torch.Tensor, k: int, m: int, uniforms: Optional[torch.Tensor]):
+    """acmil_stkim_select: (topk_idx [K,k] int64 sorted by descending score, masked_idx [K,m] int64)."""
+    lib = _lib.load()
+    _need_cuda(scores)
+    K, N = scores.shape
+    dev = scores.device
+    topk = torch.empty(K, k, dtype=torch.int64, device=dev)
+    midx = torch.empty(K, m, dtype=torch.int64, device=dev)
+    if m > 0:
+        if uniforms is None or tuple(uniforms.shape) != (K, k):
+            raise RuntimeError("acmil_amd: uniforms must be [K,k]")
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+    ws = torch.empty(lib.acmil_stkim_workspace_bytes(N, K, k), dtype=torch.uint8, device=dev)
+    rc = lib.acmil_stkim_select(scores.data_ptr(), N, K, k, m, _ptr(uniforms) if m > 0 else None, topk.data_ptr(),
+                                midx.data_ptr() if m > 0 else None, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_stkim_select")
+    return topk, midx
+
+
+def ga_pool(h: torch.Tensor, A: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode,
+            masked_idx: Optional[torch.Tensor], want_afeat: bool = False, want_bag_feat: bool = False):
+    """acmil_ga_pool: masks A IN PLACE, then softmax / weighted sum / heads on the saved h."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _need_cuda(h, A)
+    N, dev = h.shape[0], h.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    sub = torch.empty(dims.K, dims.C, **f32)
+    slide = torch.empty(dims.C, **f32) if dims.has_bag_head else None
+    af = torch.empty(dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(dims.Di, **f32) if want_bag_feat else None
+    m = 0 if masked_idx is None else masked_idx.shape[1]
+    ws = _workspace(N, dims, mode, dev)
+    rc = lib.acmil_ga_pool(h.data_ptr(), A.data_ptr(), N, packed.data_ptr(), *dims.args(), mode,
+                           _ptr(masked_idx) if m > 0 else None, m, sub.data_ptr(), _ptr(slide), _ptr(af), _ptr(bf),
+                           int(dims.has_bag_head), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_pool")
+    out = {"sub_preds": sub, "A_out": A}
+    for k, v in (("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out

@@ -1,0 +1,119 @@
+/* acmil_hip.h -- C ABI of libacmil_hip.so: MI355X (gfx950) kernels for ACMIL's per-slide
+ * gated-attention aggregation path.
+ *
+ * The reference (dazhangyu123/ACMIL) has no FFI / plugin layer: its replaceable unit is the
+ * torch.nn.Module.  These entry points are what a maintainer would bind from
+ * `architecture/transformer.py` with ctypes; each one cites the reference code it
+ * replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer unless marked "host"; the caller (PyTorch's caching allocator in
+ *     the shipped host code) owns every buffer including `packed` and `workspace`; the library allocates
+ *     nothing and keeps no global state, so it is re-entrant across threads and streams;
+ *   - `stream` is the caller's hipStream_t (0 = default stream); all work is enqueued on it, nothing
+ *     synchronises the device;
+ *   - return value: ACMIL_OK, or a negative ACMIL_ERR_* for a bad shape / unsupported configuration /
+ *     launch failure.  No exceptions, no aborts.  Asynchronous faults surface at the caller's next sync;
+ *   - all matrices are row-major, contiguous, fp32 unless a dtype argument says otherwise.
+ */
+#ifndef ACMIL_HIP_H
+#define ACMIL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACMIL_OK 0
+#define ACMIL_ERR_SHAPE (-1)       /* a dimension is out of range / not a supported multiple */
+#define ACMIL_ERR_UNSUPPORTED (-2) /* valid request this build has no kernel for */
+#define ACMIL_ERR_NULL (-3)        /* a required pointer is NULL */
+#define ACMIL_ERR_LAUNCH (-4)      /* hipLaunchKernel reported an error */
+#define ACMIL_ERR_ARCH (-5)        /* current device is not gfx950 */
+
+/* arithmetic mode of the two projection GEMMs (everything else is always fp32) */
+#define ACMIL_MODE_F32 0   /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fp32 fmaf chain        */
+#define ACMIL_MODE_F16X3 1 /* fp32-parity split: operands as f16 hi+lo, 3 f16 MFMAs per product, fp32 acc */
+#define ACMIL_MODE_F16 2   /* throughput: single f16 MFMA pass (NOT within the 1e-4 fp32 parity bound)     */
+
+/* element type of the bag matrix x[N,D] in HBM */
+#define ACMIL_DTYPE_F32 0
+#define ACMIL_DTYPE_F16 1
+#define ACMIL_DTYPE_BF16 2
+
+#define ACMIL_MAX_TOKENS 5  /* K = n_token supported by this build */
+#define ACMIL_MAX_CLASSES 16
+
+/* Library / build identification; returns a static string. */
+const char* acmil_version(void);
+
+/* 0 if the current HIP device is gfx950, else ACMIL_ERR_ARCH.  (host-side query; no kernel launch) */
+int acmil_check_device(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  Rearranges the parameters of ACMIL_GA / ABMIL
+ *   dimreduction.fc1.weight            W1 [Di,D]            (architecture/network.py:40, no bias)
+ *   attention.attention_V.0.{weight,bias}  Wv [Da,Di], bv [Da]  (architecture/transformer.py:247-250)
+ *   attention.attention_U.0.{weight,bias}  Wu [Da,Di], bu [Da]  (:252-255)
+ *   attention.attention_weights.{weight,bias}  Ww [K,Da], bw [K] (:257)
+ *   classifier.{i}.fc.{weight,bias}    Wc[i] [C,Di], bc[i] [C], i<K   (transformer.py:295-297)
+ *   Slide_classifier.fc.{weight,bias}  Ws [C,Di], bs [C]    (:301)   (NULL for ABMIL: no bag head)
+ * into the MFMA-fragment-ordered stream the forward kernel consumes.  Must be re-run whenever the
+ * parameters change (every optimiser step); it is one small launch.  `Wc`/`bc` are HOST arrays of K
+ * device pointers.  Da must be 128 (the reference's fixed ctor default D=128, transformer.py:292).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_packed_bytes(int D, int Di, int Da, int K, int C, int mode);
+
+int acmil_ga_pack_weights(const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                          const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                          const float* Ws, const float* bs, int D, int Di, int Da, int K, int C, int mode,
+                          void* packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused forward of one bag (no mask: eval, or the score pass of a training step).  Replaces
+ * ACMIL_GA.forward / forward_feature / ABMIL.forward for one slide
+ * (architecture/transformer.py:305-330, :332-352, :277-286; DimReduction network.py:49-57;
+ * Attention_Gated transformer.py:259-267; Classifier_1fc network.py:14-19):
+ *   h = relu(x W1^T); A = ((tanh(h Wv^T+bv) * sigmoid(h Wu^T+bu)) Ww^T + bw)^T          [K,N]
+ *   P = softmax_N(A); afeat = P h [K,Di]; sub_preds[k] = Wc[k] afeat[k] + bc[k]          [K,C]
+ *   bag_feat = mean_k afeat [Di]; slide_pred = Ws bag_feat + bs                          [C]
+ * x: [N,D] of x_dtype (the reference's x[0]; B must be 1).  Outputs, each may be NULL to skip:
+ *   A_out [K,N] raw scores (the reference's third return value without its leading 1),
+ *   sub_preds [K,C], slide_pred [C] (only if has_bag_head), afeat [K,Di], bag_feat [Di],
+ *   h_save [N,Di] fp32 (kept for the masked pooling pass and the backward of a training step).
+ * If sub_preds, slide_pred, afeat and bag_feat are all NULL only the scores (and h_save) are produced.
+ * ABMIL = K 1, has_bag_head 0: its logits are sub_preds[0].
+ * workspace: acmil_ga_workspace_bytes(...) bytes, 256-byte aligned (may be NULL for a scores-only call).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
+
+int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K, int C,
+                     int mode, float* A_out, float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
+                     float* h_save, int has_bag_head, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked pooling pass of a training step.  Replaces transformer.py:318-330 given the scores and h of the
+ * score pass: A[k, masked_idx[k,:]] = -1e9 (written in place into A, which then IS the reference's A_out),
+ * P = softmax_N(A), afeat = P h, heads as above.  masked_idx [K,n_masked] int64 (device) from
+ * acmil_stkim_select; n_masked may be 0 (no mask: identical maths to the fused forward).
+ * ------------------------------------------------------------------------------------------- */
+int acmil_ga_pool(const float* h, float* A, int N, const void* packed, int D, int Di, int Da, int K, int C, int mode,
+                  const int64_t* masked_idx, int n_masked, float* sub_preds, float* slide_pred, float* afeat,
+                  float* bag_feat, int has_bag_head, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * STKIM selection.  Replaces transformer.py:314-317: top-k of each branch's scores (sorted by descending
+ * score, ties broken towards the LOWER index), then the first m = int(k*mask_drop) columns of
+ * argsort(uniforms[K,k]) pick which of them are masked.  `uniforms` are the caller's U[0,1) draws (the
+ * reference draws torch.rand(K,k)); injecting them keeps the op deterministic and testable.
+ *   scores [K,N] fp32, k = min(n_masked_patch, N) <= 64, topk_idx [K,k] int64, masked_idx [K,m] int64.
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_stkim_workspace_bytes(int N, int K, int k);
+
+int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
+                       int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACMIL_HIP_H */
