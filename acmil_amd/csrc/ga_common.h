@@ -14,8 +14,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define GA_DA 128           // attention hidden width, fixed by the reference (transformer.py:292)
-#define GA_WAVES 4          // waves per workgroup; each wave owns 32 consecutive patches
-#define GA_ROWS_PER_WG 128  // 4 waves x 32 patches
+#define GA_WAVES 8          // waves per workgroup (2 per SIMD); each wave owns 32 consecutive patches
+#define GA_ROWS_PER_WG 256  // 8 waves x 32 patches (fused forward tile)
+#define GA_POOL_ROWS 128    // rows per workgroup of the h-streaming pooling kernel (ga_train.hip)
 #define GA_FRAG_ROW 1024    // one "fragment row" of the packed weight stream: 64 lanes x 16 B
 
 // Row index inside a 32x32 MFMA C/D tile held by (register r, lane-half hi): the gfx950 C/D map is
@@ -25,7 +26,7 @@ __host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3)
 // ---------------------------------------------------------------------------------------------------
 // Packed-weight buffer layout (built by ga_pack.hip, consumed by ga_forward.hip).  All offsets in bytes.
 //
-//  g1 : GEMM1 operand stream, (D/64) macro-steps x 8 x ND fragment rows (ND = Di/32 output tiles)
+//  g1 : GEMM1 operand stream, (D/16) steps x 2 x ND fragment rows (ND = Di/32 output tiles)
 //  g2 : GEMM2 operand stream, 2 unit-groups x ND x 16 fragment rows   (both: half as many rows in MODE_F16)
 //  tab: bv[128], bu[128], Ww[K][128]  raw fp32 (the C/D register quad (4rq..4rq+3) of tile pair p in lane
 //       half hi covers the 4 CONSECUTIVE units 32p + 8rq + 4hi + {0..3}, so the epilogue reads plain float4s)
@@ -59,11 +60,12 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
 //   part[tile][k][0] = running max m, [1] = sum l, [2 .. 2+Di) = sum_n exp(s-m) h[n][:]
 __host__ __device__ static inline size_t ga_part_stride(int Di) { return (size_t)(2 + Di); }
 __host__ __device__ static inline int ga_num_tiles(int N) { return (N + GA_ROWS_PER_WG - 1) / GA_ROWS_PER_WG; }
+__host__ __device__ static inline int ga_pool_tiles(int N) { return (N + GA_POOL_ROWS - 1) / GA_POOL_ROWS; }
 
 static inline int ga_check_dims(int D, int Di, int Da, int K, int C) {
     if (Da != GA_DA) return ACMIL_ERR_UNSUPPORTED;
     if (D <= 0 || Di <= 0 || K <= 0 || C <= 0) return ACMIL_ERR_SHAPE;
-    if (D % 64 != 0 || Di % 128 != 0) return ACMIL_ERR_SHAPE;
+    if (D % 64 != 0 || Di % 64 != 0) return ACMIL_ERR_SHAPE;
     if (K > ACMIL_MAX_TOKENS || C > ACMIL_MAX_CLASSES) return ACMIL_ERR_UNSUPPORTED;
     return ACMIL_OK;
 }

@@ -2,42 +2,60 @@
 // kernels that finish it: ga_merge_kernel (fixed-order combine of the per-workgroup online-softmax
 // partials) and ga_heads_kernel (K branch heads + bag head).  The fused kernel itself is
 // ga_forward_kernel.h, instantiated per family in ga_forward_inst.hip.
+#include <stdlib.h>
+
 #include "ga_forward_kernel.h"
 
 // ------------------------------------------------------------------------------------------------
 // merge: afeat[k][:] = (sum_t e^{m_t-M} acc_t) / (sum_t e^{m_t-M} l_t), fixed summation order.
-// grid (K, Di/64), 256 threads = 4 groups of 64 lanes; lane = feature, group g takes tiles g, g+4, ...
+// grid (K, Di/64), 1024 threads = 16 groups of 64 lanes; lane = feature, group g takes tiles g, g+16, ...
+// Loads of up to 4 tiles are issued together (the loop is latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ga_merge_kernel(const float* __restrict__ part, int tiles, int K, int Di,
-                                                       float* __restrict__ afeat) {
-    __shared__ float red[4][66];
-    __shared__ float smx[4];
+#define GA_MERGE_GROUPS 16
+__global__ __launch_bounds__(1024) void ga_merge_kernel(const float* __restrict__ part, int tiles, int K, int Di,
+                                                        float* __restrict__ afeat) {
+    __shared__ float red[GA_MERGE_GROUPS][66];
+    __shared__ float smx[GA_MERGE_GROUPS];
     const int k = blockIdx.x, c = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const size_t PS = 2 + Di;
     const float* base = part + (size_t)k * PS;
     const size_t tstride = (size_t)K * PS;
     float m = -INFINITY;
-    for (int t = tid; t < tiles; t += 256) m = fmaxf(m, base[t * tstride]);
+    for (int t = tid; t < tiles; t += 1024) m = fmaxf(m, base[t * tstride]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) smx[g] = m;
     __syncthreads();
-    const float M = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    float M = smx[0];
+#pragma unroll
+    for (int w = 1; w < GA_MERGE_GROUPS; ++w) M = fmaxf(M, smx[w]);
     float acc = 0.0f, l = 0.0f;
     const int di = 64 * c + lane;
-    for (int t = g; t < tiles; t += 4) {
-        const float* p = base + t * tstride;
-        const float f = __expf(p[0] - M);
-        l = fmaf(f, p[1], l);
-        acc = fmaf(f, p[2 + di], acc);
+    for (int t0 = g; t0 < tiles; t0 += 4 * GA_MERGE_GROUPS) {
+        float pm[4], pl[4], pa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * GA_MERGE_GROUPS;
+            const float* p = base + (size_t)(t < tiles ? t : t0) * tstride;
+            pm[u] = p[0]; pl[u] = p[1]; pa[u] = p[2 + di];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t0 + u * GA_MERGE_GROUPS < tiles) {
+                const float f = __expf(pm[u] - M);
+                l = fmaf(f, pl[u], l);
+                acc = fmaf(f, pa[u], acc);
+            }
+        }
     }
     red[g][lane] = acc;
     if (lane == 0) red[g][64] = l;
     __syncthreads();
     if (g == 0) {
-        const float A = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-        const float Ls = ((red[0][64] + red[1][64]) + red[2][64]) + red[3][64];
+        float A = 0.0f, Ls = 0.0f;
+#pragma unroll
+        for (int w = 0; w < GA_MERGE_GROUPS; ++w) { A += red[w][lane]; Ls += red[w][64]; }
         afeat[(size_t)k * Di + di] = A / Ls;
     }
 }
@@ -101,7 +119,7 @@ static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hip
 extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode) {
     (void)D; (void)C; (void)mode;
     if (N <= 0 || Di <= 0 || K <= 0) return 0;
-    size_t b = (size_t)ga_num_tiles(N) * K * ga_part_stride(Di) * sizeof(float);  // partials
+    size_t b = (size_t)ga_pool_tiles(N) * K * ga_part_stride(Di) * sizeof(float);  // partials (pool tiles >= fused tiles)
     b = (b + 255) & ~(size_t)255;
     b += (size_t)K * Di * sizeof(float);                                          // afeat scratch
     return (b + 255) & ~(size_t)255;
@@ -113,7 +131,7 @@ int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& 
     const int K = L.K, Di = L.Di;
     size_t poff = ((size_t)tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     float* af = afeat ? afeat : (float*)((char*)workspace + poff);
-    hipLaunchKernelGGL(ga_merge_kernel, dim3(K, Di / 64), dim3(256), 0, st, part, tiles, K, Di, af);
+    hipLaunchKernelGGL(ga_merge_kernel, dim3(K, Di / 64), dim3(1024), 0, st, part, tiles, K, Di, af);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     if (sub_preds || slide_pred || bag_feat) {
         const size_t lds = ((size_t)K * Di + Di) * sizeof(float);
@@ -139,6 +157,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     GaFwdArgs a;
     a.x = x; a.packed = (const char*)packed; a.A_out = A_out; a.part = (float*)workspace; a.h_save = h_save; a.N = N;
     a.L = ga_layout(D, Di, K, C, mode);
+    { const char* e = getenv("ACMIL_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     if (!pool && !h_save) {
         // scores only: run the pooled variant into the workspace and drop its partials
         if (!workspace) return ACMIL_ERR_NULL;

@@ -6,18 +6,19 @@
 //   ACMIL_GA.forward            architecture/transformer.py:322-324 softmax over N, P h   (heads: ga_forward.hip)
 //
 // Design (one pass over x, no intermediate ever touches HBM):
-//   * grid = ceil(N/128) workgroups x 4 waves; every wave owns 32 consecutive patches end to end, so there
-//     is no inter-wave data dependence in the GEMM chain -- the workgroup only shares the weight stream.
+//   * grid = ceil(N/256) workgroups x 8 waves (2 per SIMD, <=256 registers each); every wave owns 32
+//     consecutive patches end to end, so there is no inter-wave data dependence in the GEMM chain -- the
+//     workgroup only shares the weight stream (one pass of the packed weights serves 256 patches).
 //   * both GEMMs are computed TRANSPOSED (D = W * x^T): patches live on the MFMA column index (= lane&31),
 //     output features on the accumulator registers.  An accumulator register file in that layout IS the
 //     B operand of the next MFMA chain (K index = register index, lane = column), so relu(h) feeds GEMM2
 //     straight from registers; the K-slot permutation this implies is folded into the weight packing.
-//   * weights arrive as a pre-packed fragment stream (ga_pack.hip): staged into LDS by linear
-//     global_load_lds (LDS-DMA, no VGPR round trip), double buffered, one barrier per stage; A operands are
-//     read with lane-linear conflict-free ds_read_b128.
-//   * x is read exactly once, straight from HBM into the B operand registers (each lane 128 contiguous
-//     bytes per 64-wide K macro-step, prefetched one macro-step ahead).
-//   * GEMM2 runs in two groups of 64 attention units (4 MFMA tiles: tanh/sigmoid branch x 2) so only 64
+//   * ALL global reads of the main loop are LDS-DMA (global_load_lds, 16 B/lane): the pre-packed weight
+//     fragment stream (linear copy) and the x tile (full 64-B / 32-B row segments per lane group, XOR
+//     swizzled on the SOURCE address so the B-fragment ds_read_b128 is bank-conflict free).  They land in a
+//     4-slot ring; a step (16 K-values of GEMM1, or one 32-feature slice of GEMM2) waits with a COUNTED
+//     s_waitcnt vmcnt(N) that leaves the next two steps' loads in flight, then one raw s_barrier.
+//   * GEMM2 runs in four blocks of 32 attention units (2 MFMA tiles: tanh / sigmoid branch) so only 32
 //     accumulator registers are live next to the 128 that hold h; biases are the accumulator init.
 //   * epilogue in registers: tanh/sigmoid gate, K-way score dot with Ww (per-lane partial + one cross-half
 //     shuffle), A_out store, wave-level online-softmax statistics; the attention-weighted sum P h transposes
@@ -38,113 +39,117 @@ struct GaFwdArgs {
     float* part;     // workspace partials [tiles][K][2+Di]
     float* h_save;   // [N,Di] or null
     int N;
+    int ablate;      // debug only (env ACMIL_ABLATE): 1 = no weight staging, 2 = no x staging, 4 = stop after scores
     GaLayout L;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int ROWS>
-__device__ __forceinline__ void ga_stage_copy(const char* gsrc, char* lbuf, int wave, int lane) {
-#pragma unroll
-    for (int r = 0; r < ROWS / GA_WAVES; ++r) {
-        const int row = r * GA_WAVES + wave;
-        __builtin_amdgcn_global_load_lds((gptr_t)(gsrc + (size_t)row * GA_FRAG_ROW + lane * 16),
-                                         (lptr_t)(lbuf + row * GA_FRAG_ROW), 16, 0, 0);
-    }
+#define GA_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc), (lptr_t)(ldst), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void ga_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ void ga_sync_stage() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-}
-
-// ---- load one 64-wide K macro-step of this lane's patch row: 32 consecutive elements -> fp32 registers
-template <int XDT>
-__device__ __forceinline__ void ga_load_x(const void* xrow, int t, f32x4 (&dst)[8]) {
-    if constexpr (XDT == ACMIL_DTYPE_F32) {
-        const f32x4* p = (const f32x4*)((const float*)xrow + 64 * t);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q] = __builtin_nontemporal_load(p + q);
-    } else {
-        const u32x4* p = (const u32x4*)((const uint16_t*)xrow + 64 * t);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u32x4 w = __builtin_nontemporal_load(p + q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float lo, hi;
-                if constexpr (XDT == ACMIL_DTYPE_F16) {
-                    lo = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[e] & 0xffffu));
-                    hi = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[e] >> 16));
-                } else {
-                    lo = __builtin_bit_cast(float, w[e] << 16);
-                    hi = __builtin_bit_cast(float, w[e] & 0xffff0000u);
-                }
-                dst[2 * q + (e >> 1)][2 * (e & 1) + 0] = lo;
-                dst[2 * q + (e >> 1)][2 * (e & 1) + 1] = hi;
-            }
-        }
-    }
-}
-
-template <int ND, int KP, int MODE>
+template <int ND, int KP, int MODE, int XDT>
 struct GaGeom {
-    static constexpr int SPM = (MODE == ACMIL_MODE_F16) ? 1 : 2;     // stages per 64-wide macro-step
-    static constexpr int R1 = 4 * ND;                                // fragment rows per GEMM1 stage
-    static constexpr int R2 = (MODE == ACMIL_MODE_F16) ? 8 : 16;     // rows per GEMM2 stage (group g, h tile d)
-    static constexpr int STAGE_BYTES = (R1 > R2 ? R1 : R2) * GA_FRAG_ROW;
-    static constexpr int POOLW = 128 * 33 * 4;                       // wave-private [128 di][32 m (+1 pad)] fp32
-    static constexpr int REGION0 = (2 * STAGE_BYTES > GA_WAVES * POOLW) ? 2 * STAGE_BYTES : GA_WAVES * POOLW;
-    static constexpr int TAB_OFF = REGION0;                          // bv[128], bu[128], Ww[KP][128]
+    static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;       // bytes per bag element
+    static constexpr int WROWS1 = (MODE == ACMIL_MODE_F16) ? ND : 2 * ND;  // fragment rows per GEMM1 step
+    static constexpr int WROWS2 = (MODE == ACMIL_MODE_F16) ? 8 : 16;       // fragment rows per GEMM2 step (g, d)
+    static constexpr int WG1 = (WROWS1 + GA_WAVES - 1) / GA_WAVES;    // weight LDS-DMA instructions per wave per step
+    static constexpr int WG2 = (WROWS2 + GA_WAVES - 1) / GA_WAVES;
+    static constexpr int XG = 32 * 16 * XE / 1024;                    // x LDS-DMA instructions per wave per step
+    static constexpr int N1 = WG1 + XG, N2 = WG2;                     // VMEM ops per wave per GEMM1 / GEMM2 step
+    static constexpr int WSLOT = ((WROWS1 > WROWS2 ? WROWS1 : WROWS2) + GA_WAVES - 1) / GA_WAVES * GA_WAVES * GA_FRAG_ROW;
+    static constexpr int XB = 32 * 16 * XE;                           // x bytes per wave per step
+    static constexpr int SLOT = WSLOT + GA_WAVES * XB;
+    static constexpr int NB = 4;                                      // ring slots; prefetch distance NB-1 steps
+    static constexpr int RING = NB * SLOT;
+    static constexpr int POOLW = 64 * 36 * 4;                         // wave-private [64 di][32 m (+4 pad)] fp32
+    static constexpr int REGION0 = (RING > GA_WAVES * POOLW) ? RING : GA_WAVES * POOLW;
+    static constexpr int TAB_OFF = REGION0;                           // bv[128], bu[128], Ww[KP][128]
     static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4;
-    static constexpr int KP4 = (KP + 3) / 4 * 4;
-    static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;               // p_lds: [wave][32 m][KP4] fp32
-    static constexpr int PL_BYTES = GA_WAVES * 32 * KP4 * 4;
+    static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;                // p_lds: [wave][KP][32 m] fp32
+    static constexpr int PL_BYTES = GA_WAVES * KP * 32 * 4;
     static constexpr int LDS = PL_OFF + PL_BYTES;
 };
 
 template <int ND, int KP, int MODE, int XDT, bool POOL, bool SAVEH>
-__global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
+__global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = GaGeom<ND, KP, MODE>;
+    using G = GaGeom<ND, KP, MODE, XDT>;
     constexpr bool F32M = (MODE == ACMIL_MODE_F32);
     constexpr bool SPLIT = (MODE == ACMIL_MODE_F16X3);
     constexpr bool XLO = SPLIT && (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
-    constexpr int SPM = G::SPM, R1 = G::R1, R2 = G::R2, STAGE_BYTES = G::STAGE_BYTES, POOLW = G::POOLW;
-    constexpr int KP4 = G::KP4;
-    constexpr int NCH = ND / 4;                                // pooling chunks of 128 features
     constexpr int PARTS = SPLIT ? 2 : 1;
+    constexpr int NCH = ND / 2;                                // pooling chunks of 64 features
+    constexpr int Di = ND * 32;
 
     const GaLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i31 = lane & 31, hi = lane >> 5;
     const int N = a.N, D = L.D, K = L.K;
-    constexpr int Di = ND * 32;
-    const int T = D / 64;
     const int m0 = blockIdx.x * GA_ROWS_PER_WG + wave * 32;
     const int row = m0 + i31;
     const bool valid = row < N;
-    const int rowc = valid ? row : N - 1;
-    const size_t xelem = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;
-    const char* xrow = (const char*)a.x + ((size_t)rowc * D + 32 * hi) * xelem;
+    const int ablate = a.ablate;
 
     const char* g1 = a.packed + L.g1_off;
     const char* g2 = a.packed + L.g2_off;
-    const int S1 = T * SPM;
+    const int S1 = D / 16;                 // GEMM1 steps
+    constexpr int S2 = 2 * ND;             // GEMM2 steps (unit block g of 4, h tile pair dp)
 
-    auto issue_stage = [&](int s) {
-        char* buf = smem + (s & 1) * STAGE_BYTES;
-        if (s < S1) ga_stage_copy<R1>(g1 + (size_t)s * R1 * GA_FRAG_ROW, buf, wave, lane);
-        else if (s < S1 + 2 * ND) ga_stage_copy<R2>(g2 + (size_t)(s - S1) * R2 * GA_FRAG_ROW, buf, wave, lane);
+    // ---- per-lane source pointer of the x tile copy.  fp32: 2 instructions/step, lane l -> (row 16q + l/4, 16-B piece
+    // (l&3) ^ swz(row)); 16-bit: 1 instruction, lane l -> (row l/2, piece (l&1) ^ swz(row)).  LDS image is lane-linear.
+    const char* xsrc[G::XG];
+#pragma unroll
+    for (int q = 0; q < G::XG; ++q) {
+        int r, piece;
+        if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
+        else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
+        int gr = m0 + r;
+        gr = gr < N ? gr : N - 1;
+        xsrc[q] = (const char*)a.x + (size_t)gr * D * G::XE + piece * 16;
+    }
+
+    auto issue_step = [&](int s) {
+        char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
+        if (s < S1) {
+            if (!(ablate & 1)) {
+                const char* src = g1 + (size_t)s * G::WROWS1 * GA_FRAG_ROW + lane * 16;
+#pragma unroll
+                for (int q = 0; q < G::WG1; ++q) {
+                    int r = q * GA_WAVES + wave;
+                    r = (G::WROWS1 % GA_WAVES == 0) ? r : (r % G::WROWS1);   // padded rows re-fetch a valid row
+                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * GA_WAVES + wave) * GA_FRAG_ROW);
+                }
+            }
+            if (!(ablate & 2)) {
+                char* xdst = slot + G::WSLOT + wave * G::XB;
+#pragma unroll
+                for (int q = 0; q < G::XG; ++q) GA_GLDS16(xsrc[q] + (size_t)s * 16 * G::XE, xdst + q * 1024);
+            }
+        } else if (s < S1 + S2) {
+            if (!(ablate & 1)) {
+                const char* src = g2 + (size_t)(s - S1) * G::WROWS2 * GA_FRAG_ROW + lane * 16;
+#pragma unroll
+                for (int q = 0; q < G::WG2; ++q) {
+                    int r = q * GA_WAVES + wave;
+                    r = (G::WROWS2 % GA_WAVES == 0) ? r : (r % G::WROWS2);
+                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * GA_WAVES + wave) * GA_FRAG_ROW);
+                }
+            }
+        }
     };
 
-    // epilogue vectors bv, bu, Ww -> LDS (rows K..KP-1 of Ww zero); visible after the first stage barrier
+    // epilogue vectors bv, bu, Ww -> LDS (rows K..KP-1 of Ww zero); visible after the first step barrier
     {
         const float* src = (const float*)(a.packed + L.tab_off);
         float* dst = (float*)(smem + G::TAB_OFF);
-        for (int e = tid; e < (2 + KP) * GA_DA; e += 256) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
+        for (int e = tid; e < (2 + KP) * GA_DA; e += 512) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
     }
 
     f32x16 acc1[ND];
@@ -153,75 +158,90 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[d][r] = 0.0f;
 
-    f32x4 xr[8], xn[8];
-    ga_load_x<XDT>(xrow, 0, xr);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) xn[q] = xr[q];
-    issue_stage(0);
+    issue_step(0);
+    issue_step(1);
+    issue_step(2);
 
     // =========================================================== GEMM1: h^T = W1 * x^T
-    for (int t = 0; t < T; ++t) {
-        f16x8 xh[4], xl[4];
-        if constexpr (!F32M) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = xr[2 * s + (j >> 2)][j & 3];
-                    const _Float16 h16 = (_Float16)v;
-                    xh[s][j] = h16;
-                    if constexpr (XLO) xl[s][j] = (_Float16)(v - (float)h16);
-                }
-        }
-#pragma unroll
-        for (int half = 0; half < SPM; ++half) {
-            const int s = t * SPM + half;
-            ga_sync_stage();
-            issue_stage(s + 1);
-            if (half == 0 && t + 1 < T) ga_load_x<XDT>(xrow, t + 1, xn);
-            const char* buf = smem + (s & 1) * STAGE_BYTES;
+    // lane (m = lane&31, hi) owns the K-slots k = 16s + 8hi + j (j<8) of step s
+    const int xrd0 = G::WSLOT + wave * G::XB +
+                     ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
+    const int xrd1 = G::WSLOT + wave * G::XB + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
+    for (int s = 0; s < S1; ++s) {
+        if (s < S1 - 2) ga_wait_vm<2 * G::N1>(); else ga_wait_vm<2 * G::N2>();
+        __builtin_amdgcn_s_barrier();
+        issue_step(s + 3);
+        const char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
+        float xv[8];
+        f16x8 xh, xl;
+        if constexpr (XDT == ACMIL_DTYPE_F32) {
+            const f32x4 a0 = *(const f32x4*)(slot + xrd0), a1 = *(const f32x4*)(slot + xrd1);
+            xv[0] = a0[0]; xv[1] = a0[1]; xv[2] = a0[2]; xv[3] = a0[3];
+            xv[4] = a1[0]; xv[5] = a1[1]; xv[6] = a1[2]; xv[7] = a1[3];
+        } else if constexpr (XDT == ACMIL_DTYPE_F16) {
+            xh = *(const f16x8*)(slot + xrd0);
             if constexpr (F32M) {
-                const f32x4* wb = (const f32x4*)buf + lane;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 wf[ND];
+                for (int j = 0; j < 8; ++j) xv[j] = (float)xh[j];
+            }
+        } else {
+            const u32x4 w = *(const u32x4*)(slot + xrd0);
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) wf[d] = wb[(g * ND + d) * 64];
+            for (int e = 0; e < 4; ++e) {
+                xv[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+                xv[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            }
+        }
+        if constexpr (!F32M && XDT != ACMIL_DTYPE_F16) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 h16 = (_Float16)xv[j];
+                xh[j] = h16;
+                if constexpr (XLO) xl[j] = (_Float16)(xv[j] - (float)h16);
+            }
+        }
+        if constexpr (F32M) {
+            const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
-                        for (int d = 0; d < ND; ++d)
-                            acc1[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[d][q], xr[4 * half + g][q], acc1[d], 0, 0, 0);
-                }
-            } else {
-                const f16x8* wb = (const f16x8*)buf + lane;
-                constexpr int KS = 4 / SPM;       // 16-wide k-steps per stage
+            for (int half = 0; half < 2; ++half) {
+                f32x4 wf[ND];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int s4 = half * KS + ks;
+                for (int d = 0; d < ND; ++d) wf[d] = wb[(d * 2 + half) * 64];
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        const f16x8 wh = wb[((ks * ND + d) * PARTS + 0) * 64];
-                        acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s4], acc1[d], 0, 0, 0);
-                        if constexpr (SPLIT) {
-                            const f16x8 wl = wb[((ks * ND + d) * PARTS + 1) * 64];
-                            acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s4], acc1[d], 0, 0, 0);
-                            if constexpr (XLO) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s4], acc1[d], 0, 0, 0);
-                        }
-                    }
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int d = 0; d < ND; ++d)
+                        acc1[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[d][q], xv[4 * half + q], acc1[d], 0, 0, 0);
+            }
+        } else {
+            const f16x8* wb = (const f16x8*)slot + lane;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const f16x8 wh = wb[(d * PARTS + 0) * 64];
+                acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1[d], 0, 0, 0);
+                if constexpr (SPLIT) {
+                    const f16x8 wl = wb[(d * PARTS + 1) * 64];
+                    acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc1[d], 0, 0, 0);
+                    if constexpr (XLO) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc1[d], 0, 0, 0);
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) xr[q] = xn[q];
     }
 
+#if defined(GA_CUT) && GA_CUT == 1
+    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += acc1[d][r]; a.part[tid] = t; return; }
+#endif
     // =========================================================== relu
     // acc1[d][r] now holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)]
 #pragma unroll
     for (int d = 0; d < ND; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
+    // keep the relu (and the f16 split below) HERE: LLVM otherwise sinks them into the GEMM2 steps that use
+    // them, the old accumulator tuples stay live next to the new values and the kernel spills hundreds of
+    // registers.  An empty volatile asm makes each value opaque at this point.
+#pragma unroll
+    for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
 
     f16x8 hh[F32M ? 1 : ND][2], hl[SPLIT ? ND : 1][2];
     if constexpr (!F32M) {
@@ -236,80 +256,96 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
                     hh[d][e][j] = h16;
                     if constexpr (SPLIT) hl[d][e][j] = (_Float16)(v - (float)h16);
                 }
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                asm volatile("" : "+v"(hh[d][e]));
+                if constexpr (SPLIT) asm volatile("" : "+v"(hl[d][e]));
+            }
     }
 
-    // =========================================================== GEMM2 (two unit groups) + gate + scores
+#if defined(GA_CUT) && GA_CUT == 4
+    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += F32M ? acc1[d][r] : (float)hh[d][r>>3][r&7] + (SPLIT ? (float)hl[d][r>>3][r&7] : 0.f); a.part[tid] = t; return; }
+#endif
+    // =========================================================== GEMM2 (four unit blocks) + gate + scores
     const float* tabf = (const float*)(smem + G::TAB_OFF);
     float sc[KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) sc[k] = 0.0f;
 
+    // (rolled on purpose: one copy of the block body keeps hipcc's scheduler from hoisting loads of later blocks)
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        // unit block g = units 32g..32g+31: accumulator tile al = 0 tanh branch, 1 sigmoid branch;
+        // register r of lane half hi is unit 32g + mfma32_row(r,hi); init = bias
+        f32x16 acc2[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        // accumulator tiles: al = 0..3 -> (tanh, sigmoid) branch of unit pair-block p = 2g + (al>>1);
-        // register r of lane half hi is unit 32p + mfma32_row(r,hi); init = bias
-        f32x16 acc2[4];
-#pragma unroll
-        for (int al = 0; al < 4; ++al)
+        for (int al = 0; al < 2; ++al)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int p = 2 * g + (al >> 1);
-                const f32x4 b = *(const f32x4*)(tabf + (al & 1) * GA_DA + 32 * p + 8 * rq + 4 * hi);
+                int boff = 32 * g + 8 * rq + 4 * hi;
+                asm volatile("" : "+v"(boff) : "v"(sc[0]));   // order after the previous block's epilogue (see below)
+                const f32x4 b = *(const f32x4*)(tabf + al * GA_DA + boff);
                 acc2[al][4 * rq + 0] = b[0]; acc2[al][4 * rq + 1] = b[1];
                 acc2[al][4 * rq + 2] = b[2]; acc2[al][4 * rq + 3] = b[3];
             }
 #pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const int s = S1 + g * ND + d;
-            ga_sync_stage();
-            issue_stage(s + 1);
-            const char* buf = smem + (s & 1) * STAGE_BYTES;
-            if constexpr (F32M) {
-                const f32x4* wb = (const f32x4*)buf + lane;
+        for (int dp = 0; dp < ND / 2; ++dp) {
+            const int j = g * (ND / 2) + dp;     // GEMM2 step index, compile-time after unrolling
+            const int s = S1 + j;
+            if (j < S2 - 2) ga_wait_vm<2 * G::N2>(); else if (j == S2 - 2) ga_wait_vm<G::N2>(); else ga_wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            issue_step(s + 3);
+            const char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 wf[4];
+            for (int dd = 0; dd < 2; ++dd) {
+                const int d = 2 * dp + dd;
+                if constexpr (F32M) {
+                    const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
-                    for (int al = 0; al < 4; ++al) wf[al] = wb[(r4 * 4 + al) * 64];
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 w0 = wb[((dd * 4 + r4) * 2 + 0) * 64], w1 = wb[((dd * 4 + r4) * 2 + 1) * 64];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int al = 0; al < 4; ++al)
-                            acc2[al] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[al][q], acc1[d][4 * r4 + q], acc2[al], 0, 0, 0);
-                }
-            } else {
-                const f16x8* wb = (const f16x8*)buf + lane;
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) {
-                        const f16x8 wh = wb[((e * 4 + al) * PARTS + 0) * 64];
-                        acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[d][e], acc2[al], 0, 0, 0);
-                        if constexpr (SPLIT) {
-                            const f16x8 wl = wb[((e * 4 + al) * PARTS + 1) * 64];
-                            acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[d][e], acc2[al], 0, 0, 0);
-                            acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[d][e], acc2[al], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) {
+                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[q], acc1[d][4 * r4 + q], acc2[0], 0, 0, 0);
+                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[q], acc1[d][4 * r4 + q], acc2[1], 0, 0, 0);
                         }
                     }
-            }
-        }
-        // gate + partial scores for the 64 units of this group (this lane: 32 of them)
+                } else {
+                    const f16x8* wb = (const f16x8*)slot + lane;
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+                    for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int ubase = 32 * (2 * g + pl) + 8 * rq + 4 * hi;
-                float gate[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    gate[q] = ga_tanh(acc2[2 * pl][4 * rq + q]) * ga_sigmoid(acc2[2 * pl + 1][4 * rq + q]);
-#pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    const f32x4 w = *(const f32x4*)(tabf + (2 + k) * GA_DA + ubase);
-                    sc[k] = fmaf(gate[0], w[0], sc[k]); sc[k] = fmaf(gate[1], w[1], sc[k]);
-                    sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
+                        for (int al = 0; al < 2; ++al) {
+                            const f16x8 wh = wb[(((dd * 2 + e) * 2 + al) * PARTS + 0) * 64];
+                            acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[d][e], acc2[al], 0, 0, 0);
+                            if constexpr (SPLIT) {
+                                const f16x8 wl = wb[(((dd * 2 + e) * 2 + al) * PARTS + 1) * 64];
+                                acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[d][e], acc2[al], 0, 0, 0);
+                                acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[d][e], acc2[al], 0, 0, 0);
+                            }
+                        }
                 }
             }
+        }
+        // gate + partial scores for the 32 units of this block (this lane: 16 of them)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            int ubase = 32 * g + 8 * rq + 4 * hi;
+            float gate[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gate[q] = ga_tanh(acc2[0][4 * rq + q]) * ga_sigmoid(acc2[1][4 * rq + q]);
+            // hipcc otherwise hoists every table read of the epilogue (80+ registers) above the last GEMM2 step and
+            // spills them at once; tying the address to the gate value keeps each read next to its use.
+            asm volatile("" : "+v"(ubase) : "v"(gate[3]));
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const f32x4 w = *(const f32x4*)(tabf + (2 + k) * GA_DA + ubase);
+                sc[k] = fmaf(gate[0], w[0], sc[k]); sc[k] = fmaf(gate[1], w[1], sc[k]);
+                sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
+            }
+        }
     }
 
     const float* bwp = (const float*)(a.packed + L.bw_off);
@@ -330,73 +366,70 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
         lsum[k] = l;
     }
 
+#if defined(GA_CUT) && GA_CUT == 2
+    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += F32M ? acc1[d][r] : (float)hh[d][r>>3][r&7] + (SPLIT ? (float)hl[d][r>>3][r&7] : 0.f); a.part[tid] = t + smax[0] + lsum[0] + pe[0]; return; }
+#endif
+    if (ablate & 4) return;
     // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
-    __syncthreads();  // every wave is done with the stage buffers; region 0 becomes the pooling tiles
-    float* pool = (float*)(smem + wave * POOLW);
-    float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * 32 * KP4;
+    __syncthreads();  // every wave is done with the ring; region 0 becomes the pooling tiles
+    float* pool = (float*)(smem + wave * G::POOLW);
+    float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // [KP][32 m]
     if (POOL && hi == 0) {
 #pragma unroll
-        for (int k = 0; k < KP4; ++k) pl[i31 * KP4 + k] = (k < KP) ? pe[k < KP ? k : 0] : 0.0f;
+        for (int k = 0; k < KP; ++k) pl[k * 32 + i31] = pe[k];
     }
-    float pacc[NCH][2][KP];
+    float pacc[NCH][KP];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps)
-#pragma unroll
-            for (int k = 0; k < KP; ++k) pacc[c][ps][k] = 0.0f;
+        for (int k = 0; k < KP; ++k) pacc[c][k] = 0.0f;
 
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int dl = 0; dl < 4; ++dl)
+        for (int dl = 0; dl < 2; ++dl)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float hv;
-                if constexpr (F32M) hv = acc1[4 * c + dl][r];
-                else if constexpr (SPLIT) hv = (float)hh[4 * c + dl][r >> 3][r & 7] + (float)hl[4 * c + dl][r >> 3][r & 7];
-                else hv = (float)hh[4 * c + dl][r >> 3][r & 7];
-                pool[(dl * 32 + mfma32_row(r, hi)) * 33 + i31] = hv;
+                if constexpr (F32M) hv = acc1[2 * c + dl][r];
+                else if constexpr (SPLIT) hv = (float)hh[2 * c + dl][r >> 3][r & 7] + (float)hl[2 * c + dl][r >> 3][r & 7];
+                else hv = (float)hh[2 * c + dl][r >> 3][r & 7];
+                pool[(dl * 32 + mfma32_row(r, hi)) * 36 + i31] = hv;
             }
         __builtin_amdgcn_wave_barrier();
+        const f32x4* prow = (const f32x4*)(pool + lane * 36);     // lane = feature 64c + lane
+#pragma unroll 2
+        for (int mq = 0; mq < 8; ++mq) {
+            const f32x4 hv = prow[mq];
+            if constexpr (SAVEH) {
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
-            const int dil = 64 * ps + lane;
-            const float* prow = pool + dil * 33;
-#pragma unroll 4
-            for (int m = 0; m < 32; ++m) {
-                const float hv = prow[m];
-                if constexpr (SAVEH) {
-                    if (m0 + m < N) a.h_save[(size_t)(m0 + m) * Di + 128 * c + dil] = hv;
-                }
-                if constexpr (POOL) {
-                    float e[KP4];
+                for (int e = 0; e < 4; ++e)
+                    if (m0 + 4 * mq + e < N) a.h_save[(size_t)(m0 + 4 * mq + e) * Di + 64 * c + lane] = hv[e];
+            }
+            if constexpr (POOL) {
 #pragma unroll
-                    for (int f = 0; f < KP4 / 4; ++f) {
-                        const f32x4 v = *(const f32x4*)(pl + m * KP4 + 4 * f);
-                        e[4 * f + 0] = v[0]; e[4 * f + 1] = v[1]; e[4 * f + 2] = v[2]; e[4 * f + 3] = v[3];
-                    }
-#pragma unroll
-                    for (int k = 0; k < KP; ++k) pacc[c][ps][k] = fmaf(e[k], hv, pacc[c][ps][k]);
+                for (int k = 0; k < KP; ++k) {
+                    const f32x4 p = *(const f32x4*)(pl + k * 32 + 4 * mq);
+                    pacc[c][k] = fmaf(p[0], hv[0], pacc[c][k]); pacc[c][k] = fmaf(p[1], hv[1], pacc[c][k]);
+                    pacc[c][k] = fmaf(p[2], hv[2], pacc[c][k]); pacc[c][k] = fmaf(p[3], hv[3], pacc[c][k]);
                 }
             }
         }
     }
     if constexpr (!POOL) return;
 
-    // =========================================================== combine the 4 waves, publish the partial
+    // =========================================================== combine the 8 waves, publish the partial
     __builtin_amdgcn_wave_barrier();
-    const int PS = 2 + Di;
+    constexpr int PS = 2 + Di;
+    static_assert(KP * PS * 4 <= G::POOLW, "combine record must fit the wave's pooling tile");
     float* comb = pool;  // overlays this wave's (now dead) pooling tile
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (k < K) {
             if (lane == 0) { comb[k * PS + 0] = smax[k]; comb[k * PS + 1] = lsum[k]; }
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) comb[k * PS + 2 + 128 * c + 64 * ps + lane] = pacc[c][ps][k];
+            for (int c = 0; c < NCH; ++c) comb[k * PS + 2 + 64 * c + lane] = pacc[c][k];
         }
     }
     __syncthreads();
@@ -405,19 +438,19 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
         float mw[GA_WAVES], M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < GA_WAVES; ++w) {
-            mw[w] = ((const float*)(smem + w * POOLW))[k * PS + 0];
+            mw[w] = ((const float*)(smem + w * G::POOLW))[k * PS + 0];
             M = fmaxf(M, mw[w]);
         }
         float fw[GA_WAVES];
 #pragma unroll
         for (int w = 0; w < GA_WAVES; ++w) fw[w] = (mw[w] == -INFINITY) ? 0.0f : __expf(mw[w] - M);
-        for (int e = tid; e < PS; e += 256) {
+        for (int e = tid; e < PS; e += 512) {
             float v;
             if (e == 0) v = M;
             else {
                 v = 0.0f;
 #pragma unroll
-                for (int w = 0; w < GA_WAVES; ++w) v = fmaf(fw[w], ((const float*)(smem + w * POOLW))[k * PS + e], v);
+                for (int w = 0; w < GA_WAVES; ++w) v = fmaf(fw[w], ((const float*)(smem + w * G::POOLW))[k * PS + e], v);
             }
             out[k * PS + e] = v;
         }
@@ -427,9 +460,9 @@ __global__ __launch_bounds__(256) void ga_fwd_kernel(GaFwdArgs a) {
 // launcher for one (ND, KP, MODE, XDT) family; pool=true -> eval variant, else the h-saving score pass
 template <int ND, int KP, int MODE, int XDT>
 int ga_launch_fwd(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    using G = GaGeom<ND, KP, MODE>;
+    using G = GaGeom<ND, KP, MODE, XDT>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
-    const dim3 grid(ga_num_tiles(a.N)), block(256);
+    const dim3 grid(ga_num_tiles(a.N)), block(512);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, true, false>
                                    : ga_fwd_kernel<ND, KP, MODE, XDT, false, true>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)

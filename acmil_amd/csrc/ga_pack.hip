@@ -22,7 +22,7 @@ __device__ static inline void split_f16(float w, _Float16& hi, _Float16& lo) {
 
 // Row of [Wv;Wu] addressed by (a-tile at in 0..7, row i in 0..31): tiles alternate v,u so that the
 // accumulators of tiles 2p and 2p+1 hold tanh- and sigmoid-branch pre-activations of the SAME 32 units.
-// GEMM2 runs in two unit-groups g (tiles 4g..4g+3 = units 64g..64g+63) to halve its accumulator footprint.
+// GEMM2 runs in four unit blocks g4 (tiles 2*g4, 2*g4+1 = units 32*g4..32*g4+31): 32 accumulator registers live.
 __device__ static inline const float* vu_row(const GaPackArgs& a, int at, int i) {
     const int unit = 32 * (at >> 1) + i;
     return ((at & 1) ? a.Wu : a.Wv) + (size_t)unit * a.L.Di;
@@ -36,18 +36,18 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
     const int ND = L.ND;
     if (row < L.g1_rows) {
         char* dst = a.out + L.g1_off + row * GA_FRAG_ROW + lane * 16;
+        // GEMM1 step s covers k = 16s .. 16s+15; lane (i, hi) owns the 8 K-slots k = 16s + 8hi + j, j < 8
         if (L.mode == ACMIL_MODE_F32) {
-            // row = (t*8 + c4)*ND + d ; lane holds W1[32d+i][64t + 32hi + 4c4 + q], q<4
-            const int d = row % ND, c4 = (row / ND) % 8, t = row / ND / 8;
-            const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 64 * t + 32 * hi + 4 * c4;
+            // row = (s*ND + d)*2 + half ; lane holds W1[32d+i][16s + 8hi + 4half + q], q<4 (MFMA sub-step c = 4half+q)
+            const int half = row & 1, d = (row >> 1) % ND, st = (row >> 1) / ND;
+            const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 16 * st + 8 * hi + 4 * half;
             *(f32x4*)dst = *(const f32x4*)src;
         } else {
-            // F16X3: row = ((t*4 + s)*ND + d)*2 + part ; F16: row = (t*4 + s)*ND + d
-            // lane holds 8 f16: W1[32d+i][64t + 32hi + 8s + j], j<8
+            // F16X3: row = (s*ND + d)*2 + part ; F16: row = s*ND + d ; lane holds 8 f16 W1[32d+i][16s + 8hi + j]
             size_t r = row; int part = 0;
             if (L.mode == ACMIL_MODE_F16X3) { part = r & 1; r >>= 1; }
-            const int d = r % ND, s = (r / ND) % 4, t = r / ND / 4;
-            const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 64 * t + 32 * hi + 8 * s;
+            const int d = r % ND, st = r / ND;
+            const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 16 * st + 8 * hi;
             f16x8 v;
             for (int j = 0; j < 8; ++j) { _Float16 h, l; split_f16(src[j], h, l); v[j] = part ? l : h; }
             *(f16x8*)dst = v;
@@ -57,24 +57,28 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
     size_t r2 = row - L.g1_rows;
     if (r2 < L.g2_rows) {
         char* dst = a.out + L.g2_off + r2 * GA_FRAG_ROW + lane * 16;
+        // GEMM2 step j = g4*(ND/2) + dp: unit block g4 (tiles at = 2*g4 + al, al = 0 tanh / 1 sigmoid branch),
+        // h tiles d = 2*dp + dd.  K-slot <-> GEMM1 accumulator register of tile d (see header comment).
         if (L.mode == ACMIL_MODE_F32) {
-            // row = ((g*ND + d)*4 + r4)*4 + al, at = 4g + al ; lane holds Wvu[at,i][32d + 8r4 + 4hi + q]
-            const int al = r2 % 4, r4 = (r2 / 4) % 4, d = (r2 / 16) % ND, g = r2 / 16 / ND;
-            const int at = 4 * g + al;
+            // local row = (dd*4 + r4)*2 + al ; lane holds Wvu[at,i][32d + 8r4 + 4hi + q], q<4
+            const int loc = r2 % 16; const size_t j = r2 / 16;
+            const int al = loc & 1, r4 = (loc >> 1) & 3, dd = loc >> 3;
+            const int g4 = j / (ND / 2), d = 2 * (j % (ND / 2)) + dd, at = 2 * g4 + al;
             const float* src = vu_row(a, at, i) + 32 * d + 8 * r4 + 4 * hi;
             *(f32x4*)dst = *(const f32x4*)src;
         } else {
-            // F16X3: row = (((g*ND + d)*2 + e)*4 + al)*2 + part ; F16: row = ((g*ND + d)*2 + e)*4 + al ; at = 4g + al
-            // slot j <-> GEMM1 accumulator register 8e+j of tile d: di = 32d + (j&3) + 8(2e + (j>>2)) + 4hi
+            // F16X3: local row = ((dd*2 + e)*2 + al)*2 + part (16/step) ; F16: (dd*2 + e)*2 + al (8/step)
+            // slot jj <-> GEMM1 accumulator register 8e+jj of tile d: di = 32d + (jj&3) + 8(2e + (jj>>2)) + 4hi
             size_t r = r2; int part = 0;
             if (L.mode == ACMIL_MODE_F16X3) { part = r & 1; r >>= 1; }
-            const int al = r % 4, e = (r / 4) % 2, d = (r / 8) % ND, g = r / 8 / ND;
-            const int at = 4 * g + al;
+            const int loc = r % 8; const size_t j = r / 8;
+            const int al = loc & 1, e = (loc >> 1) & 1, dd = loc >> 2;
+            const int g4 = j / (ND / 2), d = 2 * (j % (ND / 2)) + dd, at = 2 * g4 + al;
             const float* src = vu_row(a, at, i);
             f16x8 v;
-            for (int j = 0; j < 8; ++j) {
-                const int di = 32 * d + (j & 3) + 8 * (2 * e + (j >> 2)) + 4 * hi;
-                _Float16 h, l; split_f16(src[di], h, l); v[j] = part ? l : h;
+            for (int jj = 0; jj < 8; ++jj) {
+                const int di = 32 * d + (jj & 3) + 8 * (2 * e + (jj >> 2)) + 4 * hi;
+                _Float16 h, l; split_f16(src[di], h, l); v[jj] = part ? l : h;
             }
             *(f16x8*)dst = v;
         }

@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
     float* stat = p_lds + 128 * KP;                  // [KP][2] : m, l
     float* red = stat + 2 * KP;                      // [RPI][KP][Di] cross-row-group reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * GA_ROWS_PER_WG;
-    const int rows = min(GA_ROWS_PER_WG, N - n0);
+    const int n0 = blockIdx.x * GA_POOL_ROWS;
+    const int rows = min(GA_POOL_ROWS, N - n0);
     // ---- tile statistics: wave w handles branches w, w+4, ...; 64 lanes x 2 rows each
     for (int k = wave; k < KP; k += 4) {
         float s0 = -INFINITY, s1 = -INFINITY;
@@ -217,7 +217,7 @@ extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     const GaLayout L = ga_layout(D, Di, K, C, mode);
-    const int tiles = ga_num_tiles(N);
+    const int tiles = ga_pool_tiles(N);
     float* part = (float*)workspace;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
     const int RPI = 256 / (Di / 4);
