@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libacmil_hip.so")
+LIB_PATH = os.environ.get("ACMIL_HIP_LIB", os.path.join(_HERE, "libacmil_hip.so"))  # env override: experiments only
 
 OK = 0
 ERRORS = {-1: "ACMIL_ERR_SHAPE", -2: "ACMIL_ERR_UNSUPPORTED", -3: "ACMIL_ERR_NULL", -4: "ACMIL_ERR_LAUNCH",

@@ -157,7 +157,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     GaFwdArgs a;
     a.x = x; a.packed = (const char*)packed; a.A_out = A_out; a.part = (float*)workspace; a.h_save = h_save; a.N = N;
     a.L = ga_layout(D, Di, K, C, mode);
-    { const char* e = getenv("ACMIL_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("ACMIL_GA_WAVES"); a.waves = (e && atoi(e) == 8) ? 8 : 4; }
     if (!pool && !h_save) {
         // scores only: run the pooled variant into the workspace and drop its partials
         if (!workspace) return ACMIL_ERR_NULL;
@@ -165,7 +165,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     rc = ga_dispatch(a, mode, x_dtype, pool, st);
     if (rc != ACMIL_OK || !pool) return rc;
-    return ga_finish(a.part, ga_num_tiles(N), packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
+    return ga_finish(a.part, (N + 32 * a.waves - 1) / (32 * a.waves), packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
                      workspace, st);
 }
 

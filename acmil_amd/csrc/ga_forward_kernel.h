@@ -39,7 +39,7 @@ struct GaFwdArgs {
     float* part;     // workspace partials [tiles][K][2+Di]
     float* h_save;   // [N,Di] or null
     int N;
-    int ablate;      // debug only (env ACMIL_ABLATE): 1 = no weight staging, 2 = no x staging, 4 = stop after scores
+    int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
     GaLayout L;
 };
 
@@ -53,33 +53,36 @@ __device__ __forceinline__ void ga_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int ND, int KP, int MODE, int XDT>
+template <int ND, int KP, int MODE, int XDT, int WAVES>
 struct GaGeom {
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;       // bytes per bag element
     static constexpr int WROWS1 = (MODE == ACMIL_MODE_F16) ? ND : 2 * ND;  // fragment rows per GEMM1 step
     static constexpr int WROWS2 = (MODE == ACMIL_MODE_F16) ? 8 : 16;       // fragment rows per GEMM2 step (g, d)
-    static constexpr int WG1 = (WROWS1 + GA_WAVES - 1) / GA_WAVES;    // weight LDS-DMA instructions per wave per step
-    static constexpr int WG2 = (WROWS2 + GA_WAVES - 1) / GA_WAVES;
+    static constexpr int WG1 = (WROWS1 + WAVES - 1) / WAVES;    // weight LDS-DMA instructions per wave per step
+    static constexpr int WG2 = (WROWS2 + WAVES - 1) / WAVES;
     static constexpr int XG = 32 * 16 * XE / 1024;                    // x LDS-DMA instructions per wave per step
     static constexpr int N1 = WG1 + XG, N2 = WG2;                     // VMEM ops per wave per GEMM1 / GEMM2 step
-    static constexpr int WSLOT = ((WROWS1 > WROWS2 ? WROWS1 : WROWS2) + GA_WAVES - 1) / GA_WAVES * GA_WAVES * GA_FRAG_ROW;
+    static constexpr int WSLOT = ((WROWS1 > WROWS2 ? WROWS1 : WROWS2) + WAVES - 1) / WAVES * WAVES * GA_FRAG_ROW;
     static constexpr int XB = 32 * 16 * XE;                           // x bytes per wave per step
-    static constexpr int SLOT = WSLOT + GA_WAVES * XB;
-    static constexpr int NB = 4;                                      // ring slots; prefetch distance NB-1 steps
+    static constexpr int SLOT = WSLOT + WAVES * XB;
+    static constexpr int NB = (WAVES == 8) ? 4 : 3;                   // ring slots (8-wave WG: 1 per CU; 4-wave WG: 2 per CU)
+    static constexpr int PD = NB - 1;                                 // prefetch distance in steps
+    static constexpr int ROWS = 32 * WAVES;                           // patches per workgroup
     static constexpr int RING = NB * SLOT;
     static constexpr int POOLW = 64 * 36 * 4;                         // wave-private [64 di][32 m (+4 pad)] fp32
-    static constexpr int REGION0 = (RING > GA_WAVES * POOLW) ? RING : GA_WAVES * POOLW;
+    static constexpr int REGION0 = (RING > WAVES * POOLW) ? RING : WAVES * POOLW;
     static constexpr int TAB_OFF = REGION0;                           // bv[128], bu[128], Ww[KP][128]
     static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4;
     static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;                // p_lds: [wave][KP][32 m] fp32
-    static constexpr int PL_BYTES = GA_WAVES * KP * 32 * 4;
+    static constexpr int PL_BYTES = WAVES * KP * 32 * 4;
     static constexpr int LDS = PL_OFF + PL_BYTES;
 };
 
-template <int ND, int KP, int MODE, int XDT, bool POOL, bool SAVEH>
-__global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
+template <int ND, int KP, int MODE, int XDT, int WAVES, bool POOL, bool SAVEH>
+__global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = GaGeom<ND, KP, MODE, XDT>;
+    using G = GaGeom<ND, KP, MODE, XDT, WAVES>;
+    constexpr int NTHR = 64 * WAVES;
     constexpr bool F32M = (MODE == ACMIL_MODE_F32);
     constexpr bool SPLIT = (MODE == ACMIL_MODE_F16X3);
     constexpr bool XLO = SPLIT && (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
@@ -92,10 +95,9 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i31 = lane & 31, hi = lane >> 5;
     const int N = a.N, D = L.D, K = L.K;
-    const int m0 = blockIdx.x * GA_ROWS_PER_WG + wave * 32;
+    const int m0 = blockIdx.x * G::ROWS + wave * 32;
     const int row = m0 + i31;
     const bool valid = row < N;
-    const int ablate = a.ablate;
 
     const char* g1 = a.packed + L.g1_off;
     const char* g2 = a.packed + L.g2_off;
@@ -116,30 +118,30 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
     }
 
     auto issue_step = [&](int s) {
-        char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
+        char* slot = smem + (s % G::NB) * G::SLOT;
         if (s < S1) {
-            if (!(ablate & 1)) {
-                const char* src = g1 + (size_t)s * G::WROWS1 * GA_FRAG_ROW + lane * 16;
-#pragma unroll
-                for (int q = 0; q < G::WG1; ++q) {
-                    int r = q * GA_WAVES + wave;
-                    r = (G::WROWS1 % GA_WAVES == 0) ? r : (r % G::WROWS1);   // padded rows re-fetch a valid row
-                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * GA_WAVES + wave) * GA_FRAG_ROW);
-                }
-            }
-            if (!(ablate & 2)) {
+            {   // x first: step s only needs x(s+1) early (software-pipelined convert), not W(s+1)
                 char* xdst = slot + G::WSLOT + wave * G::XB;
 #pragma unroll
                 for (int q = 0; q < G::XG; ++q) GA_GLDS16(xsrc[q] + (size_t)s * 16 * G::XE, xdst + q * 1024);
             }
+            {
+                const char* src = g1 + (size_t)s * G::WROWS1 * GA_FRAG_ROW + lane * 16;
+#pragma unroll
+                for (int q = 0; q < G::WG1; ++q) {
+                    int r = q * WAVES + wave;
+                    r = (G::WROWS1 % WAVES == 0) ? r : (r % G::WROWS1);   // padded rows re-fetch a valid row
+                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * WAVES + wave) * GA_FRAG_ROW);
+                }
+            }
         } else if (s < S1 + S2) {
-            if (!(ablate & 1)) {
+            {
                 const char* src = g2 + (size_t)(s - S1) * G::WROWS2 * GA_FRAG_ROW + lane * 16;
 #pragma unroll
                 for (int q = 0; q < G::WG2; ++q) {
-                    int r = q * GA_WAVES + wave;
-                    r = (G::WROWS2 % GA_WAVES == 0) ? r : (r % G::WROWS2);
-                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * GA_WAVES + wave) * GA_FRAG_ROW);
+                    int r = q * WAVES + wave;
+                    r = (G::WROWS2 % WAVES == 0) ? r : (r % G::WROWS2);
+                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * WAVES + wave) * GA_FRAG_ROW);
                 }
             }
         }
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
     {
         const float* src = (const float*)(a.packed + L.tab_off);
         float* dst = (float*)(smem + G::TAB_OFF);
-        for (int e = tid; e < (2 + KP) * GA_DA; e += 512) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
+        for (int e = tid; e < (2 + KP) * GA_DA; e += NTHR) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
     }
 
     f32x16 acc1[ND];
@@ -158,52 +160,64 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[d][r] = 0.0f;
 
-    issue_step(0);
-    issue_step(1);
-    issue_step(2);
+#pragma unroll
+    for (int s = 0; s < G::PD; ++s) issue_step(s);
 
     // =========================================================== GEMM1: h^T = W1 * x^T
     // lane (m = lane&31, hi) owns the K-slots k = 16s + 8hi + j (j<8) of step s
     const int xrd0 = G::WSLOT + wave * G::XB +
                      ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
     const int xrd1 = G::WSLOT + wave * G::XB + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
-    for (int s = 0; s < S1; ++s) {
-        if (s < S1 - 2) ga_wait_vm<2 * G::N1>(); else ga_wait_vm<2 * G::N2>();
-        __builtin_amdgcn_s_barrier();
-        issue_step(s + 3);
-        const char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
-        float xv[8];
-        f16x8 xh, xl;
+    // x operand of one step: read this wave's own tile from the ring slot and convert (fp32 -> f16 hi/lo split)
+    float xv[8];
+    f16x8 xh, xl;
+    auto load_x = [&](int s, float (&v)[8], f16x8& h8, f16x8& l8) {
+        const char* slot = smem + (s % G::NB) * G::SLOT;
         if constexpr (XDT == ACMIL_DTYPE_F32) {
             const f32x4 a0 = *(const f32x4*)(slot + xrd0), a1 = *(const f32x4*)(slot + xrd1);
-            xv[0] = a0[0]; xv[1] = a0[1]; xv[2] = a0[2]; xv[3] = a0[3];
-            xv[4] = a1[0]; xv[5] = a1[1]; xv[6] = a1[2]; xv[7] = a1[3];
+            v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3];
+            v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
         } else if constexpr (XDT == ACMIL_DTYPE_F16) {
-            xh = *(const f16x8*)(slot + xrd0);
+            h8 = *(const f16x8*)(slot + xrd0);
             if constexpr (F32M) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = (float)xh[j];
+                for (int j = 0; j < 8; ++j) v[j] = (float)h8[j];
             }
         } else {
             const u32x4 w = *(const u32x4*)(slot + xrd0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                xv[2 * e] = __builtin_bit_cast(float, w[e] << 16);
-                xv[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+                v[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+                v[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
             }
         }
         if constexpr (!F32M && XDT != ACMIL_DTYPE_F16) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const _Float16 h16 = (_Float16)xv[j];
-                xh[j] = h16;
-                if constexpr (XLO) xl[j] = (_Float16)(xv[j] - (float)h16);
+                const _Float16 h16 = (_Float16)v[j];
+                h8[j] = h16;
+                if constexpr (XLO) l8[j] = (_Float16)(v[j] - (float)h16);
             }
         }
+    };
+    // x(0) is wave-private: only this wave's own DMA has to land (no barrier)
+    ga_wait_vm<G::WG1 + (G::PD - 1) * G::N1>();
+    load_x(0, xv, xh, xl);
+    constexpr int STEADYW = G::WG1 + (G::PD - 2) * G::N1;                       // W(s+1) + steps s+2 .. s+PD-1
+    constexpr int TAILW = (G::PD - 1) * (G::WG1 < G::N2 ? G::WG1 : G::N2);       // lower bound near the GEMM1/GEMM2 seam
+    for (int s = 0; s < S1; ++s) {
+        // wait for W(s) and for this wave's x(s+1); the rest of step s+1 and all of step s+2 stay in flight
+        if (s + G::PD - 1 < S1) ga_wait_vm<STEADYW>(); else ga_wait_vm<TAILW>();
+        __builtin_amdgcn_s_barrier();
+        issue_step(s + G::PD);
+        const char* slot = smem + (s % G::NB) * G::SLOT;
+        float xvn[8];
+        f16x8 xhn, xln;
         if constexpr (F32M) {
             const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+                if (half == 1 && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);   // next step's x: overlaps this step's MFMAs
                 f32x4 wf[ND];
 #pragma unroll
                 for (int d = 0; d < ND; ++d) wf[d] = wb[(d * 2 + half) * 64];
@@ -215,22 +229,29 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
             }
         } else {
             const f16x8* wb = (const f16x8*)slot + lane;
+            // two output tiles at a time, products interleaved so consecutive MFMAs hit different accumulators
 #pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const f16x8 wh = wb[(d * PARTS + 0) * 64];
-                acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc1[d], 0, 0, 0);
+            for (int d = 0; d < ND; d += 2) {
+                if (d == 2 && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);      // next step's x: overlaps this step's MFMAs
+                const f16x8 wh0 = wb[((d + 0) * PARTS + 0) * 64], wh1 = wb[((d + 1) * PARTS + 0) * 64];
+                acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh, acc1[d + 0], 0, 0, 0);
+                acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh, acc1[d + 1], 0, 0, 0);
                 if constexpr (SPLIT) {
-                    const f16x8 wl = wb[(d * PARTS + 1) * 64];
-                    acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc1[d], 0, 0, 0);
-                    if constexpr (XLO) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc1[d], 0, 0, 0);
+                    const f16x8 wl0 = wb[((d + 0) * PARTS + 1) * 64], wl1 = wb[((d + 1) * PARTS + 1) * 64];
+                    acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, xh, acc1[d + 0], 0, 0, 0);
+                    acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, xh, acc1[d + 1], 0, 0, 0);
+                    if constexpr (XLO) {
+                        acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xl, acc1[d + 0], 0, 0, 0);
+                        acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xl, acc1[d + 1], 0, 0, 0);
+                    }
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = xvn[j];
+        xh = xhn; xl = xln;
     }
 
-#if defined(GA_CUT) && GA_CUT == 1
-    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += acc1[d][r]; a.part[tid] = t; return; }
-#endif
     // =========================================================== relu
     // acc1[d][r] now holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)]
 #pragma unroll
@@ -265,9 +286,6 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
             }
     }
 
-#if defined(GA_CUT) && GA_CUT == 4
-    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += F32M ? acc1[d][r] : (float)hh[d][r>>3][r&7] + (SPLIT ? (float)hl[d][r>>3][r&7] : 0.f); a.part[tid] = t; return; }
-#endif
     // =========================================================== GEMM2 (four unit blocks) + gate + scores
     const float* tabf = (const float*)(smem + G::TAB_OFF);
     float sc[KP];
@@ -294,10 +312,10 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
         for (int dp = 0; dp < ND / 2; ++dp) {
             const int j = g * (ND / 2) + dp;     // GEMM2 step index, compile-time after unrolling
             const int s = S1 + j;
-            if (j < S2 - 2) ga_wait_vm<2 * G::N2>(); else if (j == S2 - 2) ga_wait_vm<G::N2>(); else ga_wait_vm<0>();
+            if (j + G::PD - 1 < S2) ga_wait_vm<(G::PD - 1) * G::N2>(); else if (G::PD == 3 && j == S2 - 2) ga_wait_vm<G::N2>(); else ga_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
-            issue_step(s + 3);
-            const char* slot = smem + (s & (G::NB - 1)) * G::SLOT;
+            issue_step(s + G::PD);
+            const char* slot = smem + (s % G::NB) * G::SLOT;
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) {
                 const int d = 2 * dp + dd;
@@ -315,17 +333,20 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
                 } else {
                     const f16x8* wb = (const f16x8*)slot + lane;
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
-#pragma unroll
-                        for (int al = 0; al < 2; ++al) {
-                            const f16x8 wh = wb[(((dd * 2 + e) * 2 + al) * PARTS + 0) * 64];
-                            acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hh[d][e], acc2[al], 0, 0, 0);
-                            if constexpr (SPLIT) {
-                                const f16x8 wl = wb[(((dd * 2 + e) * 2 + al) * PARTS + 1) * 64];
-                                acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hh[d][e], acc2[al], 0, 0, 0);
-                                acc2[al] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, hl[d][e], acc2[al], 0, 0, 0);
-                            }
+                    for (int e = 0; e < 2; ++e) {
+                        const f16x8 wh0 = wb[(((dd * 2 + e) * 2 + 0) * PARTS + 0) * 64];
+                        const f16x8 wh1 = wb[(((dd * 2 + e) * 2 + 1) * PARTS + 0) * 64];
+                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, hh[d][e], acc2[0], 0, 0, 0);
+                        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, hh[d][e], acc2[1], 0, 0, 0);
+                        if constexpr (SPLIT) {
+                            const f16x8 wl0 = wb[(((dd * 2 + e) * 2 + 0) * PARTS + 1) * 64];
+                            const f16x8 wl1 = wb[(((dd * 2 + e) * 2 + 1) * PARTS + 1) * 64];
+                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, hh[d][e], acc2[0], 0, 0, 0);
+                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, hh[d][e], acc2[1], 0, 0, 0);
+                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, hl[d][e], acc2[0], 0, 0, 0);
+                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, hl[d][e], acc2[1], 0, 0, 0);
                         }
+                    }
                 }
             }
         }
@@ -366,10 +387,6 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
         lsum[k] = l;
     }
 
-#if defined(GA_CUT) && GA_CUT == 2
-    { float t = 0; for (int d = 0; d < ND; ++d) for (int r = 0; r < 16; ++r) t += F32M ? acc1[d][r] : (float)hh[d][r>>3][r&7] + (SPLIT ? (float)hl[d][r>>3][r&7] : 0.f); a.part[tid] = t + smax[0] + lsum[0] + pe[0]; return; }
-#endif
-    if (ablate & 4) return;
     // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
     __syncthreads();  // every wave is done with the ring; region 0 becomes the pooling tiles
     float* pool = (float*)(smem + wave * G::POOLW);
@@ -435,38 +452,46 @@ __global__ __launch_bounds__(512) void ga_fwd_kernel(GaFwdArgs a) {
     __syncthreads();
     float* out = a.part + (size_t)blockIdx.x * K * PS;
     for (int k = 0; k < K; ++k) {
-        float mw[GA_WAVES], M = -INFINITY;
+        float mw[WAVES], M = -INFINITY;
 #pragma unroll
-        for (int w = 0; w < GA_WAVES; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             mw[w] = ((const float*)(smem + w * G::POOLW))[k * PS + 0];
             M = fmaxf(M, mw[w]);
         }
-        float fw[GA_WAVES];
+        float fw[WAVES];
 #pragma unroll
-        for (int w = 0; w < GA_WAVES; ++w) fw[w] = (mw[w] == -INFINITY) ? 0.0f : __expf(mw[w] - M);
-        for (int e = tid; e < PS; e += 512) {
+        for (int w = 0; w < WAVES; ++w) fw[w] = (mw[w] == -INFINITY) ? 0.0f : __expf(mw[w] - M);
+        for (int e = tid; e < PS; e += NTHR) {
             float v;
             if (e == 0) v = M;
             else {
                 v = 0.0f;
 #pragma unroll
-                for (int w = 0; w < GA_WAVES; ++w) v = fmaf(fw[w], ((const float*)(smem + w * G::POOLW))[k * PS + e], v);
+                for (int w = 0; w < WAVES; ++w) v = fmaf(fw[w], ((const float*)(smem + w * G::POOLW))[k * PS + e], v);
             }
             out[k * PS + e] = v;
         }
     }
 }
 
-// launcher for one (ND, KP, MODE, XDT) family; pool=true -> eval variant, else the h-saving score pass
-template <int ND, int KP, int MODE, int XDT>
-int ga_launch_fwd(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    using G = GaGeom<ND, KP, MODE, XDT>;
+// launcher for one (ND, KP, MODE, XDT) family; pool=true -> eval variant, else the h-saving score pass.
+// waves = 8: one 256-patch workgroup per CU; waves = 4: two independent 128-patch workgroups per CU whose
+// phases drift apart, so one's VALU/LDS epilogues overlap the other's MFMA steps.
+template <int ND, int KP, int MODE, int XDT, int WAVES>
+int ga_launch_fwd_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
+    using G = GaGeom<ND, KP, MODE, XDT, WAVES>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
-    const dim3 grid(ga_num_tiles(a.N)), block(512);
-    void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, true, false>
-                                   : ga_fwd_kernel<ND, KP, MODE, XDT, false, true>;
+    static_assert(WAVES == 8 || 2 * G::LDS <= 160 * 1024, "two 4-wave workgroups must fit one CU");
+    const dim3 grid((a.N + G::ROWS - 1) / G::ROWS), block(64 * WAVES);
+    void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>
+                                   : ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
         return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+template <int ND, int KP, int MODE, int XDT>
+int ga_launch_fwd(const GaFwdArgs& a, bool pool, hipStream_t st) {
+    return a.waves == 4 ? ga_launch_fwd_w<ND, KP, MODE, XDT, 4>(a, pool, st) : ga_launch_fwd_w<ND, KP, MODE, XDT, 8>(a, pool, st);
 }
