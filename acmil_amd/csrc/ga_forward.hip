@@ -157,7 +157,10 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     GaFwdArgs a;
     a.x = x; a.packed = (const char*)packed; a.A_out = A_out; a.part = (float*)workspace; a.h_save = h_save; a.N = N;
     a.L = ga_layout(D, Di, K, C, mode);
-    { const char* e = getenv("ACMIL_GA_WAVES"); a.waves = (e && atoi(e) == 8) ? 8 : 4; }
+    // tile geometry: 8-wave (256-patch) workgroups stream the weights once per 256 patches; small bags use
+    // 4-wave (128-patch) workgroups, two per CU, to spread over more CUs.  ACMIL_GA_WAVES=4|8 overrides (tuning).
+    a.waves = (N >= 32768) ? 8 : 4;
+    { const char* e = getenv("ACMIL_GA_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) a.waves = atoi(e); }
     if (!pool && !h_save) {
         // scores only: run the pooled variant into the workspace and drop its partials
         if (!workspace) return ACMIL_ERR_NULL;

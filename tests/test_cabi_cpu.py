@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports every symbol that
+include/acmil_hip.h declares; argument validation works without a GPU; host modules mirror the reference."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from acmil_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from acmil_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "acmil_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(acmil_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.acmil_version().startswith(b"acmil_hip")
+
+
+def test_size_queries_and_argument_validation(lib):
+    from acmil_amd import _lib
+    # sizes: D=512, Di=256, K=5, C=2
+    for mode in (_lib.MODE_F32, _lib.MODE_F16X3, _lib.MODE_F16):
+        n = lib.acmil_ga_packed_bytes(512, 256, 128, 5, 2, mode)
+        stream = 768 * 1024 if mode != _lib.MODE_F16 else 384 * 1024
+        assert n >= stream and n % 256 == 0
+    assert lib.acmil_ga_packed_bytes(500, 256, 128, 5, 2, 0) == 0          # D not a multiple of 64
+    assert lib.acmil_ga_packed_bytes(512, 256, 64, 5, 2, 0) == 0           # Da must be 128
+    assert lib.acmil_ga_workspace_bytes(50000, 512, 256, 5, 2, 1) >= 391 * 5 * 258 * 4
+    # error codes instead of crashes (no kernel is launched for invalid arguments)
+    assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 5, 2, 0, None, None, None, None, None, None, 1, None, None) == -3
+    assert lib.acmil_ga_forward(None, 0, 0, None, 512, 256, 128, 5, 2, 0, None, None, None, None, None, None, 1, None, None) == -1
+    assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 9, 2, 0, None, None, None, None, None, None, 1, None, None) == -2
+    assert lib.acmil_stkim_select(None, 100, 5, 200, 0, None, None, None, None, None) == -1   # k > N
+    assert lib.acmil_stkim_workspace_bytes(50000, 5, 10) >= 5 * 13 * 10 * 8
+
+
+def test_modules_mirror_reference_surface():
+    from acmil_amd.architecture.network import Classifier_1fc, DimReduction
+    from acmil_amd.architecture.transformer import ABMIL, ACMIL_GA, Attention_Gated
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 384, 128, 7, 5
+
+    m = ACMIL_GA(Conf, n_token=5, n_masked_patch=10, mask_drop=0.6)
+    keys = list(m.state_dict().keys())
+    assert keys[:7] == ["dimreduction.fc1.weight", "attention.attention_V.0.weight", "attention.attention_V.0.bias",
+                        "attention.attention_U.0.weight", "attention.attention_U.0.bias",
+                        "attention.attention_weights.weight", "attention.attention_weights.bias"]
+    assert "classifier.4.fc.weight" in keys and "Slide_classifier.fc.bias" in keys and len(keys) == 19
+    assert m.state_dict()["dimreduction.fc1.weight"].shape == (128, 384)
+    assert m.state_dict()["attention.attention_weights.weight"].shape == (5, 128)
+    assert m.n_token == 5 and m.n_masked_patch == 10 and m.mask_drop == 0.6
+    ab = ABMIL(Conf)
+    assert "classifier.fc.weight" in ab.state_dict() and len(ab.state_dict()) == 9
+    assert isinstance(m.dimreduction, DimReduction) and isinstance(m.Slide_classifier, Classifier_1fc)
+    assert isinstance(m.attention, Attention_Gated)
+    # no CPU fallback: a CPU bag is rejected loudly
+    with pytest.raises(RuntimeError):
+        m.eval()(torch.zeros(1, 8, 384))
+
+
+def test_fixtures_load_into_modules():
+    from conftest import case_dims, load_golden
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    case, sd = load_golden("ga_eval_n257_d512_k5_c2")
+    d, di, k, c = case_dims(sd)
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = d, di, c, k
+
+    m = ACMIL_GA(Conf, n_token=k)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
