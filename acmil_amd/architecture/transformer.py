@@ -38,6 +38,34 @@ class Attention_Gated(nn.Module):
         return torch.transpose(a, 1, 0)
 
 
+class _GaTrainFn(torch.autograd.Function):
+    """Training step of the aggregator as one autograd node: HIP score pass + STKIM + masked pooling forward,
+    HIP backward (acmil_ga_backward).  Differentiable outputs: sub_preds, slide_pred, A_out."""
+
+    @staticmethod
+    def forward(ctx, module, xb, uniforms, n_params, *params):
+        packed, dims = module._packed()
+        out = module._masked_forward(xb, packed, dims, uniforms, want_afeat=True,
+                                     masking=getattr(module, "_masking_now", True))
+        ctx.dims = dims
+        ctx.has_slide = "slide_pred" in out
+        ctx.save_for_backward(xb, out["h"], out["A_out"], out["afeat"], *[p.detach() for p in params])
+        module._last = out
+        slide = out["slide_pred"].unsqueeze(0) if ctx.has_slide else out["sub_preds"].new_zeros(1, dims.C)
+        return out["sub_preds"], slide, out["A_out"].unsqueeze(0)
+
+    @staticmethod
+    def backward(ctx, d_sub, d_slide, d_attn):
+        xb, h, A_out, afeat, *params = ctx.saved_tensors
+        dims = ctx.dims
+        if d_sub is None:
+            d_sub = torch.zeros(dims.K, dims.C, device=xb.device)
+        if ctx.has_slide and d_slide is None:
+            d_slide = torch.zeros(dims.C, device=xb.device)
+        grads = ops.ga_backward(xb, h, A_out, afeat, params, dims, d_sub, d_slide if ctx.has_slide else None, d_attn)
+        return (None, None, None, None, *grads)
+
+
 class _GatedBase(nn.Module):
     """Shared plumbing: parameter gathering and the packed-weight cache."""
 
@@ -115,23 +143,36 @@ class ACMIL_GA(_GatedBase):
         return ([c.fc.weight for c in self.classifier], [c.fc.bias for c in self.classifier],
                 self.Slide_classifier.fc.weight, self.Slide_classifier.fc.bias)
 
-    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False):
+    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
+        """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
         n = xb.shape[0]
-        k = min(self.n_masked_patch, n)
-        m = int(k * self.mask_drop)
         A, h = ops.ga_scores(xb, packed, dims, self.precision)
-        if uniforms is None:
-            uniforms = torch.rand(dims.K, k, device=xb.device)
-        topk, midx = ops.stkim_select(A, k, m, uniforms)
-        out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat)
+        k = min(self.n_masked_patch, n) if masking else 0
+        m = int(k * self.mask_drop)
+        topk = midx = None
+        if k > 0:
+            if uniforms is None:
+                uniforms = torch.rand(dims.K, k, device=xb.device)
+            topk, midx = ops.stkim_select(A, k, m, uniforms)
+        out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat,
+                          want_afeat=want_afeat)
         out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
         return out
 
+    def _all_params(self):
+        base, wc, bc, ws, bs = self._raw_params()
+        return base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
+
     def forward(self, x, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N])  (transformer.py:305-330)."""
-        packed, dims = self._packed()
         xb = self._bag(x)
-        if self.n_masked_patch > 0 and self.training:
+        params = self._all_params()
+        masking = self.n_masked_patch > 0 and self.training
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._masking_now = masking
+            return _GaTrainFn.apply(self, xb, uniforms, len(params), *params)
+        packed, dims = self._packed()
+        if masking:
             out = self._masked_forward(xb, packed, dims, uniforms)
         else:
             out = ops.ga_forward(xb, packed, dims, self.precision)

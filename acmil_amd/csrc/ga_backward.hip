@@ -1,0 +1,313 @@
+// ga_backward.hip -- backward of one ACMIL_GA training step (autograd of architecture/transformer.py:305-330;
+// the reference has no explicit backward code).
+//
+// Given x, the saved h = relu(x W1^T) and the (masked) scores A the forward returned, with
+//   P = softmax_N(A), afeat = P h, sub_k = Wc_k afeat_k + bc_k, slide = Ws mean_k(afeat_k) + bs
+// and incoming dsub [K,C], dslide [C], dA_ext [K,N]:
+//   1 heads      d_afeat_k = Wc_k^T dsub_k + Ws^T dslide / K ; c_k = d_afeat_k . afeat_k ; dWc, dbc, dWs, dbs
+//   2 stats      M_k = max_n A[k,n], L_k = sum_n exp(A[k,n] - M_k)
+//   3 G          = h [Wv;Wu]^T + [bv;bu]                          (fp32 MFMA GEMM, recompute instead of saving)
+//   4 gate pass  per row n: P, dP = d_afeat h_n, dA = P (dP - c) + dA_ext (0 where masked),
+//                V = tanh, U = sigmoid, g = V U, dg = dA^T Ww, dGv = dg U (1-V^2), dGu = dg V U (1-U)  (G <- dG),
+//                dh0_n = sum_k P[k,n] d_afeat_k ; partial sums of dWw, dbw, dbv, dbu per workgroup
+//   5 dpre       = (dh0 + dGv Wv + dGu Wu) * [h > 0]              (two GEMMs, beta = 1, relu-mask epilogue)
+//   6 dWv, dWu   = dGv^T h, dGu^T h ; dW1 = dpre^T x              (split-K GEMMs over the N patches)
+//   7 reduce     the per-workgroup partials of step 4 in a fixed order
+// Everything heavy is exact-fp32 MFMA (gemm_f32.hip); the row pass is HBM-streaming with one wave per row.
+#include "ga_common.h"
+
+extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                              long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                              float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                              int batch, void* workspace, void* stream);
+extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
+
+#define GB_MAXK ACMIL_MAX_TOKENS
+#define GB_GATE_BLOCKS 1024
+
+struct GaBwdHeadArgs {
+    const float* afeat; const float* Ws; const float* d_sub; const float* d_slide;
+    const float* Wc[GB_MAXK];
+    float* dWc[GB_MAXK]; float* dbc[GB_MAXK];
+    float *dWs, *dbs;
+    float* d_afeat;   // [K][Di] out
+    float* ck;        // [K] out
+    int K, C, Di;
+};
+
+// one workgroup; thread = feature di (looped)
+__global__ __launch_bounds__(256) void ga_bwd_heads_kernel(GaBwdHeadArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, C = a.C, Di = a.Di;
+    const float invK = 1.0f / (float)K;
+    for (int k = 0; k < K; ++k) {
+        float cpart = 0.0f;
+        for (int di = tid; di < Di; di += 256) {
+            float s = 0.0f;
+            for (int c = 0; c < C; ++c) s = fmaf(a.Wc[k][(size_t)c * Di + di], a.d_sub[k * C + c], s);
+            if (a.Ws)
+                for (int c = 0; c < C; ++c) s = fmaf(a.Ws[(size_t)c * Di + di] * invK, a.d_slide[c], s);
+            a.d_afeat[(size_t)k * Di + di] = s;
+            const float af = a.afeat[(size_t)k * Di + di];
+            cpart = fmaf(s, af, cpart);
+            for (int c = 0; c < C; ++c) a.dWc[k][(size_t)c * Di + di] = a.d_sub[k * C + c] * af;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cpart += __shfl_xor(cpart, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = cpart;
+        __syncthreads();
+        if (tid == 0) a.ck[k] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid < C) a.dbc[k][tid] = a.d_sub[k * C + tid];
+    }
+    if (a.Ws) {
+        for (int di = tid; di < Di; di += 256) {
+            float bf = 0.0f;
+            for (int k = 0; k < K; ++k) bf += a.afeat[(size_t)k * Di + di];
+            bf *= invK;
+            for (int c = 0; c < C; ++c) a.dWs[(size_t)c * Di + di] = a.d_slide[c] * bf;
+        }
+        if (tid < C) a.dbs[tid] = a.d_slide[tid];
+    }
+}
+
+// grid K; softmax statistics of one branch: stats[2k] = max, stats[2k+1] = sum exp
+__global__ __launch_bounds__(1024) void ga_bwd_stats_kernel(const float* __restrict__ A, int N, float* __restrict__ stats) {
+    __shared__ float red[16];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = A + (size_t)k * N;
+    float m = -INFINITY;
+    for (int n = tid; n < N; n += 1024) m = fmaxf(m, row[n]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, red[w]);
+    __syncthreads();
+    float l = 0.0f;
+    for (int n = tid; n < N; n += 1024) l += __expf(row[n] - M);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    if (tid == 0) {
+        float L = 0.0f;
+        for (int w = 0; w < 16; ++w) L += red[w];
+        stats[2 * k] = M; stats[2 * k + 1] = L;
+    }
+}
+
+struct GaBwdGateArgs {
+    const float *h, *A, *dA_ext, *d_afeat, *ck, *stats, *Ww;
+    float* G;     // [N][256] in: pre-activations (v | u), out: dG
+    float* dh0;   // [N][Di] out
+    float* part;  // [blocks][KP*128 + KP + 256] partial sums
+    int N, K;
+};
+
+// one wave per row (grid-stride); lane l: features 4l..4l+3 of h / dh0 (Di = 64*FPL), units 2l, 2l+1 of the gate
+template <int KP, int FPL>
+__global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
+    constexpr int Di = 64 * FPL;
+    constexpr int PREC = KP * GA_DA + KP + 2 * GA_DA;   // floats per workgroup partial record
+    __shared__ float sred[4][PREC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N, K = a.K;
+    float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const bool on = k < K;
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) daf[k][f] = on ? a.d_afeat[(size_t)k * Di + FPL * lane + f] : 0.0f;
+        ww[k][0] = on ? a.Ww[k * GA_DA + 2 * lane] : 0.0f;
+        ww[k][1] = on ? a.Ww[k * GA_DA + 2 * lane + 1] : 0.0f;
+        ck[k] = on ? a.ck[k] : 0.0f;
+        Mk[k] = on ? a.stats[2 * k] : 0.0f;
+        iL[k] = on ? 1.0f / a.stats[2 * k + 1] : 0.0f;
+    }
+    float aWw[KP][2], abw[KP], abv[2] = {0.f, 0.f}, abu[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { aWw[k][0] = aWw[k][1] = 0.0f; abw[k] = 0.0f; }
+
+    const int nwaves = gridDim.x * 4;
+    for (int n = blockIdx.x * 4 + wave; n < N; n += nwaves) {
+        float hv[FPL];
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) hv[f] = a.h[(size_t)n * Di + FPL * lane + f];
+        float dA[KP], P[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            float dp = 0.0f;
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) dp = fmaf(daf[k][f], hv[f], dp);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) dp += __shfl_xor(dp, o);
+            const float s = (k < K) ? a.A[(size_t)k * N + n] : -INFINITY;
+            const bool masked = !(s > -5e8f);                 // masked_fill(-1e9) positions (and padded branches)
+            P[k] = masked ? 0.0f : __expf(s - Mk[k]) * iL[k];
+            const float ext = (a.dA_ext && k < K) ? a.dA_ext[(size_t)k * N + n] : 0.0f;
+            dA[k] = masked ? 0.0f : fmaf(P[k], dp - ck[k], ext);
+        }
+        const float* grow = a.G + (size_t)n * (2 * GA_DA);
+        const float gv0 = grow[2 * lane], gv1 = grow[2 * lane + 1];
+        const float gu0 = grow[GA_DA + 2 * lane], gu1 = grow[GA_DA + 2 * lane + 1];
+        const float V0 = ga_tanh(gv0), V1 = ga_tanh(gv1), U0 = ga_sigmoid(gu0), U1 = ga_sigmoid(gu1);
+        const float g0 = V0 * U0, g1 = V1 * U1;
+        float dg0 = 0.0f, dg1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            dg0 = fmaf(dA[k], ww[k][0], dg0); dg1 = fmaf(dA[k], ww[k][1], dg1);
+            aWw[k][0] = fmaf(dA[k], g0, aWw[k][0]); aWw[k][1] = fmaf(dA[k], g1, aWw[k][1]);
+            abw[k] += dA[k];
+        }
+        const float dGv0 = dg0 * U0 * (1.0f - V0 * V0), dGv1 = dg1 * U1 * (1.0f - V1 * V1);
+        const float dGu0 = dg0 * V0 * U0 * (1.0f - U0), dGu1 = dg1 * V1 * U1 * (1.0f - U1);
+        abv[0] += dGv0; abv[1] += dGv1; abu[0] += dGu0; abu[1] += dGu1;
+        float* gout = a.G + (size_t)n * (2 * GA_DA);
+        gout[2 * lane] = dGv0; gout[2 * lane + 1] = dGv1;
+        gout[GA_DA + 2 * lane] = dGu0; gout[GA_DA + 2 * lane + 1] = dGu1;
+#pragma unroll
+        for (int f = 0; f < FPL; ++f) {
+            float d = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) d = fmaf(P[k], daf[k][f], d);
+            a.dh0[(size_t)n * Di + FPL * lane + f] = d;
+        }
+    }
+    // workgroup partial record: [k][128] dWw, [k] dbw, [128] dbv, [128] dbu
+    float* rec = sred[wave];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        rec[k * GA_DA + 2 * lane] = aWw[k][0]; rec[k * GA_DA + 2 * lane + 1] = aWw[k][1];
+        if (lane == 0) rec[KP * GA_DA + k] = abw[k];
+    }
+    rec[KP * GA_DA + KP + 2 * lane] = abv[0]; rec[KP * GA_DA + KP + 2 * lane + 1] = abv[1];
+    rec[KP * GA_DA + KP + GA_DA + 2 * lane] = abu[0]; rec[KP * GA_DA + KP + GA_DA + 2 * lane + 1] = abu[1];
+    __syncthreads();
+    float* out = a.part + (size_t)blockIdx.x * PREC;
+    for (int e = tid; e < PREC; e += 256) out[e] = (sred[0][e] + sred[1][e]) + (sred[2][e] + sred[3][e]);
+}
+
+// fixed-order sum of the gate pass partial records -> dWw [K][128], dbw [K], dbv [128], dbu [128]
+template <int KP>
+__global__ __launch_bounds__(256) void ga_bwd_reduce_kernel(const float* __restrict__ part, int blocks, int K,
+                                                            float* dWw, float* dbw, float* dbv, float* dbu) {
+    constexpr int PREC = KP * GA_DA + KP + 2 * GA_DA;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= PREC) return;
+    float s = 0.0f;
+    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * PREC + e];
+    if (e < KP * GA_DA) { const int k = e / GA_DA; if (k < K) dWw[k * GA_DA + e % GA_DA] = s; }
+    else if (e < KP * GA_DA + KP) { const int k = e - KP * GA_DA; if (k < K) dbw[k] = s; }
+    else if (e < KP * GA_DA + KP + GA_DA) dbv[e - KP * GA_DA - KP] = s;
+    else dbu[e - KP * GA_DA - KP - GA_DA] = s;
+}
+
+static size_t gb_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, gemm, total; };
+
+static GbWs gb_layout(int N, int D, int Di, int K) {
+    GbWs w; size_t off = 0;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    w.G = off;       off += gb_align((size_t)N * 2 * GA_DA * 4);
+    w.dpre = off;    off += gb_align((size_t)N * Di * 4);
+    w.d_afeat = off; off += gb_align((size_t)K * Di * 4);
+    w.ck = off;      off += 256;
+    w.stats = off;   off += 256;
+    w.part = off;    off += gb_align((size_t)GB_GATE_BLOCKS * (KP * GA_DA + KP + 2 * GA_DA) * 4);
+    size_t g = acmil_gemm_workspace_bytes(Di, D, N, 1);
+    size_t g2 = acmil_gemm_workspace_bytes(GA_DA, Di, N, 1);
+    w.gemm = off;    off += gb_align(g > g2 ? g : g2);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K, int C) {
+    (void)C;
+    if (N <= 0 || D <= 0 || Di <= 0 || K <= 0) return 0;
+    return gb_layout(N, D, Di, K).total;
+}
+
+extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const float* A_out,
+                                 const float* afeat, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                 const float* Ww, const float* const* Wc, const float* Ws, const float* d_sub,
+                                 const float* d_slide, const float* d_A, float* dW1, float* dWv, float* dbv, float* dWu,
+                                 float* dbu, float* dWw, float* dbw, float* const* dWc, float* const* dbc, float* dWs,
+                                 float* dbs, int D, int Di, int Da, int K, int C, void* workspace, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (N <= 0) return ACMIL_ERR_SHAPE;
+    if (Di != 128 && Di != 256 && Di != 384 && Di != 512) return ACMIL_ERR_UNSUPPORTED;
+    if (!x || !h || !A_out || !afeat || !Wv || !bv || !Wu || !bu || !Ww || !Wc || !d_sub || !workspace) return ACMIL_ERR_NULL;
+    if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc) return ACMIL_ERR_NULL;
+    if ((Ws != nullptr) != (d_slide != nullptr) || (Ws && (!dWs || !dbs))) return ACMIL_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const GbWs L = gb_layout(N, D, Di, K);
+    float* G = (float*)(ws + L.G);
+    float* dpre = (float*)(ws + L.dpre);
+    float* d_afeat = (float*)(ws + L.d_afeat);
+    float* ck = (float*)(ws + L.ck);
+    float* stats = (float*)(ws + L.stats);
+    float* part = (float*)(ws + L.part);
+    void* gws = ws + L.gemm;
+
+    // 1 heads
+    GaBwdHeadArgs ha;
+    ha.afeat = afeat; ha.Ws = Ws; ha.d_sub = d_sub; ha.d_slide = d_slide; ha.dWs = dWs; ha.dbs = dbs;
+    ha.d_afeat = d_afeat; ha.ck = ck; ha.K = K; ha.C = C; ha.Di = Di;
+    for (int k = 0; k < GB_MAXK; ++k) {
+        ha.Wc[k] = k < K ? Wc[k] : nullptr; ha.dWc[k] = k < K ? dWc[k] : nullptr; ha.dbc[k] = k < K ? dbc[k] : nullptr;
+        if (k < K && (!ha.Wc[k] || !ha.dWc[k] || !ha.dbc[k])) return ACMIL_ERR_NULL;
+    }
+    hipLaunchKernelGGL(ga_bwd_heads_kernel, dim3(1), dim3(256), 0, st, ha);
+    // 2 stats
+    hipLaunchKernelGGL(ga_bwd_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    // 3 G = h [Wv;Wu]^T + [bv;bu]
+    rc = acmil_gemm_f32(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bv, 0,
+                        nullptr, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    rc = acmil_gemm_f32(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 0.0f, G + GA_DA, 2 * GA_DA, 0, bu,
+                        0, nullptr, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    // 4 gate pass
+    GaBwdGateArgs ga;
+    ga.h = h; ga.A = A_out; ga.dA_ext = d_A; ga.d_afeat = d_afeat; ga.ck = ck; ga.stats = stats; ga.Ww = Ww;
+    ga.G = G; ga.dh0 = dpre; ga.part = part; ga.N = N; ga.K = K;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int FPL = Di / 64;
+    const int blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
+#define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
+    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else GB_LAUNCH_GATE(1, 8); }
+    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else GB_LAUNCH_GATE(5, 8); }
+    else return ACMIL_ERR_UNSUPPORTED;
+#undef GB_LAUNCH_GATE
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    // 5 dpre = (dh0 + dGv Wv + dGu Wu) * [h > 0]
+    rc = acmil_gemm_f32(0, 0, N, Di, GA_DA, 1.0f, G, 2 * GA_DA, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 0,
+                        nullptr, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    rc = acmil_gemm_f32(0, 0, N, Di, GA_DA, 1.0f, G + GA_DA, 2 * GA_DA, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0,
+                        nullptr, 2, h, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    // 6 weight gradients (contraction over the N patches, split-K)
+    rc = acmil_gemm_f32(1, 0, GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWv, Di, 0, nullptr, 0,
+                        nullptr, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    rc = acmil_gemm_f32(1, 0, GA_DA, Di, N, 1.0f, G + GA_DA, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWu, Di, 0,
+                        nullptr, 0, nullptr, 1, gws, st);
+    if (rc != ACMIL_OK) return rc;
+    rc = acmil_gemm_f32(1, 0, Di, D, N, 1.0f, dpre, Di, 0, x, x_dtype, D, 0, 0.0f, dW1, D, 0, nullptr, 0, nullptr, 1, gws,
+                        st);
+    if (rc != ACMIL_OK) return rc;
+    // 7 reduce gate partials
+    const int prec = KP * GA_DA + KP + 2 * GA_DA;
+    if (KP == 1) hipLaunchKernelGGL(ga_bwd_reduce_kernel<1>, dim3((prec + 255) / 256), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
+    else hipLaunchKernelGGL(ga_bwd_reduce_kernel<5>, dim3((prec + 255) / 256), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}

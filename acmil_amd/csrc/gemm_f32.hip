@@ -1,0 +1,244 @@
+// gemm_f32.hip -- exact-fp32 matrix-core GEMM for gfx950 (v_mfma_f32_32x32x2_f32: bitwise an fp32 fma chain,
+// 157 TFLOP/s peak), the building block of the backward pass of the gated-attention path and of the
+// TransMIL / Nystrom path.  Hand-written, no rocBLAS / hipBLASLt.
+//
+//   C[b] = act( alpha * op(A[b]) * op(B[b]) + bias + beta * C[b] )        b < batch
+//   op(A) is M x K, op(B) is K x N, all row-major with leading dimensions; transA/transB select op = transpose.
+//   B may be fp32 / fp16 / bf16 in memory (converted to fp32 on load; used for dW1 = dpre^T * x on fp16 bags).
+//
+// Tiling: 128 x 128 x 32 per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles, 64
+// accumulator registers).  Both operand tiles are staged K-major in LDS ([k][m] / [k][n], +4 pad), so the
+// one-float-per-lane MFMA fragments A[i = lane&31][k = lane>>5] are conflict-free ds_read_b32 whatever the
+// transposition; global loads are float4 along the contiguous axis and register-prefetched one tile ahead.
+// Tall-K problems (weight gradients: K = number of patches) are split along K over gridDim.z into a
+// workspace and reduced in a fixed order (deterministic), the epilogue then runs in the reduce kernel.
+#include "ga_common.h"
+
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 32
+#define GM_LD (GM_BM + 4)
+
+struct GemmArgs {
+    const float* A; const void* B; float* C; const float* bias; const float* aux; float* ws;
+    int M, N, K, lda, ldb, ldc;
+    long long sA, sB, sC;   // batch strides (elements)
+    int transA, transB, b_dtype, act, splits, kchunk;
+    float alpha, beta;
+};
+
+template <int BDT>
+__device__ __forceinline__ float gm_ldb(const void* B, long long idx) {
+    if constexpr (BDT == ACMIL_DTYPE_F32) return ((const float*)B)[idx];
+    else if constexpr (BDT == ACMIL_DTYPE_F16) return (float)((const _Float16*)B)[idx];
+    else return __builtin_bit_cast(float, (uint32_t)((const uint16_t*)B)[idx] << 16);
+}
+
+// stage one 128 x 32 (or 32 x 128) tile of a row-major matrix into registers; `contig_is_k` tells whether
+// the contiguous memory axis is K (operand stored [rows][K]) or the M/N axis (operand stored [K][rows]).
+template <bool IS_B, int BDT>
+__device__ __forceinline__ void gm_load_tile(const void* P, int ld, bool contig_is_k, int r0, int k0, int R, int K,
+                                             int kend, int tid, float (&reg)[4][4]) {
+    if (contig_is_k) {
+        // thread -> (row = tid/8 + 32*i, 4 consecutive k at 4*(tid%8))
+        const int kq = 4 * (tid & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + (tid >> 3) + 32 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + kq + q;
+                float v = 0.0f;
+                if (r < R && k < kend) {
+                    const long long idx = (long long)r * ld + k;
+                    v = IS_B ? gm_ldb<BDT>(P, idx) : ((const float*)P)[idx];
+                }
+                reg[i][q] = v;
+            }
+        }
+    } else {
+        // thread -> (k = tid/32 + 8*i, 4 consecutive rows at 4*(tid%32))
+        const int rq = 4 * (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + (tid >> 5) + 8 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + rq + q;
+                float v = 0.0f;
+                if (r < R && k < kend) {
+                    const long long idx = (long long)k * ld + r;
+                    v = IS_B ? gm_ldb<BDT>(P, idx) : ((const float*)P)[idx];
+                }
+                reg[i][q] = v;
+            }
+        }
+    }
+    (void)K;
+}
+
+__device__ __forceinline__ void gm_store_tile(float* S, bool contig_is_k, int tid, const float (&reg)[4][4]) {
+    if (contig_is_k) {
+        const int kq = 4 * (tid & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(kq + q) * GM_LD + r] = reg[i][q];
+        }
+    } else {
+        const int rq = 4 * (tid & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = (tid >> 5) + 8 * i;
+            *(f32x4*)(S + k * GM_LD + rq) = f32x4{reg[i][0], reg[i][1], reg[i][2], reg[i][3]};
+        }
+    }
+}
+
+// act: 0 none, 1 relu, 2 relu-backward mask (v if aux[row][col] > 0 else 0; aux has C's leading dimension)
+__device__ __forceinline__ float gm_act(float v, int act, const float* aux, long long idx) {
+    if (act == 1) return fmaxf(v, 0.0f);
+    if (act == 2) return aux[idx] > 0.0f ? v : 0.0f;
+    return v;
+}
+
+template <int BDT>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GM_BK * GM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * GM_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    int batch = 0, split = 0;
+    if (g.splits > 1) split = blockIdx.z; else batch = blockIdx.z;
+    const float* A = g.A + (long long)batch * g.sA;
+    const char* B = (const char*)g.B + (long long)batch * g.sB * (BDT == ACMIL_DTYPE_F32 ? 4 : 2);
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    // operand A is stored [M][K] (contiguous K) unless transA; operand B is stored [K][N] unless transB ([N][K])
+    const bool a_ck = !g.transA, b_ck = (g.transB != 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    float ra[4][4], rb[4][4];
+    gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, kbeg, g.M, g.K, kend, tid, ra);
+    gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, kbeg, g.N, g.K, kend, tid, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
+        __syncthreads();   // previous tile fully consumed
+        gm_store_tile(As, a_ck, tid, ra);
+        gm_store_tile(Bs, b_ck, tid, rb);
+        __syncthreads();
+        if (k0 + GM_BK < kend) {
+            gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, k0 + GM_BK, g.M, g.K, kend, tid, ra);
+            gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, k0 + GM_BK, g.N, g.K, kend, tid, rb);
+        }
+        const float* ap = As + hi * GM_LD + 64 * wm + i31;
+        const float* bp = Bs + hi * GM_LD + 64 * wn + i31;
+#pragma unroll
+        for (int kk = 0; kk < GM_BK / 2; ++kk) {
+            const float a0 = ap[2 * kk * GM_LD], a1 = ap[2 * kk * GM_LD + 32];
+            const float b0 = bp[2 * kk * GM_LD], b1 = bp[2 * kk * GM_LD + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + 64wm + 32a + mfma32_row(r,hi), col = n0 + 64wn + 32b + i31
+    float* Cb = (g.splits > 1) ? g.ws + (long long)split * g.M * g.N : g.C + (long long)batch * g.sC;
+    const int ldc = (g.splits > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + 64 * wn + 32 * b + i31;
+            if (col >= g.N) continue;
+            const float bias = (g.splits > 1 || !g.bias) ? 0.0f : g.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wm + 32 * a + mfma32_row(r, hi);
+                if (row >= g.M) continue;
+                float* dst = Cb + (long long)row * ldc + col;
+                if (g.splits > 1) *dst = acc[a][b][r];
+                else {
+                    float v = g.alpha * acc[a][b][r] + bias;
+                    if (g.beta != 0.0f) v += g.beta * *dst;
+                    *dst = gm_act(v, g.act, g.aux + (long long)batch * g.sC, (long long)row * ldc + col);
+                }
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
+    const long long total = (long long)g.M * g.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        float s = 0.0f;
+        for (int sp = 0; sp < g.splits; ++sp) s += g.ws[(long long)sp * total + e];   // fixed order
+        const int row = e / g.N, col = e % g.N;
+        float v = g.alpha * s + (g.bias ? g.bias[col] : 0.0f);
+        float* dst = g.C + (long long)row * g.ldc + col;
+        if (g.beta != 0.0f) v += g.beta * *dst;
+        *dst = gm_act(v, g.act, g.aux, (long long)row * g.ldc + col);
+    }
+}
+
+// choose a K split so that (tiles * splits) roughly fills the 256 CUs when the output is small and K is long
+static int gm_pick_splits(int M, int N, int K, int batch) {
+    if (batch > 1) return 1;
+    const long long tiles = (long long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    if (tiles >= 128 || K < 4 * GM_BK * 8) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    const long long maxs = K / (GM_BK * 4);
+    if (s > maxs) s = maxs;
+    if (s > 256) s = 256;
+    return s < 2 ? 1 : (int)s;
+}
+
+extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch) {
+    const int s = gm_pick_splits(M, N, K, batch);
+    return s > 1 ? (((size_t)s * M * N * sizeof(float) + 255) & ~(size_t)255) : 256;
+}
+
+extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                              long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                              float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                              int batch, void* workspace, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
+    if (!A || !B || !C) return ACMIL_ERR_NULL;
+    if (act < 0 || act > 2) return ACMIL_ERR_UNSUPPORTED;
+    if (act == 2 && !aux) return ACMIL_ERR_NULL;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.ws = (float*)workspace;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sA = strideA; g.sB = strideB; g.sC = strideC;
+    g.transA = transA; g.transB = transB; g.b_dtype = b_dtype; g.act = act; g.alpha = alpha; g.beta = beta;
+    g.splits = gm_pick_splits(M, N, K, batch);
+    if (g.splits > 1 && !workspace) return ACMIL_ERR_NULL;
+    const int ktiles = (K + GM_BK - 1) / GM_BK;
+    g.kchunk = g.splits > 1 ? ((ktiles + g.splits - 1) / g.splits) * GM_BK : K;
+    if (g.splits > 1) g.splits = (K + g.kchunk - 1) / g.kchunk;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, g.splits > 1 ? g.splits : batch);
+    switch (b_dtype) {
+        case ACMIL_DTYPE_F32: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F32>, grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_F16: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F16>, grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_BF16>, grid, dim3(256), 0, st, g); break;
+        default: return ACMIL_ERR_UNSUPPORTED;
+    }
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (g.splits > 1) {
+        const long long total = (long long)M * N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
+    return ACMIL_OK;
+}

@@ -170,3 +170,65 @@ def ga_pool(h: torch.Tensor, A: torch.Tensor, packed: torch.Tensor, dims: GaDims
         if v is not None:
             out[k] = v
     return out
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
+         bias: Optional[torch.Tensor] = None, act: int = 0, out: Optional[torch.Tensor] = None, beta: float = 0.0,
+         aux: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """acmil_gemm_f32 on 2-D (or batched 3-D) row-major tensors: out = act(alpha * op(a) @ op(b) + bias + beta*out).
+    a fp32; b fp32/fp16/bf16; inner-most stride must be 1 (leading dimensions / batch strides are honoured)."""
+    lib = _lib.load()
+    _need_cuda(a, b)
+    if a.dim() == 2:
+        a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
+    else:
+        a3, b3 = a, b
+    if a3.stride(-1) != 1 or b3.stride(-1) != 1 or a3.dtype != torch.float32 or b3.dtype not in _DT:
+        raise RuntimeError("acmil_amd.gemm: operands must have unit inner stride; A fp32")
+    batch = a3.shape[0]
+    M, K = (a3.shape[2], a3.shape[1]) if trans_a else (a3.shape[1], a3.shape[2])
+    K2, N = (b3.shape[2], b3.shape[1]) if trans_b else (b3.shape[1], b3.shape[2])
+    if K != K2 or b3.shape[0] not in (1, batch):
+        raise RuntimeError("acmil_amd.gemm: shape mismatch")
+    if out is None:
+        out = torch.empty((batch, M, N) if a.dim() == 3 else (M, N), dtype=torch.float32, device=a.device)
+    o3 = out if out.dim() == 3 else out.unsqueeze(0)
+    ws = torch.empty(lib.acmil_gemm_workspace_bytes(M, N, K, batch), dtype=torch.uint8, device=a.device)
+    sb = 0 if b3.shape[0] == 1 else b3.stride(0)
+    rc = lib.acmil_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), a3.data_ptr(), a3.stride(1),
+                            a3.stride(0) if batch > 1 else 0, b3.data_ptr(), _DT[b3.dtype], b3.stride(1), sb, float(beta),
+                            o3.data_ptr(), o3.stride(1), o3.stride(0) if batch > 1 else 0, _ptr(bias), act, _ptr(aux),
+                            batch, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_gemm_f32")
+    return out
+
+
+def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: torch.Tensor, params: Sequence[torch.Tensor],
+                dims: GaDims, d_sub: torch.Tensor, d_slide: Optional[torch.Tensor], d_A: Optional[torch.Tensor]):
+    """acmil_ga_backward.  params = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0..Wc_{K-1}, bc_0..bc_{K-1}, (Ws, bs)];
+    returns the gradients in the same order."""
+    lib = _lib.load()
+    K, Cc, Di, D = dims.K, dims.C, dims.Di, dims.D
+    W1, Wv, bv, Wu, bu, Ww, bw = params[:7]
+    Wc = list(params[7:7 + K]); bc = list(params[7 + K:7 + 2 * K])
+    Ws = params[7 + 2 * K] if dims.has_bag_head else None
+    N, dev = x.shape[0], x.device
+    grads = [torch.empty_like(p) for p in params]
+    gW1, gWv, gbv, gWu, gbu, gWw, gbw = grads[:7]
+    gWc, gbc = grads[7:7 + K], grads[7 + K:7 + 2 * K]
+    gWs, gbs = (grads[7 + 2 * K], grads[8 + 2 * K]) if dims.has_bag_head else (None, None)
+    f = lambda t: None if t is None else t.to(torch.float32).contiguous()
+    d_sub, d_slide, d_A = f(d_sub), f(d_slide), f(d_A)
+    if d_slide is not None:
+        d_slide = d_slide.reshape(-1)
+    if d_A is not None:
+        d_A = d_A.reshape(K, N)
+    arr = lambda ts: (ctypes.c_void_p * K)(*[t.data_ptr() for t in ts])
+    ws = torch.empty(lib.acmil_ga_backward_workspace_bytes(N, D, Di, K, Cc), dtype=torch.uint8, device=dev)
+    rc = lib.acmil_ga_backward(x.data_ptr(), _DT[x.dtype], N, h.data_ptr(), A_out.data_ptr(), afeat.data_ptr(),
+                               Wv.data_ptr(), bv.data_ptr(), Wu.data_ptr(), bu.data_ptr(), Ww.data_ptr(), arr(Wc), _ptr(Ws),
+                               d_sub.data_ptr(), _ptr(d_slide), _ptr(d_A), gW1.data_ptr(), gWv.data_ptr(), gbv.data_ptr(),
+                               gWu.data_ptr(), gbu.data_ptr(), gWw.data_ptr(), gbw.data_ptr(), arr(gWc), arr(gbc),
+                               _ptr(gWs), _ptr(gbs), D, Di, GA_DA, K, Cc, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_backward")
+    return grads

@@ -113,6 +113,40 @@ size_t acmil_stkim_workspace_bytes(int N, int K, int k);
 int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
                        int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Exact-fp32 matrix-core GEMM (v_mfma_f32_32x32x2_f32), row-major, optional batch and transpose:
+ *   C[b] = act( alpha * op(A[b]) * op(B[b]) + bias[col] + beta * C[b] ),  op(A) M x K, op(B) K x N.
+ * Stands in for the aten::mm / addmm / bmm calls of the reference's backward (autograd of
+ * architecture/transformer.py:305-330) and of TransMIL (architecture/transMIL.py, nystrom_attention.py).
+ * B may be fp32/fp16/bf16 (b_dtype).  act: 0 none, 1 relu, 2 relu-backward mask by aux (same layout as C).
+ * Tall-K products are split along K into `workspace` (acmil_gemm_workspace_bytes) and reduced in a fixed order.
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
+
+int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                   long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta, float* C,
+                   int ldc, long long strideC, const float* bias, int act, const float* aux, int batch,
+                   void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of one training step of ACMIL_GA (the autograd graph of architecture/transformer.py:305-330,
+ * reference has no explicit backward code).  Inputs: the bag x, h [N,Di] and the masked scores A_out [K,N]
+ * kept by the forward, afeat [K,Di]; the parameters (raw fp32 tensors); incoming gradients d_sub [K,C],
+ * d_slide [C] (NULL without bag head) and d_A [K,N] (gradient w.r.t. the returned attention scores, NULL if
+ * unused).  Outputs: every parameter gradient (overwritten, not accumulated):
+ *   dW1 [Di,D], dWv [Da,Di], dbv [Da], dWu [Da,Di], dbu [Da], dWw [K,Da], dbw [K],
+ *   dWc[k] [C,Di], dbc[k] [C] (HOST arrays of K device pointers), dWs [C,Di], dbs [C].
+ * Masked positions (A_out == -1e9) receive zero gradient, as masked_fill does.  No dx (the bag has no grad).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K, int C);
+
+int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const float* A_out, const float* afeat,
+                      const float* Wv, const float* bv, const float* Wu, const float* bu, const float* Ww,
+                      const float* const* Wc, const float* Ws, const float* d_sub, const float* d_slide,
+                      const float* d_A, float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw,
+                      float* dbw, float* const* dWc, float* const* dbc, float* dWs, float* dbs, int D, int Di, int Da,
+                      int K, int C, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
