@@ -1,0 +1,344 @@
+"""Step3-style trainer for the MI355X aggregation path (`--arch ga | abmil`).
+
+Own-code counterpart of the reference's `Step3_WSI_classification_ACMIL.py` (main :59-173,
+train_one_epoch :175-235, evaluate :242-286) and of the helpers it takes from `utils/utils.py`
+(Struct :246-248, adjust_learning_rate :250-262, save_model :415-422).  Same hyper-parameters, loss
+assembly (sub-branch CE + bag CE + pairwise-cosine diversity loss), AdamW, per-iteration cosine schedule,
+model selection on val_f1 + val_auc and checkpoint dictionary {'model','optimizer','epoch','config'}.
+
+What is new (not in the reference, which is single-GPU): slide-level data parallelism -- one process per
+GPU (`torchrun`), rank r takes slides r, r+G, ... of the shuffled epoch, and every step all-reduces ONE flat
+fp32 gradient bucket (0.8 MB) with RCCL (`torch.distributed`, backend nccl; gloo on CPU for tests).
+
+Data: bags are dicts {'input': [N,D] fp16/fp32, 'label': int} as produced by the reference's
+`datasets/datasets.py:138-155`; this file reads `.npz` bag directories or generates synthetic bags (the
+reference's HDF5 reader needs h5py, which is outside the hot path).
+"""
+from __future__ import annotations
+
+import argparse
+import math
+import os
+import random
+import time
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+PRETRAIN_DIMS = {  # Step3_WSI_classification_ACMIL.py:69-87
+    "medical_ssl": (384, 128), "natural_supervised": (512, 256), "path-clip-B": (512, 256), "openai-clip-B": (512, 256),
+    "plip": (512, 256), "quilt-net": (512, 256), "path-clip-B-AAAI": (512, 256), "biomedclip": (512, 256),
+    "path-clip-L-336": (768, 384), "openai-clip-L-336": (768, 384), "UNI": (1024, 512), "GigaPath": (1536, 768),
+}
+
+
+class Struct:  # utils/utils.py:246-248
+    def __init__(self, **entries):
+        self.__dict__.update(entries)
+
+
+def set_seed(seed: int) -> None:  # utils/utils.py:226-244
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def adjust_learning_rate(optimizer, epoch: float, cfg) -> float:
+    """Linear warm-up then half-cycle cosine, evaluated per iteration (utils/utils.py:250-262)."""
+    if epoch < cfg.warmup_epoch:
+        lr = cfg.lr * epoch / cfg.warmup_epoch
+    else:
+        lr = cfg.min_lr + (cfg.lr - cfg.min_lr) * 0.5 * (
+            1.0 + math.cos(math.pi * (epoch - cfg.warmup_epoch) / (cfg.train_epoch - cfg.warmup_epoch)))
+    for group in optimizer.param_groups:
+        group["lr"] = lr * group["lr_scale"] if "lr_scale" in group else lr
+    return lr
+
+
+def save_model(conf, epoch, model, optimizer, save_path) -> None:  # utils/utils.py:415-422
+    torch.save({"model": model.state_dict(), "optimizer": optimizer.state_dict(), "epoch": epoch, "config": conf}, save_path)
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def acmil_losses(sub_preds, slide_preds, attn, labels, n_token: int):
+    """(loss0, loss1, diff_loss) of Step3_WSI_classification_ACMIL.py:201-214 (trainer-side, tiny tensors)."""
+    if n_token > 1:
+        loss0 = F.cross_entropy(sub_preds, labels.repeat_interleave(n_token))
+    else:
+        loss0 = torch.zeros((), device=slide_preds.device)
+    loss1 = F.cross_entropy(slide_preds, labels)
+    diff_loss = torch.zeros((), device=slide_preds.device)
+    p = torch.softmax(attn, dim=-1)
+    for i in range(n_token):
+        for j in range(i + 1, n_token):
+            diff_loss = diff_loss + torch.cosine_similarity(p[:, i], p[:, j], dim=-1).mean() / (n_token * (n_token - 1) / 2)
+    return loss0, loss1, diff_loss
+
+
+# ----------------------------------------------------------------------------------------------- metrics
+def multiclass_auroc(prob: torch.Tensor, target: torch.Tensor, n_class: int) -> float:
+    """Macro one-vs-rest AUROC (what torchmetrics.AUROC(task='multiclass') computes by default); classes absent
+    from `target` are skipped."""
+    prob, target = prob.detach().cpu().double(), target.detach().cpu()
+    aucs = []
+    for c in range(n_class):
+        pos = target == c
+        n_pos, n_neg = int(pos.sum()), int((~pos).sum())
+        if n_pos == 0 or n_neg == 0:
+            continue
+        s = prob[:, c]
+        order = torch.argsort(s)
+        ranks = torch.empty_like(s)
+        ranks[order] = torch.arange(1, len(s) + 1, dtype=torch.double)
+        # average ranks over ties
+        uniq, inv = torch.unique(s, return_inverse=True)
+        if len(uniq) != len(s):
+            sums = torch.zeros(len(uniq), dtype=torch.double).scatter_add_(0, inv, ranks)
+            cnts = torch.zeros(len(uniq), dtype=torch.double).scatter_add_(0, inv, torch.ones_like(ranks))
+            ranks = (sums / cnts)[inv]
+        aucs.append(float((ranks[pos].sum() - n_pos * (n_pos + 1) / 2) / (n_pos * n_neg)))
+    return float(np.mean(aucs)) if aucs else float("nan")
+
+
+def micro_f1(prob: torch.Tensor, target: torch.Tensor) -> float:
+    """torchmetrics.F1Score(task='multiclass') default (micro average) == accuracy of argmax."""
+    return float((prob.argmax(dim=1).cpu() == target.cpu()).double().mean())
+
+
+# ----------------------------------------------------------------------------------------------- data
+class SyntheticBags:
+    """Deterministic stand-in for HDF5_feat_dataset2: fp16 bags with a weak class signal so that training moves."""
+
+    def __init__(self, n_slides: int, n_patches, d_feat: int, n_class: int, seed: int = 0):
+        self.items = []
+        g = torch.Generator().manual_seed(seed)
+        for i in range(n_slides):
+            n = n_patches if isinstance(n_patches, int) else int(torch.randint(n_patches[0], n_patches[1] + 1, (1,), generator=g))
+            label = i % n_class
+            x = torch.randn(n, d_feat, generator=g)
+            k = max(1, n // 50)
+            x[:k, label::n_class] += 1.5   # a few "tumour" patches carry the class signal
+            self.items.append({"input": x.half(), "label": label})
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+class NpzBags:
+    """Directory of `<slide>.npz` files with arrays `feat` [N,D] and `label` (same content as the reference's HDF5 groups)."""
+
+    def __init__(self, root: str):
+        self.files = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith(".npz"))
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        z = np.load(self.files[i])
+        return {"input": torch.from_numpy(z["feat"]), "label": int(z["label"])}
+
+
+def epoch_order(n: int, epoch: int, seed: int, shuffle: bool, rank: int, world: int, drop_last: bool = True) -> List[int]:
+    """Slide order of one epoch for this rank: the same permutation on every rank, strided by rank."""
+    idx = list(range(n))
+    if shuffle:
+        rng = random.Random(seed * 100003 + epoch)
+        rng.shuffle(idx)
+    if world > 1:
+        usable = (n // world) * world if drop_last else n
+        idx = idx[:usable][rank::world]
+    return idx
+
+
+# ----------------------------------------------------------------------------------------------- data parallel
+class GradBucket:
+    """All parameter gradients as ONE flat fp32 buffer: a single all-reduce per step (latency-bound at 0.8 MB,
+    so one collective beats per-tensor calls), averaged over ranks, scattered back as views."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:   # gradients become views into the flat buffer: no copy in / out
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def sync_from_grads(self):
+        """Re-point after an autograd pass that replaced .grad tensors."""
+        off = 0
+        for p in self.params:
+            view = self.flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+            off += p.numel()
+
+    def allreduce_mean(self, world: int):
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(world)
+
+
+def broadcast_parameters(model, world: int):
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+
+
+# ----------------------------------------------------------------------------------------------- loops
+def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Optional[GradBucket] = None,
+                    rank: int = 0, world: int = 1, log_every: int = 100) -> Dict[str, float]:
+    """One epoch, one slide per iteration per rank (Step3_WSI_classification_ACMIL.py:175-227)."""
+    model.train()
+    order = epoch_order(len(data), epoch, conf.seed, True, rank, world)
+    sums = {"sub_loss": 0.0, "diff_loss": 0.0, "slide_loss": 0.0}
+    t0 = time.time()
+    for it, idx in enumerate(order):
+        item = data[idx]
+        x = item["input"].to(device, non_blocking=True)            # fp16 stays fp16: converted inside the kernel
+        labels = torch.tensor([item["label"]], device=device)
+        adjust_learning_rate(optimizer, epoch + it / len(order), conf)
+        sub_preds, slide_preds, attn = model(x.unsqueeze(0))
+        loss0, loss1, diff_loss = acmil_losses(sub_preds, slide_preds, attn, labels, conf.n_token)
+        loss = diff_loss + loss0 + loss1
+        optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        if bucket is not None:
+            bucket.sync_from_grads()
+            bucket.allreduce_mean(world)
+        optimizer.step()
+        sums["sub_loss"] += float(loss0); sums["diff_loss"] += float(diff_loss); sums["slide_loss"] += float(loss1)
+        if rank == 0 and log_every and (it + 1) % log_every == 0:
+            print("Epoch: [%d] [%d/%d] lr: %.6f sub_loss: %.4f diff_loss: %.4f slide_loss: %.4f (%.1f slides/s/rank)" % (
+                epoch, it + 1, len(order), optimizer.param_groups[0]["lr"], sums["sub_loss"] / (it + 1),
+                sums["diff_loss"] / (it + 1), sums["slide_loss"] / (it + 1), (it + 1) / (time.time() - t0)))
+    n = max(1, len(order))
+    return {k: v / n for k, v in sums.items()}
+
+
+@torch.no_grad()
+def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, world: int = 1):
+    """(auroc, acc, f1, loss) as Step3_WSI_classification_ACMIL.py:242-286; slides sharded over ranks, gathered on all."""
+    model.eval()
+    order = epoch_order(len(data), 0, 0, False, rank, world, drop_last=False)
+    probs, labels, losses, divs = [], [], [], []
+    for idx in order:
+        item = data[idx]
+        x = item["input"].to(device)
+        y = torch.tensor([item["label"]], device=device)
+        sub_preds, slide_preds, attn = model(x.unsqueeze(0))
+        divs.append(float(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1]))
+        losses.append(float(F.cross_entropy(slide_preds, y)))
+        probs.append(torch.softmax(slide_preds, dim=-1))
+        labels.append(y)
+    prob = torch.cat(probs) if probs else torch.zeros(0, conf.n_class, device=device)
+    lab = torch.cat(labels) if labels else torch.zeros(0, dtype=torch.long, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (prob.cpu(), lab.cpu(), losses))
+        prob = torch.cat([g[0] for g in gathered]); lab = torch.cat([g[1] for g in gathered])
+        losses = [l for g in gathered for l in g[2]]
+    auroc = multiclass_auroc(prob, lab, conf.n_class)
+    acc = float((prob.argmax(1).cpu() == lab.cpu()).double().mean()) * 100.0
+    f1 = micro_f1(prob, lab)
+    loss = float(np.mean(losses)) if losses else float("nan")
+    if rank == 0:
+        print("* %s Acc@1 %.3f loss %.3f auroc %.3f f1_score %.3f" % (header, acc, loss, auroc, f1))
+    return auroc, acc, f1, loss
+
+
+def build_model(conf):
+    from .architecture.transformer import ABMIL, ACMIL_GA
+    if conf.arch == "ga":
+        return ACMIL_GA(conf, n_token=conf.n_token, n_masked_patch=conf.n_masked_patch, mask_drop=conf.mask_drop,
+                        precision=conf.precision)
+    if conf.arch == "abmil":
+        return ABMIL(conf, precision=conf.precision)
+    raise SystemExit("--arch %s is not on the MI355X path yet (ga, abmil)" % conf.arch)
+
+
+def get_arguments(argv=None):
+    p = argparse.ArgumentParser("WSI classification training (MI355X aggregation path)")
+    p.add_argument("--config", default=None, help="yaml with the reference's keys (train_epoch, warmup_epoch, wd, lr, min_lr, n_class, ...)")
+    p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--n_token", type=int, default=1)
+    p.add_argument("--n_masked_patch", type=int, default=0)
+    p.add_argument("--mask_drop", type=float, default=0.6)
+    p.add_argument("--arch", default="ga", choices=["ga", "abmil"])
+    p.add_argument("--pretrain", default="medical_ssl", choices=sorted(PRETRAIN_DIMS))
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16"])
+    p.add_argument("--data_dir", default=None, help="directory with train/ val/ test/ sub-directories of .npz bags; synthetic if omitted")
+    p.add_argument("--synthetic_slides", type=int, default=64)
+    p.add_argument("--synthetic_patches", type=int, default=10000)
+    p.add_argument("--train_epoch", type=int, default=None)
+    p.add_argument("--n_class", type=int, default=None)
+    p.add_argument("--out_dir", default="runs/acmil")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_arguments(argv)
+    c = dict(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, dataset="synthetic", B=1, n_class=2)
+    if args.config:
+        import yaml
+        with open(args.config) as f:
+            c.update(yaml.safe_load(f))
+    c.update({k: v for k, v in vars(args).items() if v is not None})
+    conf = Struct(**c)
+    conf.D_feat, conf.D_inner = PRETRAIN_DIMS[conf.pretrain]
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    set_seed(conf.seed)
+    if conf.data_dir:
+        train, val, test = (NpzBags(os.path.join(conf.data_dir, s)) for s in ("train", "val", "test"))
+    else:
+        mk = lambda n, s: SyntheticBags(n, conf.synthetic_patches, conf.D_feat, conf.n_class, seed=s)
+        train, val, test = mk(conf.synthetic_slides, 1), mk(max(8, conf.synthetic_slides // 4), 2), mk(max(8, conf.synthetic_slides // 4), 3)
+    model = build_model(conf).to(device)
+    broadcast_parameters(model, world)
+    optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=0.001, weight_decay=conf.wd)
+    bucket = GradBucket(list(model.parameters())) if world > 1 else None
+    os.makedirs(conf.out_dir, exist_ok=True)
+    best = {"epoch": -1, "val_acc": 0, "val_auc": 0, "val_f1": 0, "test_acc": 0, "test_auc": 0, "test_f1": 0}
+    for epoch in range(conf.train_epoch):
+        train_one_epoch(model, train, optimizer, device, epoch, conf, bucket, rank, world)
+        val_auc, val_acc, val_f1, _ = evaluate(model, val, device, conf, "Val", rank, world)
+        test_auc, test_acc, test_f1, _ = evaluate(model, test, device, conf, "Test", rank, world)
+        if val_f1 + val_auc > best["val_f1"] + best["val_auc"]:
+            best.update(epoch=epoch, val_auc=val_auc, val_acc=val_acc, val_f1=val_f1, test_auc=test_auc, test_acc=test_acc, test_f1=test_f1)
+            if rank == 0:
+                save_model(conf, epoch, model, optimizer, os.path.join(conf.out_dir, "checkpoint-best.pth"))
+    if rank == 0:
+        save_model(conf, epoch, model, optimizer, os.path.join(conf.out_dir, "checkpoint-last.pth"))
+        print("Results on best epoch:"); print(best)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
