@@ -192,14 +192,18 @@ __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
 }
 
 // fixed-order sum of the gate pass partial records -> dWw [K][128], dbw [K], dbv [128], dbu [128]
+// one wave per output element: lanes stride over the workgroup records, then a shuffle tree (deterministic)
 template <int KP>
 __global__ __launch_bounds__(256) void ga_bwd_reduce_kernel(const float* __restrict__ part, int blocks, int K,
                                                             float* dWw, float* dbw, float* dbv, float* dbu) {
     constexpr int PREC = KP * GA_DA + KP + 2 * GA_DA;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= PREC) return;
     float s = 0.0f;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * PREC + e];
+    for (int b = lane; b < blocks; b += 64) s += part[(size_t)b * PREC + e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
     if (e < KP * GA_DA) { const int k = e / GA_DA; if (k < K) dWw[k * GA_DA + e % GA_DA] = s; }
     else if (e < KP * GA_DA + KP) { const int k = e - KP * GA_DA; if (k < K) dbw[k] = s; }
     else if (e < KP * GA_DA + KP + GA_DA) dbv[e - KP * GA_DA - KP] = s;
@@ -307,7 +311,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     if (rc != ACMIL_OK) return rc;
     // 7 reduce gate partials
     const int prec = KP * GA_DA + KP + 2 * GA_DA;
-    if (KP == 1) hipLaunchKernelGGL(ga_bwd_reduce_kernel<1>, dim3((prec + 255) / 256), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
-    else hipLaunchKernelGGL(ga_bwd_reduce_kernel<5>, dim3((prec + 255) / 256), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
+    if (KP == 1) hipLaunchKernelGGL(ga_bwd_reduce_kernel<1>, dim3((prec + 3) / 4), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
+    else hipLaunchKernelGGL(ga_bwd_reduce_kernel<5>, dim3((prec + 3) / 4), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

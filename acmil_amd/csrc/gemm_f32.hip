@@ -96,7 +96,8 @@ __device__ __forceinline__ void gm_store_tile(float* S, bool contig_is_k, int ti
     }
 }
 
-// act: 0 none, 1 relu, 2 relu-backward mask (v if aux[row][col] > 0 else 0; aux has C's leading dimension)
+// act: 0 none, 1 relu, 2 relu-backward mask (v if aux[row][col] > 0 else 0; aux has C's leading dimension),
+//      3 "c I - P": out = (row == col ? beta : 0) - alpha * P   (beta is the diagonal constant, not an accumulate factor)
 __device__ __forceinline__ float gm_act(float v, int act, const float* aux, long long idx) {
     if (act == 1) return fmaxf(v, 0.0f);
     if (act == 2) return aux[idx] > 0.0f ? v : 0.0f;
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int i31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
-    int batch = 0, split = 0;
-    if (g.splits > 1) split = blockIdx.z; else batch = blockIdx.z;
+    const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const float* A = g.A + (long long)batch * g.sA;
     const char* B = (const char*)g.B + (long long)batch * g.sB * (BDT == ACMIL_DTYPE_F32 ? 4 : 2);
     const int kbeg = split * g.kchunk;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
     }
     // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + 64wm + 32a + mfma32_row(r,hi), col = n0 + 64wn + 32b + i31
-    float* Cb = (g.splits > 1) ? g.ws + (long long)split * g.M * g.N : g.C + (long long)batch * g.sC;
+    float* Cb = (g.splits > 1) ? g.ws + ((long long)batch * g.splits + split) * g.M * g.N : g.C + (long long)batch * g.sC;
     const int ldc = (g.splits > 1) ? g.N : g.ldc;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 if (row >= g.M) continue;
                 float* dst = Cb + (long long)row * ldc + col;
                 if (g.splits > 1) *dst = acc[a][b][r];
+                else if (g.act == 3) *dst = (row == col ? g.beta : 0.0f) - g.alpha * acc[a][b][r];
                 else {
                     float v = g.alpha * acc[a][b][r] + bias;
                     if (g.beta != 0.0f) v += g.beta * *dst;
@@ -177,23 +178,26 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
 }
 
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
-    const long long total = (long long)g.M * g.N;
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) {
+    const long long per = (long long)g.M * g.N, total = per * nbatch;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int b = e / per; const long long r = e % per;
+        const float* src = g.ws + (long long)b * g.splits * per + r;
         float s = 0.0f;
-        for (int sp = 0; sp < g.splits; ++sp) s += g.ws[(long long)sp * total + e];   // fixed order
-        const int row = e / g.N, col = e % g.N;
+        for (int sp = 0; sp < g.splits; ++sp) s += src[(long long)sp * per];   // fixed order
+        const int row = r / g.N, col = r % g.N;
         float v = g.alpha * s + (g.bias ? g.bias[col] : 0.0f);
-        float* dst = g.C + (long long)row * g.ldc + col;
+        const long long idx = (long long)row * g.ldc + col;
+        float* dst = g.C + (long long)b * g.sC + idx;
+        if (g.act == 3) { *dst = (row == col ? g.beta : 0.0f) - g.alpha * s; continue; }
         if (g.beta != 0.0f) v += g.beta * *dst;
-        *dst = gm_act(v, g.act, g.aux, (long long)row * g.ldc + col);
+        *dst = gm_act(v, g.act, g.aux + (long long)b * g.sC, idx);
     }
 }
 
 // choose a K split so that (tiles * splits) roughly fills the 256 CUs when the output is small and K is long
 static int gm_pick_splits(int M, int N, int K, int batch) {
-    if (batch > 1) return 1;
-    const long long tiles = (long long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN);
+    const long long tiles = (long long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN) * batch;
     if (tiles >= 128 || K < 4 * GM_BK * 8) return 1;
     long long s = (512 + tiles - 1) / tiles;
     const long long maxs = K / (GM_BK * 4);
@@ -204,7 +208,7 @@ static int gm_pick_splits(int M, int N, int K, int batch) {
 
 extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch) {
     const int s = gm_pick_splits(M, N, K, batch);
-    return s > 1 ? (((size_t)s * M * N * sizeof(float) + 255) & ~(size_t)255) : 256;
+    return s > 1 ? (((size_t)s * batch * M * N * sizeof(float) + 255) & ~(size_t)255) : 256;
 }
 
 extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -213,7 +217,7 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
                               int batch, void* workspace, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
     if (!A || !B || !C) return ACMIL_ERR_NULL;
-    if (act < 0 || act > 2) return ACMIL_ERR_UNSUPPORTED;
+    if (act < 0 || act > 3) return ACMIL_ERR_UNSUPPORTED;
     if (act == 2 && !aux) return ACMIL_ERR_NULL;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.ws = (float*)workspace;
@@ -225,8 +229,9 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
     const int ktiles = (K + GM_BK - 1) / GM_BK;
     g.kchunk = g.splits > 1 ? ((ktiles + g.splits - 1) / g.splits) * GM_BK : K;
     if (g.splits > 1) g.splits = (K + g.kchunk - 1) / g.kchunk;
+    if (g.splits < 1) g.splits = 1;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, g.splits > 1 ? g.splits : batch);
+    const dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, g.splits * batch);
     switch (b_dtype) {
         case ACMIL_DTYPE_F32: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F32>, grid, dim3(256), 0, st, g); break;
         case ACMIL_DTYPE_F16: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F16>, grid, dim3(256), 0, st, g); break;
@@ -235,9 +240,9 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
     }
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     if (g.splits > 1) {
-        const long long total = (long long)M * N;
+        const long long total = (long long)M * N * batch;
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, batch);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     return ACMIL_OK;

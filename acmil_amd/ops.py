@@ -232,3 +232,45 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
                                _ptr(gWs), _ptr(gbs), D, Di, GA_DA, K, Cc, ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_backward")
     return grads
+
+
+def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int, debug: bool = False) -> Dict[str, torch.Tensor]:
+    """acmil_transmil_forward.  x [N,D] fp32 CUDA; sd: parameters under the reference's state_dict names
+    (fp32, CUDA, contiguous).  Returns {'logits': [C]} plus 'h1','hp','h2' [(side^2+1), Di] when debug."""
+    lib = _lib.load()
+    _need_cuda(x)
+    if x.dtype != torch.float32:
+        x = x.float()        # storage-format conversion only (fp16 bag -> fp32 operand of the fp32 MFMA GEMM)
+    x = x.contiguous()
+    N, D = x.shape
+    Di = sd["_fc1.0.weight"].shape[0]
+    c = lambda k: sd[k].detach().contiguous()
+    keep = []
+
+    def arr(keys):
+        ts = [c(k) for k in keys]
+        keep.extend(ts)
+        return (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    lay = lambda p: arr([p + ".norm.weight", p + ".norm.bias", p + ".attn.to_qkv.weight", p + ".attn.to_out.0.weight",
+                         p + ".attn.to_out.0.bias", p + ".attn.res_conv.weight"])
+    l1, l2 = lay("layer1"), lay("layer2")
+    pp = arr(["pos_layer.proj.weight", "pos_layer.proj.bias", "pos_layer.proj1.weight", "pos_layer.proj1.bias",
+              "pos_layer.proj2.weight", "pos_layer.proj2.bias"])
+    small = [c(k) for k in ("_fc1.0.weight", "_fc1.0.bias", "cls_token", "norm.weight", "norm.bias", "_fc2.weight", "_fc2.bias")]
+    nbytes = lib.acmil_transmil_workspace_bytes(N, D, Di, n_class)
+    if nbytes == 0:
+        raise RuntimeError("acmil_amd: unsupported TransMIL dimensions")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    logits = torch.empty(n_class, dtype=torch.float32, device=x.device)
+    import math
+    side = int(math.ceil(math.sqrt(N)))
+    dbg = [torch.empty(side * side + 1, Di, dtype=torch.float32, device=x.device) for _ in range(3)] if debug else [None] * 3
+    rc = lib.acmil_transmil_forward(x.data_ptr(), N, D, Di, n_class, small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(),
+                                    l1, l2, pp, small[3].data_ptr(), small[4].data_ptr(), small[5].data_ptr(), small[6].data_ptr(),
+                                    logits.data_ptr(), _ptr(dbg[0]), _ptr(dbg[1]), _ptr(dbg[2]), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_transmil_forward")
+    out = {"logits": logits}
+    if debug:
+        out.update(h1=dbg[0], hp=dbg[1], h2=dbg[2])
+    return out

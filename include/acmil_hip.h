@@ -147,6 +147,27 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
                       float* dbw, float* const* dWc, float* const* dbc, float* dWs, float* dbs, int D, int Di, int Da,
                       int K, int C, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * TransMIL forward (eval) of one bag.  Replaces TransMIL.forward architecture/transMIL.py:60-91 with its
+ * TransLayer :25-28, PPEG :38-45 and NystromAttention (pip nystrom_attention 0.0.12; vendored stand-in
+ * architecture/nystrom_attention.py:67-149, pinv :12-27).  heads = 8, dim_head = Di/8, landmarks = Di/2,
+ * 6 pinv iterations, residual conv 33 (the reference's fixed ctor arguments, transMIL.py:13-23).
+ *   x [N,D] fp32 (B = 1); fc1_w [Di,D], fc1_b [Di]; cls_token [Di];
+ *   layer1 / layer2: HOST arrays of 6 device pointers {norm.weight, norm.bias, attn.to_qkv.weight [3Di,Di],
+ *                    attn.to_out.0.weight [Di,Di], attn.to_out.0.bias, attn.res_conv.weight [8,33]};
+ *   ppeg: HOST array of 6 device pointers {proj.weight [Di,7,7], proj.bias, proj1.weight [Di,5,5], proj1.bias,
+ *         proj2.weight [Di,3,3], proj2.bias};  norm_w/norm_b [Di]; fc2_w [C,Di], fc2_b [C].
+ * Output logits [C].  dbg_h1 / dbg_hp / dbg_h2: NULL, or [(side^2+1), Di] buffers receiving the token matrix
+ * after layer1 / PPEG / layer2 (parity tests).  Dropout (train mode) is not implemented: eval forward only.
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C);
+
+int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
+                           const float* cls_token, const float* const* layer1, const float* const* layer2,
+                           const float* const* ppeg, const float* norm_w, const float* norm_b, const float* fc2_w,
+                           const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2,
+                           void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
