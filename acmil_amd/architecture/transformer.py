@@ -67,9 +67,11 @@ class _GaTrainFn(torch.autograd.Function):
 
 
 class _GatedBase(nn.Module):
-    """Shared plumbing: parameter gathering and the packed-weight cache."""
+    """Shared plumbing: parameter gathering, the packed-weight cache, the two-pass training forward."""
 
     precision: str
+    n_masked_patch = 0
+    mask_drop = 0.0
 
     def _heads(self):
         raise NotImplementedError
@@ -96,6 +98,26 @@ class _GatedBase(nn.Module):
             self._pack_cache = cache
         return cache[1], cache[2]
 
+    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
+        """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
+        n = xb.shape[0]
+        A, h = ops.ga_scores(xb, packed, dims, self.precision)
+        k = min(self.n_masked_patch, n) if masking else 0
+        m = int(k * self.mask_drop)
+        topk = midx = None
+        if k > 0:
+            if uniforms is None:
+                uniforms = torch.rand(dims.K, k, device=xb.device)
+            topk, midx = ops.stkim_select(A, k, m, uniforms)
+        out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat,
+                          want_afeat=want_afeat)
+        out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
+        return out
+
+    def _all_params(self):
+        base, wc, bc, ws, bs = self._raw_params()
+        return base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
+
     @staticmethod
     def _bag(x: torch.Tensor) -> torch.Tensor:
         if x.dim() != 3:
@@ -117,9 +139,14 @@ class ABMIL(_GatedBase):
     def _heads(self):
         return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
 
-    def forward(self, x):  # x: [1, N, D_feat] -> logits [1, C]
+    def forward(self, x):  # x: [1, N, D_feat] -> logits [1, C]   (transformer.py:277-286)
+        xb = self._bag(x)
+        params = self._all_params()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            self._masking_now = False
+            return _GaTrainFn.apply(self, xb, None, len(params), *params)[0]
         packed, dims = self._packed()
-        out = ops.ga_forward(self._bag(x), packed, dims, self.precision, want_scores=False)
+        out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=False)
         return out["sub_preds"]
 
 
@@ -142,26 +169,6 @@ class ACMIL_GA(_GatedBase):
     def _heads(self):
         return ([c.fc.weight for c in self.classifier], [c.fc.bias for c in self.classifier],
                 self.Slide_classifier.fc.weight, self.Slide_classifier.fc.bias)
-
-    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
-        """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
-        n = xb.shape[0]
-        A, h = ops.ga_scores(xb, packed, dims, self.precision)
-        k = min(self.n_masked_patch, n) if masking else 0
-        m = int(k * self.mask_drop)
-        topk = midx = None
-        if k > 0:
-            if uniforms is None:
-                uniforms = torch.rand(dims.K, k, device=xb.device)
-            topk, midx = ops.stkim_select(A, k, m, uniforms)
-        out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat,
-                          want_afeat=want_afeat)
-        out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
-        return out
-
-    def _all_params(self):
-        base, wc, bc, ws, bs = self._raw_params()
-        return base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
 
     def forward(self, x, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N])  (transformer.py:305-330)."""

@@ -122,3 +122,24 @@ def test_half_bag_and_no_mask_training_paths():
         grads.append([p.grad.clone() for p in model.parameters()])
     for a, b in zip(*grads):
         assert (a - b).abs().max() <= 1e-5 * a.abs().max() + 1e-8
+
+
+def test_abmil_training_gradients_match_oracle_autograd():
+    from acmil_amd.architecture.transformer import ABMIL
+    from oracle import ga_oracle as O
+    case, sd = load_golden("abmil_eval_n1000_d512_c2")
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 512, 256, 2, 1
+
+    model = ABMIL(Conf, precision="fp32")
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    x = torch.from_numpy(case["x"])
+    y = torch.tensor([1])
+    torch.nn.functional.cross_entropy(model(x.cuda()), y.cuda()).backward()
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.nn.functional.cross_entropy(O.abmil_forward(x, sdg), y).backward()
+    for name_p, p in model.named_parameters():
+        ref = sdg[name_p].grad
+        assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-7, name_p
