@@ -186,6 +186,15 @@ class ACMIL_GA(_GatedBase):
         self._last = out
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
 
+    @torch.no_grad()
+    def forward_batch(self, bags):
+        """Eval forward of up to 16 bags (list of [N_b, D_feat] CUDA tensors, ragged N allowed) in ONE fused launch
+        (acmil_ga_forward_batch).  Returns a list of the reference's per-slide triples
+        (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N_b]).  Not in the reference (it is strictly B=1); same maths per bag."""
+        packed, dims = self._packed()
+        out = ops.ga_forward_batch([b if b.is_contiguous() else b.contiguous() for b in bags], packed, dims, self.precision)
+        return [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
+
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> bag_feat [1,Di]  (transformer.py:332-352)."""
         packed, dims = self._packed()

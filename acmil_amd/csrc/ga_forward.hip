@@ -12,8 +12,14 @@
 // Loads of up to 4 tiles are issued together (the loop is latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------------------
 #define GA_MERGE_GROUPS 16
-__global__ __launch_bounds__(1024) void ga_merge_kernel(const float* __restrict__ part, int tiles, int K, int Di,
-                                                        float* __restrict__ afeat) {
+struct GaBatchTiles { int start[GA_MAX_BATCH + 1]; };
+
+__global__ __launch_bounds__(1024) void ga_merge_kernel(const float* __restrict__ part_all, GaBatchTiles bt, int K, int Di,
+                                                        float* __restrict__ afeat_all) {
+    const int bag = blockIdx.z;
+    const int tiles = bt.start[bag + 1] - bt.start[bag];
+    const float* part = part_all + (size_t)bt.start[bag] * K * (2 + Di);
+    float* afeat = afeat_all + (size_t)bag * K * Di;
     __shared__ float red[GA_MERGE_GROUPS][66];
     __shared__ float smx[GA_MERGE_GROUPS];
     const int k = blockIdx.x, c = blockIdx.y;
@@ -74,6 +80,11 @@ __global__ __launch_bounds__(256) void ga_heads_kernel(const float* __restrict__
     float* bf = af + (size_t)L.K * L.Di;    // [Di]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = L.K, C = L.C, Di = L.Di;
+    const int bag = blockIdx.x;             // batched launch: one workgroup per bag
+    afeat += (size_t)bag * K * Di;
+    if (sub_preds) sub_preds += (size_t)bag * K * C;
+    if (slide_pred) slide_pred += (size_t)bag * C;
+    if (bag_feat) bag_feat += (size_t)bag * Di;
     for (int e = tid; e < K * Di; e += 256) af[e] = afeat[e];
     __syncthreads();
     for (int di = tid; di < Di; di += 256) {
@@ -125,21 +136,85 @@ extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, i
     return (b + 255) & ~(size_t)255;
 }
 
-// merge + heads shared by the fused forward and the masked pooling pass
-int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
-              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st) {
+// merge + heads shared by the fused forward (batched) and the masked pooling pass.
+// part: partials of all bags back to back; tile_start[b]: first tile of bag b; afeat scratch lives after the partials.
+static int ga_finish_batch(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L,
+                           float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                           float* af_scratch, hipStream_t st) {
     const int K = L.K, Di = L.Di;
-    size_t poff = ((size_t)tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
-    float* af = afeat ? afeat : (float*)((char*)workspace + poff);
-    hipLaunchKernelGGL(ga_merge_kernel, dim3(K, Di / 64), dim3(1024), 0, st, part, tiles, K, Di, af);
+    GaBatchTiles bt;
+    for (int b = 0; b <= GA_MAX_BATCH; ++b) bt.start[b] = b <= nbags ? tile_start[b] : tile_start[nbags];
+    float* af = afeat ? afeat : af_scratch;
+    hipLaunchKernelGGL(ga_merge_kernel, dim3(K, Di / 64, nbags), dim3(1024), 0, st, part, bt, K, Di, af);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     if (sub_preds || slide_pred || bag_feat) {
         const size_t lds = ((size_t)K * Di + Di) * sizeof(float);
-        hipLaunchKernelGGL(ga_heads_kernel, dim3(1), dim3(256), lds, st, af, (const char*)packed, L, has_bag_head,
+        hipLaunchKernelGGL(ga_heads_kernel, dim3(nbags), dim3(256), lds, st, af, (const char*)packed, L, has_bag_head,
                            sub_preds, slide_pred, bag_feat);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     return ACMIL_OK;
+}
+
+int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
+              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st) {
+    const int ts[2] = {0, tiles};
+    size_t poff = ((size_t)tiles * L.K * ga_part_stride(L.Di) * sizeof(float) + 255) & ~(size_t)255;
+    return ga_finish_batch(part, ts, 1, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
+                           (float*)((char*)workspace + poff), st);
+}
+
+static int ga_pick_waves(int maxN) {
+    // tile geometry: 8-wave (256-patch) workgroups stream the weights once per 256 patches; small bags use
+    // 4-wave (128-patch) workgroups, two per CU, to spread over more CUs.  ACMIL_GA_WAVES=4|8 overrides (tuning).
+    int w = (maxN >= 32768) ? 8 : 4;
+    const char* e = getenv("ACMIL_GA_WAVES");
+    if (e && (atoi(e) == 4 || atoi(e) == 8)) w = atoi(e);
+    return w;
+}
+
+extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D, int Di, int K, int C, int mode) {
+    (void)D; (void)C; (void)mode;
+    if (nbags <= 0 || nbags > GA_MAX_BATCH || !Ns || Di <= 0 || K <= 0) return 0;
+    size_t tiles = 0;
+    for (int b = 0; b < nbags; ++b) { if (Ns[b] <= 0) return 0; tiles += ga_pool_tiles(Ns[b]); }
+    size_t bytes = (tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
+    bytes += ((size_t)nbags * K * Di * sizeof(float) + 255) & ~(size_t)255;
+    return bytes;
+}
+
+extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
+                                      int D, int Di, int Da, int K, int C, int mode, float* const* A_outs,
+                                      float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
+                                      int has_bag_head, void* workspace, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (nbags <= 0 || nbags > GA_MAX_BATCH) return ACMIL_ERR_SHAPE;
+    if (!xs || !Ns || !packed || !workspace) return ACMIL_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    GaFwdArgs a;
+    int maxN = 0;
+    for (int b = 0; b < nbags; ++b) {
+        if (Ns[b] <= 0) return ACMIL_ERR_SHAPE;
+        if (!xs[b]) return ACMIL_ERR_NULL;
+        if (Ns[b] > maxN) maxN = Ns[b];
+    }
+    a.waves = ga_pick_waves(maxN);
+    a.tile_start[0] = 0;
+    for (int b = 0; b < GA_MAX_BATCH; ++b) {
+        a.xs[b] = b < nbags ? xs[b] : nullptr;
+        a.Ns[b] = b < nbags ? Ns[b] : 0;
+        a.A_outs[b] = (b < nbags && A_outs) ? A_outs[b] : nullptr;
+        a.tile_start[b + 1] = a.tile_start[b] + (b < nbags ? (Ns[b] + 32 * a.waves - 1) / (32 * a.waves) : 0);
+    }
+    a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = nullptr;
+    a.L = ga_layout(D, Di, K, C, mode);
+    rc = ga_dispatch(a, mode, x_dtype, true, st);
+    if (rc != ACMIL_OK) return rc;
+    if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
+    const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
+    return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
+                           (float*)((char*)workspace + poff), st);
 }
 
 extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,
@@ -153,23 +228,23 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     if (pool && !workspace) return ACMIL_ERR_NULL;
     if (pool && h_save) return ACMIL_ERR_UNSUPPORTED;  // score pass (h_save) and pooled outputs are separate calls
     if (!pool && !h_save && !A_out) return ACMIL_ERR_NULL;
+    if (!h_save) {
+        // eval / scores-only: the batched path with one bag (scores-only drops the partials it writes)
+        if (!workspace) return ACMIL_ERR_NULL;
+        float* A1[1] = {A_out};
+        const void* x1[1] = {x};
+        return acmil_ga_forward_batch(1, x1, &N, x_dtype, packed, D, Di, Da, K, C, mode, A1, sub_preds, slide_pred, afeat,
+                                      bag_feat, has_bag_head, workspace, stream);
+    }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.x = x; a.packed = (const char*)packed; a.A_out = A_out; a.part = (float*)workspace; a.h_save = h_save; a.N = N;
+    a.waves = ga_pick_waves(N);
+    for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
+    a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
+    for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);
+    a.nbags = 1; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = h_save;
     a.L = ga_layout(D, Di, K, C, mode);
-    // tile geometry: 8-wave (256-patch) workgroups stream the weights once per 256 patches; small bags use
-    // 4-wave (128-patch) workgroups, two per CU, to spread over more CUs.  ACMIL_GA_WAVES=4|8 overrides (tuning).
-    a.waves = (N >= 32768) ? 8 : 4;
-    { const char* e = getenv("ACMIL_GA_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) a.waves = atoi(e); }
-    if (!pool && !h_save) {
-        // scores only: run the pooled variant into the workspace and drop its partials
-        if (!workspace) return ACMIL_ERR_NULL;
-        return ga_dispatch(a, mode, x_dtype, true, st);
-    }
-    rc = ga_dispatch(a, mode, x_dtype, pool, st);
-    if (rc != ACMIL_OK || !pool) return rc;
-    return ga_finish(a.part, (N + 32 * a.waves - 1) / (32 * a.waves), packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
-                     workspace, st);
+    return ga_dispatch(a, mode, x_dtype, false, st);
 }
 
 extern "C" const char* acmil_version(void) { return "acmil_hip 0.1 (gfx950)"; }

