@@ -218,7 +218,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
         // wait for W(s) and for this wave's x(s+1); the rest of step s+1 and all of step s+2 stay in flight
         if (s + G::PD - 1 < S1) ga_wait_vm<STEADYW>(); else ga_wait_vm<TAILW>();
         __builtin_amdgcn_s_barrier();
-        issue_step(s + G::PD);
+        // (the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
+        //  VALU, M0 writes, ~100 cycles per instruction -- then overlaps matrix-core work instead of delaying it)
         const char* slot = smem + (s % G::NB) * G::SLOT;
         float xvn[8];
         f16x8 xhn, xln;
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
+                if (half == 1) issue_step(s + G::PD);
                 if (half == 1 && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);   // next step's x: overlaps this step's MFMAs
                 f32x4 wf[ND];
 #pragma unroll
@@ -241,7 +243,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             // two output tiles at a time, products interleaved so consecutive MFMAs hit different accumulators
 #pragma unroll
             for (int d = 0; d < ND; d += 2) {
-                if (d == 2 && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);      // next step's x: overlaps this step's MFMAs
+                if (d == 2) issue_step(s + G::PD);
+                if (d == (ND > 4 ? 4 : 2) && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);   // next step's x: overlaps this step's MFMAs
                 const f16x8 wh0 = wb[((d + 0) * PARTS + 0) * 64], wh1 = wb[((d + 1) * PARTS + 0) * 64];
                 acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh, acc1[d + 0], 0, 0, 0);
                 acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh, acc1[d + 1], 0, 0, 0);
@@ -323,11 +326,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             const int s = S1 + j;
             if (j + G::PD - 1 < S2) ga_wait_vm<(G::PD - 1) * G::N2>(); else if (G::PD == 3 && j == S2 - 2) ga_wait_vm<G::N2>(); else ga_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
-            issue_step(s + G::PD);
             const char* slot = smem + (s % G::NB) * G::SLOT;
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) {
                 const int d = 2 * dp + dd;
+                if (dd == 1) issue_step(s + G::PD);
                 if constexpr (F32M) {
                     const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
