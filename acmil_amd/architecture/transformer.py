@@ -187,6 +187,27 @@ class ACMIL_GA(_GatedBase):
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
 
     @torch.no_grad()
+    def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None):
+        """One fused training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), fused ACMIL loss
+        (acmil_ga_loss) and HIP backward, writing the gradients into `p.grad` (allocated on first use, overwritten).
+        Same mathematics as `loss = diff + loss0 + loss1; loss.backward()` of the reference's train_one_epoch
+        (Step3_WSI_classification_ACMIL.py:200-219); the optimiser step stays with the caller.
+        x [1,N,D_feat], label [1] int64 on the GPU.  Returns (losses [4] = loss0, loss1, diff_loss, total, on device; outputs dict)."""
+        packed, dims = self._packed()
+        xb = self._bag(x)
+        params = self._all_params()
+        out = self._masked_forward(xb, packed, dims, uniforms, want_afeat=True,
+                                   masking=self.n_masked_patch > 0 and self.training)
+        losses, d_sub, d_slide, d_A = ops.ga_loss(out["sub_preds"], out.get("slide_pred"), out["A_out"], label)
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], dims, d_sub, d_slide, d_A,
+                        grads_out=[p.grad for p in params])
+        self._last = out
+        return losses, out
+
+    @torch.no_grad()
     def forward_batch(self, bags):
         """Eval forward of up to 16 bags (list of [N_b, D_feat] CUDA tensors, ragged N allowed) in ONE fused launch
         (acmil_ga_forward_batch).  Returns a list of the reference's per-slide triples

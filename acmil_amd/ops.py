@@ -236,7 +236,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
 
 
 def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: torch.Tensor, params: Sequence[torch.Tensor],
-                dims: GaDims, d_sub: torch.Tensor, d_slide: Optional[torch.Tensor], d_A: Optional[torch.Tensor]):
+                dims: GaDims, d_sub: torch.Tensor, d_slide: Optional[torch.Tensor], d_A: Optional[torch.Tensor],
+                grads_out: Optional[Sequence[torch.Tensor]] = None):
     """acmil_ga_backward.  params = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0..Wc_{K-1}, bc_0..bc_{K-1}, (Ws, bs)];
     returns the gradients in the same order."""
     lib = _lib.load()
@@ -245,7 +246,7 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
     Wc = list(params[7:7 + K]); bc = list(params[7 + K:7 + 2 * K])
     Ws = params[7 + 2 * K] if dims.has_bag_head else None
     N, dev = x.shape[0], x.device
-    grads = [torch.empty_like(p) for p in params]
+    grads = list(grads_out) if grads_out is not None else [torch.empty_like(p) for p in params]
     gW1, gWv, gbv, gWu, gbu, gWw, gbw = grads[:7]
     gWc, gbc = grads[7:7 + K], grads[7 + K:7 + 2 * K]
     gWs, gbs = (grads[7 + 2 * K], grads[8 + 2 * K]) if dims.has_bag_head else (None, None)
@@ -306,3 +307,22 @@ def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int,
     if debug:
         out.update(h1=dbg[0], hp=dbg[1], h2=dbg[2])
     return out
+
+
+def ga_loss(sub_preds: torch.Tensor, slide_pred: Optional[torch.Tensor], A_out: torch.Tensor, label: torch.Tensor):
+    """acmil_ga_loss: (losses [4] = loss0, loss1, diff, total; d_sub [K,C]; d_slide [C] or None; d_A [K,N])."""
+    lib = _lib.load()
+    _need_cuda(sub_preds, A_out, label)
+    K, N = A_out.shape[-2], A_out.shape[-1]
+    Cc = sub_preds.shape[1]
+    dev = A_out.device
+    losses = torch.empty(4, dtype=torch.float32, device=dev)
+    d_sub = torch.empty(K, Cc, dtype=torch.float32, device=dev)
+    d_slide = torch.empty(Cc, dtype=torch.float32, device=dev) if slide_pred is not None else None
+    d_A = torch.empty(K, N, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.acmil_ga_loss_workspace_bytes(N, K), dtype=torch.uint8, device=dev)
+    label = label.to(torch.int64)
+    rc = lib.acmil_ga_loss(sub_preds.data_ptr(), _ptr(slide_pred), A_out.data_ptr(), label.data_ptr(), N, K, Cc,
+                           losses.data_ptr(), d_sub.data_ptr(), _ptr(d_slide), d_A.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_loss")
+    return losses, d_sub, d_slide, d_A

@@ -203,33 +203,45 @@ def broadcast_parameters(model, world: int):
 
 # ----------------------------------------------------------------------------------------------- loops
 def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Optional[GradBucket] = None,
-                    rank: int = 0, world: int = 1, log_every: int = 100) -> Dict[str, float]:
-    """One epoch, one slide per iteration per rank (Step3_WSI_classification_ACMIL.py:175-227)."""
+                    rank: int = 0, world: int = 1, log_every: int = 100, fused: bool = True) -> Dict[str, float]:
+    """One epoch, one slide per iteration per rank (Step3_WSI_classification_ACMIL.py:175-227).
+    fused=True uses the module's autograd-free `train_step` (fused HIP loss + backward); fused=False runs the
+    reference's op sequence through torch autograd on top of the HIP forward/backward node (same gradients)."""
     model.train()
     order = epoch_order(len(data), epoch, conf.seed, True, rank, world)
     sums = {"sub_loss": 0.0, "diff_loss": 0.0, "slide_loss": 0.0}
+    acc = torch.zeros(4, device=device)          # loss sums stay on the device: no .item() sync per step
+    use_fused = fused and hasattr(model, "train_step")
     t0 = time.time()
     for it, idx in enumerate(order):
         item = data[idx]
         x = item["input"].to(device, non_blocking=True)            # fp16 stays fp16: converted inside the kernel
         labels = torch.tensor([item["label"]], device=device)
         adjust_learning_rate(optimizer, epoch + it / len(order), conf)
-        sub_preds, slide_preds, attn = model(x.unsqueeze(0))
-        loss0, loss1, diff_loss = acmil_losses(sub_preds, slide_preds, attn, labels, conf.n_token)
-        loss = diff_loss + loss0 + loss1
-        optimizer.zero_grad(set_to_none=False)
-        loss.backward()
+        if use_fused:
+            losses, _ = model.train_step(x.unsqueeze(0), labels)
+            acc += losses
+        else:
+            sub_preds, slide_preds, attn = model(x.unsqueeze(0))
+            loss0, loss1, diff_loss = acmil_losses(sub_preds, slide_preds, attn, labels, conf.n_token)
+            loss = diff_loss + loss0 + loss1
+            optimizer.zero_grad(set_to_none=False)
+            loss.backward()
+            acc += torch.stack([loss0.detach(), loss1.detach(), diff_loss.detach(), loss.detach()])
         if bucket is not None:
             bucket.sync_from_grads()
             bucket.allreduce_mean(world)
         optimizer.step()
-        sums["sub_loss"] += float(loss0); sums["diff_loss"] += float(diff_loss); sums["slide_loss"] += float(loss1)
+        if rank == 0 and log_every and (it + 1) % log_every == 0:
+            a = acc.tolist()
+            sums = {"sub_loss": a[0], "slide_loss": a[1], "diff_loss": a[2]}
         if rank == 0 and log_every and (it + 1) % log_every == 0:
             print("Epoch: [%d] [%d/%d] lr: %.6f sub_loss: %.4f diff_loss: %.4f slide_loss: %.4f (%.1f slides/s/rank)" % (
                 epoch, it + 1, len(order), optimizer.param_groups[0]["lr"], sums["sub_loss"] / (it + 1),
                 sums["diff_loss"] / (it + 1), sums["slide_loss"] / (it + 1), (it + 1) / (time.time() - t0)))
     n = max(1, len(order))
-    return {k: v / n for k, v in sums.items()}
+    a = acc.tolist()
+    return {"sub_loss": a[0] / n, "slide_loss": a[1] / n, "diff_loss": a[2] / n}
 
 
 @torch.no_grad()

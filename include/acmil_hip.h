@@ -161,6 +161,18 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
                       int K, int C, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216
+ * (loss0 = CE(sub_preds, label x K) [0 if K == 1], loss1 = CE(slide_pred, label), diff_loss = mean pairwise cosine
+ * similarity of softmax_N(attn) rows) and the first autograd step through them.
+ *   sub_preds [K,C], slide_pred [C] (NULL without bag head), A_out [K,N] (masked scores), label [1] int64 (device);
+ *   losses [4] = {loss0, loss1, diff_loss, total}; d_sub [K,C], d_slide [C], d_A [K,N] = d total / d (.)
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_loss_workspace_bytes(int N, int K);
+
+int acmil_ga_loss(const float* sub_preds, const float* slide_pred, const float* A_out, const int64_t* label, int N, int K,
+                  int C, float* losses, float* d_sub, float* d_slide, float* d_A, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * TransMIL forward (eval) of one bag.  Replaces TransMIL.forward architecture/transMIL.py:60-91 with its
  * TransLayer :25-28, PPEG :38-45 and NystromAttention (pip nystrom_attention 0.0.12; vendored stand-in
  * architecture/nystrom_attention.py:67-149, pinv :12-27).  heads = 8, dim_head = Di/8, landmarks = Di/2,

@@ -143,3 +143,47 @@ def test_abmil_training_gradients_match_oracle_autograd():
     for name_p, p in model.named_parameters():
         ref = sdg[name_p].grad
         assert (p.grad.cpu() - ref).abs().max() <= 2e-4 * ref.abs().max() + 1e-7, name_p
+
+
+@pytest.mark.parametrize("name", ["ga_train_n640_d512_k5_c2", "ga_train_n2048_d512_k5_c7"])
+def test_fused_train_step_equals_reference_step(name):
+    """model.train_step (fused HIP loss + backward, no autograd) reproduces the reference's losses and gradients."""
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    case, sd = load_golden(name)
+    d, di, k, c = case_dims(sd)
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = d, di, c, k
+
+    model = ACMIL_GA(Conf, n_token=k, n_masked_patch=10, mask_drop=0.6, precision="f16x3")
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    x = torch.from_numpy(case["x"]).cuda().unsqueeze(0)[0:1]
+    losses, out = model.train_step(torch.from_numpy(case["x"]).cuda(), torch.from_numpy(case["label"]).cuda(),
+                                   uniforms=torch.from_numpy(case["uniforms"]).cuda())
+    l = losses.cpu().numpy()
+    assert l[0] == pytest.approx(float(case["loss0"]), abs=2e-5) and l[1] == pytest.approx(float(case["loss1"]), abs=2e-5)
+    assert l[3] == pytest.approx(l[0] + l[1] + l[2], abs=1e-6)
+    for name_p, p in model.named_parameters():
+        ref = case["grad." + name_p]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= 2e-4 * np.abs(ref).max() + 1e-7, (name_p, err)
+
+
+def test_fused_loss_matches_torch_autograd():
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(4)
+    sub = torch.randn(5, 7, generator=g).cuda().requires_grad_(True)
+    slide = torch.randn(1, 7, generator=g).cuda().requires_grad_(True)
+    attn = (torch.randn(1, 5, 3000, generator=g) * 2).cuda()
+    attn[0, 1, 17] = attn[0, 3, 99] = -1e9                      # masked positions
+    attn.requires_grad_(True)
+    y = torch.tensor([4]).cuda()
+    l0, l1, df = _losses(sub, slide, attn, y, 5)
+    (l0 + l1 + df).backward()
+    losses, d_sub, d_slide, d_A = ops.ga_loss(sub.detach(), slide.detach()[0], attn.detach()[0], y)
+    ref = torch.stack([l0, l1, df, l0 + l1 + df]).detach()
+    assert (losses - ref).abs().max() < 2e-6
+    assert (d_sub - sub.grad).abs().max() < 1e-6 and (d_slide - slide.grad[0]).abs().max() < 1e-6
+    assert (d_A - attn.grad[0]).abs().max() <= 1e-4 * attn.grad.abs().max() + 1e-10
+    assert d_A[1, 17] == 0 and d_A[3, 99] == 0

@@ -12,7 +12,11 @@ model = T.build_model(conf).to(dev).train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5)
 xs = [torch.randn(1, args.n, 512, device=dev).half() for _ in range(8)]
 y = torch.tensor([1], device=dev)
+import os as _os
+FUSED = _os.environ.get("FUSED", "1") == "1"
 def step(i):
+    if FUSED:
+        model.train_step(xs[i % 8], y); opt.step(); return
     sub, slide, attn = model(xs[i % 8])
     l0, l1, d = T.acmil_losses(sub, slide, attn, y, 5)
     opt.zero_grad(set_to_none=False); (l0 + l1 + d).backward(); opt.step()
@@ -20,4 +24,4 @@ for i in range(5): step(i)
 torch.cuda.synchronize(); t0 = time.time()
 for i in range(args.iters): step(i)
 torch.cuda.synchronize()
-print("train step N=%d C=%d %s: %.3f ms/step" % (args.n, args.c, args.precision, (time.time() - t0) / args.iters * 1e3))
+print("train step (fused=%s) N=%d C=%d %s: %.3f ms/step" % (FUSED, args.n, args.c, args.precision, (time.time() - t0) / args.iters * 1e3))
