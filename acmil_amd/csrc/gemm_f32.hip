@@ -34,44 +34,54 @@ __device__ __forceinline__ float gm_ldb(const void* B, long long idx) {
     else return __builtin_bit_cast(float, (uint32_t)((const uint16_t*)B)[idx] << 16);
 }
 
+// 4 consecutive elements starting at idx (idx % 4 == 0 and the base 16-B aligned when vec) -> fp32
+template <bool IS_B, int BDT>
+__device__ __forceinline__ void gm_ld4(const void* P, long long idx, bool vec, int nvalid, float (&o)[4]) {
+    constexpr bool HALF = IS_B && (BDT != ACMIL_DTYPE_F32);
+    if (vec && nvalid == 4) {
+        if constexpr (!HALF) {
+            const f32x4 v = *(const f32x4*)((const float*)P + idx);
+            o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+        } else {
+            const uint2 w = *(const uint2*)((const uint16_t*)P + idx);
+            if constexpr (BDT == ACMIL_DTYPE_F16) {
+                o[0] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.x & 0xffffu)); o[1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.x >> 16));
+                o[2] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.y & 0xffffu)); o[3] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w.y >> 16));
+            } else {
+                o[0] = __builtin_bit_cast(float, w.x << 16); o[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+                o[2] = __builtin_bit_cast(float, w.y << 16); o[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (q < nvalid) ? (IS_B ? gm_ldb<BDT>(P, idx + q) : ((const float*)P)[idx + q]) : 0.0f;
+}
+
 // stage one 128 x 32 (or 32 x 128) tile of a row-major matrix into registers; `contig_is_k` tells whether
 // the contiguous memory axis is K (operand stored [rows][K]) or the M/N axis (operand stored [K][rows]).
+// Each thread owns 4 groups of 4 elements that are contiguous in memory: one 16-B (8-B for 16-bit B) load
+// when the matrix is vector-aligned (`vec`) and the group is interior, guarded scalar loads at the edges.
 template <bool IS_B, int BDT>
 __device__ __forceinline__ void gm_load_tile(const void* P, int ld, bool contig_is_k, int r0, int k0, int R, int K,
-                                             int kend, int tid, float (&reg)[4][4]) {
+                                             int kend, int tid, bool vec, float (&reg)[4][4]) {
     if (contig_is_k) {
         // thread -> (row = tid/8 + 32*i, 4 consecutive k at 4*(tid%8))
-        const int kq = 4 * (tid & 7);
+        const int k = k0 + 4 * (tid & 7);
+        const int nv = kend - k < 0 ? 0 : (kend - k > 4 ? 4 : kend - k);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + (tid >> 3) + 32 * i;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0 + kq + q;
-                float v = 0.0f;
-                if (r < R && k < kend) {
-                    const long long idx = (long long)r * ld + k;
-                    v = IS_B ? gm_ldb<BDT>(P, idx) : ((const float*)P)[idx];
-                }
-                reg[i][q] = v;
-            }
+            gm_ld4<IS_B, BDT>(P, (long long)r * ld + k, vec, r < R ? nv : 0, reg[i]);
         }
     } else {
         // thread -> (k = tid/32 + 8*i, 4 consecutive rows at 4*(tid%32))
-        const int rq = 4 * (tid & 31);
+        const int r = r0 + 4 * (tid & 31);
+        const int nv = R - r < 0 ? 0 : (R - r > 4 ? 4 : R - r);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + (tid >> 5) + 8 * i;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + rq + q;
-                float v = 0.0f;
-                if (r < R && k < kend) {
-                    const long long idx = (long long)k * ld + r;
-                    v = IS_B ? gm_ldb<BDT>(P, idx) : ((const float*)P)[idx];
-                }
-                reg[i][q] = v;
-            }
+            gm_ld4<IS_B, BDT>(P, (long long)k * ld + r, vec, k < kend ? nv : 0, reg[i]);
         }
     }
     (void)K;
@@ -128,17 +138,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
+    // vector loads need 16-B (A, fp32 B) / 8-B (16-bit B) aligned groups: base and leading dimension multiples of 4 elements
+    const bool va = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0) && ((kbeg & 3) == 0);
+    const bool vb = ((g.ldb & 3) == 0) && ((((size_t)B) & (BDT == ACMIL_DTYPE_F32 ? 15 : 7)) == 0) && ((kbeg & 3) == 0);
     float ra[4][4], rb[4][4];
-    gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, kbeg, g.M, g.K, kend, tid, ra);
-    gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, kbeg, g.N, g.K, kend, tid, rb);
+    gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, kbeg, g.M, g.K, kend, tid, va, ra);
+    gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, kbeg, g.N, g.K, kend, tid, vb, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
         __syncthreads();   // previous tile fully consumed
         gm_store_tile(As, a_ck, tid, ra);
         gm_store_tile(Bs, b_ck, tid, rb);
         __syncthreads();
         if (k0 + GM_BK < kend) {
-            gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, k0 + GM_BK, g.M, g.K, kend, tid, ra);
-            gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, k0 + GM_BK, g.N, g.K, kend, tid, rb);
+            gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, k0 + GM_BK, g.M, g.K, kend, tid, va, ra);
+            gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, k0 + GM_BK, g.N, g.K, kend, tid, vb, rb);
         }
         const float* ap = As + hi * GM_LD + 64 * wm + i31;
         const float* bp = Bs + hi * GM_LD + 64 * wn + i31;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void tm_landmark_kernel(const float* __restric
     const int j = blockIdx.x;           // landmark
     const int d = Di / TM_HEADS;
     const float inv = 1.0f / (float)l;
-    for (int c = threadIdx.x; c < 2 * Di; c += blockDim.x) {       // c < Di: q column, else k column
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < 2 * Di; c += gridDim.y * blockDim.x) {   // c < Di: q column, else k column
         const float* src = qkv + (size_t)j * l * 3 * Di + c;
         float s = 0.0f;
         for (int t = 0; t < l; ++t) s += src[(size_t)t * 3 * Di];
@@ -196,32 +196,38 @@ __global__ void tm_ppeg_pack_kernel(const float* w7, const float* b7, const floa
     beff[c] = b7[c] + b5[c] + b3[c];
 }
 
-// depth-wise 7x7 on the [side x side] token grid, channels-last (token p = y*side + x lives at row p of `in`);
-// one workgroup = 64 channels x 4 pixels per iteration; thread = channel (coalesced rows)
+// depth-wise 7x7 on the [side x side] token grid, channels-last (token p = y*side + x lives at row p of `in`).
+// One workgroup = 64 channels x an 8 x 8 pixel tile: the 14 x 14 halo tile is staged in LDS (lane = channel, so
+// every LDS access is conflict-free and every global row read is a coalesced 256-B segment); thread (c, g)
+// computes pixels g, g+4, ... of the tile with its 49 taps in registers.
+#define TM_PT 8
 __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
                                                      const float* __restrict__ weff, const float* __restrict__ beff) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    __shared__ float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int tiles_x = (side + TM_PT - 1) / TM_PT;
+    const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
+    for (int e = grp; e < (TM_PT + 6) * (TM_PT + 6); e += 4) {
+        const int yy = ty0 + e / (TM_PT + 6) - 3, xx = tx0 + e % (TM_PT + 6) - 3;
+        tile[e * 64 + cl] = (c < C && yy >= 0 && yy < side && xx >= 0 && xx < side) ? in[((size_t)yy * side + xx) * C + c] : 0.0f;
+    }
+    __syncthreads();
     if (c >= C) return;
     float w[49];
 #pragma unroll
     for (int t = 0; t < 49; ++t) w[t] = weff[(size_t)t * C + c];
     const float b = beff[c];
-    const int npix = side * side;
-    for (int p = blockIdx.y * 4 + (threadIdx.x >> 6); p < npix; p += gridDim.y * 4) {
-        const int y = p / side, x = p % side;
+    for (int p = grp; p < TM_PT * TM_PT; p += 4) {
+        const int py = p / TM_PT, px = p % TM_PT;
+        const int y = ty0 + py, x = tx0 + px;
+        if (y >= side || x >= side) continue;
         float s = b;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const int yy = y + ky - 3;
-            if (yy < 0 || yy >= side) continue;
+        for (int ky = 0; ky < 7; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                const int xx = x + kx - 3;
-                if (xx < 0 || xx >= side) continue;
-                s = fmaf(w[ky * 7 + kx], in[((size_t)yy * side + xx) * C + c], s);
-            }
-        }
-        out[(size_t)p * C + c] = s;
+            for (int kx = 0; kx < 7; ++kx) s = fmaf(w[ky * 7 + kx], tile[((py + ky) * (TM_PT + 6) + px + kx) * 64 + cl], s);
+        out[((size_t)y * side + x) * C + c] = s;
     }
 }
 
@@ -304,7 +310,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
     TM_GEMM(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
-    hipLaunchKernelGGL(tm_landmark_kernel, dim3(m), dim3(256), 0, st, QKV, g.l, m, Di, QL, KL);
+    hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, QKV, g.l, m, Di, QL, KL);
     TM_CHECK_LAUNCH();
     // sim1 = scale q k_l^T  [H, npad, m] ; softmax over m
     TM_GEMM(0, 1, npad, m, d, scale, QKV, 3 * Di, d, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S1, m, (long long)npad * m, nullptr, 0, nullptr, H, gws, st);
@@ -375,8 +381,8 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((Di + 63) / 64), dim3(64), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff);
     hipLaunchKernelGGL(tm_copy_kernel, dim3(1), dim3(256), 0, st, XA + (size_t)g.pad * Di, XB + (size_t)g.pad * Di, (size_t)Di);
     {
-        int gy = (g.nsq + 3) / 4; if (gy > 4096) gy = 4096;
-        hipLaunchKernelGGL(tm_ppeg_kernel, dim3((Di + 63) / 64, gy), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
+        const int tiles = (g.side + TM_PT - 1) / TM_PT;
+        hipLaunchKernelGGL(tm_ppeg_kernel, dim3((Di + 63) / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
                            XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff);
     }
     TM_CHECK_LAUNCH();
