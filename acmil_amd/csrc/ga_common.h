@@ -65,7 +65,7 @@ __host__ __device__ static inline int ga_pool_tiles(int N) { return (N + GA_POOL
 static inline int ga_check_dims(int D, int Di, int Da, int K, int C) {
     if (Da != GA_DA) return ACMIL_ERR_UNSUPPORTED;
     if (D <= 0 || Di <= 0 || K <= 0 || C <= 0) return ACMIL_ERR_SHAPE;
-    if (D % 64 != 0 || Di % 64 != 0) return ACMIL_ERR_SHAPE;
+    if (D % 64 != 0 || Di % 128 != 0) return ACMIL_ERR_SHAPE;
     if (K > ACMIL_MAX_TOKENS || C > ACMIL_MAX_CLASSES) return ACMIL_ERR_UNSUPPORTED;
     return ACMIL_OK;
 }

@@ -2,6 +2,7 @@
 // kernels that finish it: ga_merge_kernel (fixed-order combine of the per-workgroup online-softmax
 // partials) and ga_heads_kernel (K branch heads + bag head).  The fused kernel itself is
 // ga_forward_kernel.h, instantiated per family in ga_forward_inst.hip.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "ga_forward_kernel.h"
@@ -209,8 +210,42 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     }
     a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = nullptr;
     a.L = ga_layout(D, Di, K, C, mode);
+#ifdef GA_TRACE
+    static unsigned long long* tr = nullptr;
+    if (!tr) { hipMalloc(&tr, 8 * 512 * 8); }
+    hipMemset(tr, 0, 8 * 512 * 8);
+    a.trace = tr;
+#endif
     rc = ga_dispatch(a, mode, x_dtype, true, st);
     if (rc != ACMIL_OK) return rc;
+#ifdef GA_TRACE
+    {
+        static int calls = 0;
+        if (++calls == 8) {
+            static unsigned long long h[8 * 512];
+            hipDeviceSynchronize();
+            hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost);
+            const int S1 = D / 16;
+            unsigned long long t0 = h[0];
+            for (int w = 1; w < 8; ++w) if (h[w * 512] < t0) t0 = h[w * 512];
+            for (int s2 = 6; s2 < 14; ++s2) {
+                printf("TRACE step %2d:", s2);
+                for (int w = 0; w < 8; ++w) {
+                    unsigned long long* q = h + w * 512 + 4 * s2;
+                    printf(" w%d[arr %5llu wait %4llu bar %4llu body %4llu]", w, q[0] - t0, q[1] - q[0], q[2] - q[1], q[3] - q[2]);
+                }
+                printf("\n");
+            }
+            printf("TRACE step 9 sub-phases (cycles after barrier release): hh-MFMAs issued / DMA issued / lh-MFMAs issued / x read+split / end\n");
+            for (int w = 0; w < 8; ++w) {
+                unsigned long long* q = h + w * 512;
+                unsigned long long b0 = q[4 * 9 + 2];
+                printf("TRACE   w%d: gemm1 %llu relu+cvt %llu gemm2 blocks %llu %llu %llu %llu scores %llu pool %llu comb %llu total %llu\n", w, q[400] - q[0], q[4 * S1] - q[400], q[300] - q[400], q[301] - q[300], q[302] - q[301], q[303] - q[302], q[402] - q[401], q[403] - q[402], q[404] - q[403], q[404] - q[0]);
+            }
+            (void)S1;
+        }
+    }
+#endif
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,

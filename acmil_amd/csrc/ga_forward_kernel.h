@@ -44,13 +44,38 @@ struct GaFwdArgs {
     float* part;     // workspace partials [total tiles][K][2+Di]
     float* h_save;   // [N,Di] or null (single-bag score pass only)
     int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
+#ifdef GA_TRACE
+    unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0
+#endif
     GaLayout L;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-#define GA_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc), (lptr_t)(ldst), 16, 0, 0)
+// LDS-DMA of 16 B per lane (global_load_lds_dwordx4): lane l's 16 bytes at gsrc land at ldst + 16*l (ldst wave-uniform).
+// Issued through inline asm on purpose: with the __builtin_amdgcn_global_load_lds builtin hipcc's wait-count pass
+// treats the LDS counter as out of order and guards EVERY ds_read consumer with s_waitcnt lgkmcnt(0) -- a wave then
+// waits for all 16 fragment reads of a step before its first MFMA instead of counting down (15, 14, ...).  The asm
+// form is invisible to that pass; its completion is tracked by the hand-counted ga_wait_vm<> below.  M0 carries the
+// LDS destination and is compiler-reserved: saved and restored inside the statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void ga_glds16(const char* gsrc, unsigned ldst) {   // ldst: wave-uniform LDS byte address
+    unsigned keep;
+    const unsigned lds = __builtin_amdgcn_readfirstlane(ldst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+}
+#ifdef GA_GLDS_BUILTIN
+#define GA_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc), (lptr_t)(size_t)(ldst), 16, 0, 0)
+#else
+#define GA_GLDS16(gsrc, ldst) ga_glds16((const char*)(gsrc), (unsigned)(ldst))
+#endif
+
+#ifdef GA_TRACE
+#define GA_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.trace[(threadIdx.x >> 6) * 512 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GA_STAMP(i) do {} while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void ga_wait_vm() {
@@ -60,18 +85,24 @@ __device__ __forceinline__ void ga_wait_vm() {
 template <int ND, int KP, int MODE, int XDT, int WAVES>
 struct GaGeom {
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;       // bytes per bag element
-    static constexpr int WROWS1 = (MODE == ACMIL_MODE_F16) ? ND : 2 * ND;  // fragment rows per GEMM1 step
-    static constexpr int WROWS2 = (MODE == ACMIL_MODE_F16) ? 8 : 16;       // fragment rows per GEMM2 step (g, d)
-    static constexpr int WG1 = (WROWS1 + WAVES - 1) / WAVES;    // weight LDS-DMA instructions per wave per step
-    static constexpr int WG2 = (WROWS2 + WAVES - 1) / WAVES;
+    static constexpr int WROWS = (MODE == ACMIL_MODE_F16) ? ND : 2 * ND;   // fragment rows per step (GEMM1 and GEMM2 alike)
+    static constexpr int DD = ND / 4;                                 // h tiles consumed per GEMM2 step (4 steps per unit block)
+    static constexpr int WG1 = (WROWS + WAVES - 1) / WAVES;           // weight LDS-DMA instructions per wave per step
     static constexpr int XG = 32 * 16 * XE / 1024;                    // x LDS-DMA instructions per wave per step
-    static constexpr int N1 = WG1 + XG, N2 = WG2;                     // VMEM ops per wave per GEMM1 / GEMM2 step
-    static constexpr int WSLOT = ((WROWS1 > WROWS2 ? WROWS1 : WROWS2) + WAVES - 1) / WAVES * WAVES * GA_FRAG_ROW;
+    static constexpr int N1 = WG1 + XG;                               // VMEM ops per wave per step (every step issues the same)
+    // 8-wave workgroups ALTERNATE the LDS-DMA issue between the two waves of each SIMD: waves 0-3 issue the even
+    // steps, waves 4-7 the odd ones (for both x tiles of the pair and 1/4 of the weight rows).  While one wave of a SIMD
+    // spends ~600 cycles in the vector-memory issue path, its partner has the matrix pipe to itself.
+    static constexpr bool ALT = (WAVES == 8);
+    static constexpr int WGA = (WROWS + 3) / 4;                       // weight rows per issuing wave (ALT)
+    static constexpr int NA = 2 * XG + WGA;                           // VMEM ops per issuing wave per step (ALT)
+    static constexpr int WSLOT = (WROWS + WAVES - 1) / WAVES * WAVES * GA_FRAG_ROW;
     static constexpr int XB = 32 * 16 * XE;                           // x bytes per wave per step
     static constexpr int SLOT = WSLOT + WAVES * XB;
     static constexpr int NB = (WAVES == 8) ? 4 : 3;                   // ring slots (8-wave WG: 1 per CU; 4-wave WG: 2 per CU)
     static constexpr int PD = NB - 1;                                 // prefetch distance in steps
     static constexpr int ROWS = 32 * WAVES;                           // patches per workgroup
+    static_assert(ND % 4 == 0, "Di must be a multiple of 128");
     static constexpr int RING = NB * SLOT;
     static constexpr int POOLW = 64 * 36 * 4;                         // wave-private [64 di][32 m (+4 pad)] fp32
     static constexpr int REGION0 = (RING > WAVES * POOLW) ? RING : WAVES * POOLW;
@@ -108,52 +139,58 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     const int row = m0 + i31;
     const bool valid = row < N;
 
-    const char* g1 = a.packed + L.g1_off;
-    const char* g2 = a.packed + L.g2_off;
+    const char* wstream = a.packed + L.g1_off;   // GEMM1 rows then GEMM2 rows, contiguous: step u starts at u * WROWS rows
     const int S1 = D / 16;                 // GEMM1 steps
-    constexpr int S2 = 2 * ND;             // GEMM2 steps (unit block g of 4, h tile pair dp)
+    constexpr int S2 = 16;                 // GEMM2 steps: 4 unit blocks x 4 (each consumes DD h tiles)
+    const int SL = S1 + S2 - 1;            // last real step
 
     // ---- per-lane source pointer of the x tile copy.  fp32: 2 instructions/step, lane l -> (row 16q + l/4, 16-B piece
     // (l&3) ^ swz(row)); 16-bit: 1 instruction, lane l -> (row l/2, piece (l&1) ^ swz(row)).  LDS image is lane-linear.
-    const char* xsrc[G::XG];
+    constexpr int NXT = G::ALT ? 2 : 1;        // x tiles this wave copies: its own, and (ALT) its SIMD partner's (wave ^ 4)
+    const char* xsrc[NXT][G::XG];
 #pragma unroll
-    for (int q = 0; q < G::XG; ++q) {
-        int r, piece;
-        if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
-        else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
-        int gr = m0 + r;
-        gr = gr < N ? gr : N - 1;
-        xsrc[q] = xbase + (size_t)gr * D * G::XE + piece * 16;
-    }
-
-    auto issue_step = [&](int s) {
-        char* slot = smem + (s % G::NB) * G::SLOT;
-        if (s < S1) {
-            {   // x first: step s only needs x(s+1) early (software-pipelined convert), not W(s+1)
-                char* xdst = slot + G::WSLOT + wave * G::XB;
+    for (int t = 0; t < NXT; ++t)
 #pragma unroll
-                for (int q = 0; q < G::XG; ++q) GA_GLDS16(xsrc[q] + (size_t)s * 16 * G::XE, xdst + q * 1024);
-            }
-            {
-                const char* src = g1 + (size_t)s * G::WROWS1 * GA_FRAG_ROW + lane * 16;
-#pragma unroll
-                for (int q = 0; q < G::WG1; ++q) {
-                    int r = q * WAVES + wave;
-                    r = (G::WROWS1 % WAVES == 0) ? r : (r % G::WROWS1);   // padded rows re-fetch a valid row
-                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * WAVES + wave) * GA_FRAG_ROW);
-                }
-            }
-        } else if (s < S1 + S2) {
-            {
-                const char* src = g2 + (size_t)(s - S1) * G::WROWS2 * GA_FRAG_ROW + lane * 16;
-#pragma unroll
-                for (int q = 0; q < G::WG2; ++q) {
-                    int r = q * WAVES + wave;
-                    r = (G::WROWS2 % WAVES == 0) ? r : (r % G::WROWS2);
-                    GA_GLDS16(src + (size_t)r * GA_FRAG_ROW, slot + (q * WAVES + wave) * GA_FRAG_ROW);
-                }
-            }
+        for (int q = 0; q < G::XG; ++q) {
+            int r, piece;
+            if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
+            else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
+            int gr = m0 + (t ? ((wave ^ 4) - wave) * 32 : 0) + r;
+            gr = gr < N ? gr : N - 1;
+            gr = gr < 0 ? 0 : gr;
+            xsrc[t][q] = xbase + (size_t)gr * D * G::XE + piece * 16;
         }
+    const int wrow0 = G::ALT ? (wave & 3) : wave;                 // first weight row this wave copies; stride 4 (ALT) or WAVES
+    const char* wsrc = wstream + lane * 16;
+
+    // Every issuing wave issues the SAME number of LDS-DMA instructions per step (so all s_waitcnt counts are constants):
+    // steps past the end of a stream re-fetch its last step (clamped source, L2 hits) into the slot the ring discipline
+    // assigns -- data nobody reads.
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic region
+    auto issue_step = [&](int u) {
+        if constexpr (G::ALT) { if ((wave >> 2) != (u & 1)) return; }
+        const unsigned slot = lds_base + (u % G::NB) * G::SLOT;
+        const int ux = u < S1 ? u : S1 - 1;
+        const int uw = u < SL ? u : SL;
+#if !defined(GA_EXP) || !(GA_EXP & 1)
+#pragma unroll
+        for (int t = 0; t < NXT; ++t) {                           // x first (see the waits)
+            const unsigned xdst = slot + G::WSLOT + (t ? (wave ^ 4) : wave) * G::XB;
+#pragma unroll
+            for (int q = 0; q < G::XG; ++q) GA_GLDS16(xsrc[t][q] + (size_t)ux * 16 * G::XE, xdst + q * 1024);
+        }
+#endif
+#if !defined(GA_EXP) || !(GA_EXP & 2)
+        const char* src = wsrc + (size_t)uw * G::WROWS * GA_FRAG_ROW;
+        constexpr int RSTRIDE = G::ALT ? 4 : WAVES;
+        constexpr int NW = G::ALT ? G::WGA : G::WG1;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int r = wrow0 + q * RSTRIDE;                    // rows beyond WROWS (padding) re-fetch a valid row
+            GA_GLDS16(src + (size_t)(r % G::WROWS) * GA_FRAG_ROW, slot + r * GA_FRAG_ROW);
+        }
+#endif
+        (void)ux; (void)uw;
     };
 
     // epilogue vectors bv, bu, Ww -> LDS (rows K..KP-1 of Ww zero); visible after the first step barrier
@@ -209,16 +246,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             }
         }
     };
-    // x(0) is wave-private: only this wave's own DMA has to land (no barrier)
-    ga_wait_vm<G::WG1 + (G::PD - 1) * G::N1>();
+    if constexpr (G::ALT) {
+        // steps 0 and 2 were issued by waves 0-3, step 1 by waves 4-7; x(0) of BOTH waves of a pair was copied by the even
+        // group: it waits for it (newer: W(0) and all of step 2), then a barrier publishes it to the partner
+        static_assert(G::PD == 3, "alternating issue assumes a prefetch distance of 3 steps");
+        if ((wave >> 2) == 0) ga_wait_vm<G::WGA + G::NA>();
+        __builtin_amdgcn_s_barrier();
+    } else {
+        // x(0) is wave-private: only this wave's own DMA has to land (no barrier)
+        ga_wait_vm<G::WG1 + (G::PD - 1) * G::N1>();
+    }
     load_x(0, xv, xh, xl);
-    constexpr int STEADYW = G::WG1 + (G::PD - 2) * G::N1;                       // W(s+1) + steps s+2 .. s+PD-1
-    constexpr int TAILW = (G::PD - 1) * (G::WG1 < G::N2 ? G::WG1 : G::N2);       // lower bound near the GEMM1/GEMM2 seam
+    // Drain the scalar-load / LDS counter once, with the BUILTIN (which hipcc's wait-count pass models): otherwise the
+    // kernarg s_loads still pending at the loop header make lgkmcnt "out of order" in the compiler's model and every
+    // first MFMA of a step waits lgkmcnt(0) -- for all 16 fragment reads instead of the first one.
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0) only
+    constexpr int WAIT1 = G::WG1 + (G::PD - 2) * G::N1;    // newer than x(s+1): W(s+1) and all of steps s+2 .. s+PD-1
+    constexpr int WAIT2 = (G::PD - 1) * G::N1;             // GEMM2 only needs W(s): all of steps s+1 .. s+PD-1 may be in flight
     for (int s = 0; s < S1; ++s) {
         // wait for W(s) and for this wave's x(s+1); the rest of step s+1 and all of step s+2 stay in flight
-        if (s + G::PD - 1 < S1) ga_wait_vm<STEADYW>(); else ga_wait_vm<TAILW>();
+        GA_STAMP(4 * s + 0);
+        if constexpr (G::ALT) {
+            // the group that issued step s (and, one step ago, step s+2) needs all of step s: its step s+2 stays in flight;
+            // the other group issued step s+1 (x first) and needs x(s+1): its W(s+1) stays in flight
+            if ((wave >> 2) == (s & 1)) ga_wait_vm<G::NA>(); else ga_wait_vm<G::WGA>();
+        } else ga_wait_vm<WAIT1>();
+        GA_STAMP(4 * s + 1);
         __builtin_amdgcn_s_barrier();
-        // (the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
+        GA_STAMP(4 * s + 2);
+        if constexpr (G::ALT) issue_step(s + G::PD);   // issuing wave: DMA first, while its partner owns the matrix pipe
+        // (non-ALT: the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
         //  VALU, M0 writes, ~100 cycles per instruction -- then overlaps matrix-core work instead of delaying it)
         const char* slot = smem + (s % G::NB) * G::SLOT;
         float xvn[8];
@@ -227,8 +284,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                if (half == 1) issue_step(s + G::PD);
-                if (half == 1 && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);   // next step's x: overlaps this step's MFMAs
+                if (half == 1 && !G::ALT) issue_step(s + G::PD);
+                if (half == 1) load_x(s + 1, xvn, xhn, xln);   // next step's x (dummy after the last): overlaps this step's MFMAs
                 f32x4 wf[ND];
 #pragma unroll
                 for (int d = 0; d < ND; ++d) wf[d] = wb[(d * 2 + half) * 64];
@@ -240,29 +297,43 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             }
         } else {
             const f16x8* wb = (const f16x8*)slot + lane;
-            // two output tiles at a time, products interleaved so consecutive MFMAs hit different accumulators
+            // All A fragments of the step are requested up front, "hi" parts first, and the MFMAs consume them in
+            // request order, so the compiler's lgkmcnt waits count down (15, 14, ...) and only the FIRST fragment's
+            // LDS latency is exposed after the barrier.  sched_barrier(0) keeps hipcc from re-clustering the phases.
+            f16x8 wh[ND], wl[SPLIT ? ND : 1];
 #pragma unroll
-            for (int d = 0; d < ND; d += 2) {
-                if (d == 2) issue_step(s + G::PD);
-                if (d == (ND > 4 ? 4 : 2) && s + 1 < S1) load_x(s + 1, xvn, xhn, xln);   // next step's x: overlaps this step's MFMAs
-                const f16x8 wh0 = wb[((d + 0) * PARTS + 0) * 64], wh1 = wb[((d + 1) * PARTS + 0) * 64];
-                acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh, acc1[d + 0], 0, 0, 0);
-                acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh, acc1[d + 1], 0, 0, 0);
-                if constexpr (SPLIT) {
-                    const f16x8 wl0 = wb[((d + 0) * PARTS + 1) * 64], wl1 = wb[((d + 1) * PARTS + 1) * 64];
-                    acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, xh, acc1[d + 0], 0, 0, 0);
-                    acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, xh, acc1[d + 1], 0, 0, 0);
-                    if constexpr (XLO) {
-                        acc1[d + 0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xl, acc1[d + 0], 0, 0, 0);
-                        acc1[d + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xl, acc1[d + 1], 0, 0, 0);
-                    }
+            for (int d = 0; d < ND; ++d) wh[d] = wb[d * 64];               // packed: ND "hi" rows, then ND "lo" rows
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[d], xh, acc1[d], 0, 0, 0);
+                if (SPLIT && d == 1) {                                       // "lo" requests go out under the first MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int d2 = 0; d2 < ND; ++d2) wl[d2] = wb[(ND + d2) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!G::ALT) issue_step(s + G::PD);   // LDS-DMA issue in the shadow of the MFMAs just queued
+            if constexpr (SPLIT) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[d], xh, acc1[d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_x(s + 1, xvn, xhn, xln);                // next step's x (dummy after the last): read + f16 split
+            if constexpr (XLO) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[d], xl, acc1[d], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = xvn[j];
         xh = xhn; xl = xln;
+        GA_STAMP(4 * s + 3);
     }
+    GA_STAMP(400);
 
     // =========================================================== relu
     // acc1[d][r] now holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)]
@@ -321,16 +392,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
                 acc2[al][4 * rq + 2] = b[2]; acc2[al][4 * rq + 3] = b[3];
             }
 #pragma unroll
-        for (int dp = 0; dp < ND / 2; ++dp) {
-            const int j = g * (ND / 2) + dp;     // GEMM2 step index, compile-time after unrolling
-            const int s = S1 + j;
-            if (j + G::PD - 1 < S2) ga_wait_vm<(G::PD - 1) * G::N2>(); else if (G::PD == 3 && j == S2 - 2) ga_wait_vm<G::N2>(); else ga_wait_vm<0>();
+        for (int st = 0; st < 4; ++st) {
+            const int s = S1 + g * 4 + st;
+            GA_STAMP(4 * s + 0);
+            if constexpr (G::ALT) {
+                // S1 is even (D % 64 == 0), so step parity == (g*4 + st) parity: the group that issued step s drains it
+                if ((wave >> 2) == (st & 1)) ga_wait_vm<G::NA>();
+            } else ga_wait_vm<WAIT2>();
+            GA_STAMP(4 * s + 1);
             __builtin_amdgcn_s_barrier();
+            GA_STAMP(4 * s + 2);
+            if constexpr (G::ALT) issue_step(s + G::PD);
             const char* slot = smem + (s % G::NB) * G::SLOT;
 #pragma unroll
-            for (int dd = 0; dd < 2; ++dd) {
-                const int d = 2 * dp + dd;
-                if (dd == 1) issue_step(s + G::PD);
+            for (int dd = 0; dd < G::DD; ++dd) {
+                const int d = G::DD * st + dd;
+                if (dd == G::DD - 1 && !G::ALT) issue_step(s + G::PD);
                 if constexpr (F32M) {
                     const f32x4* wb = (const f32x4*)slot + lane;
 #pragma unroll
@@ -344,21 +421,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
                     }
                 } else {
                     const f16x8* wb = (const f16x8*)slot + lane;
+                    // same discipline as GEMM1: request the 4 "hi" then the 4 "lo" fragments of this h tile, consume in order
+                    f16x8 wh[4], wl[SPLIT ? 4 : 1];
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const f16x8 wh0 = wb[(((dd * 2 + e) * 2 + 0) * PARTS + 0) * 64];
-                        const f16x8 wh1 = wb[(((dd * 2 + e) * 2 + 1) * PARTS + 0) * 64];
-                        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, hh[d][e], acc2[0], 0, 0, 0);
-                        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, hh[d][e], acc2[1], 0, 0, 0);
-                        if constexpr (SPLIT) {
-                            const f16x8 wl0 = wb[(((dd * 2 + e) * 2 + 0) * PARTS + 1) * 64];
-                            const f16x8 wl1 = wb[(((dd * 2 + e) * 2 + 1) * PARTS + 1) * 64];
-                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, hh[d][e], acc2[0], 0, 0, 0);
-                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, hh[d][e], acc2[1], 0, 0, 0);
-                            acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, hl[d][e], acc2[0], 0, 0, 0);
-                            acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, hl[d][e], acc2[1], 0, 0, 0);
-                        }
+                    for (int t = 0; t < 4; ++t) wh[t] = wb[((dd * PARTS + 0) * 4 + t) * 64];      // t = e*2 + al
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) wl[t] = wb[((dd * PARTS + 1) * 4 + t) * 64];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], hh[d][t >> 1], acc2[t & 1], 0, 0, 0);
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], hh[d][t >> 1], acc2[t & 1], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], hl[d][t >> 1], acc2[t & 1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -379,8 +459,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
                 sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
             }
         }
+        GA_STAMP(300 + g);
     }
 
+    GA_STAMP(401);
     const float* bwp = (const float*)(a.packed + L.bw_off);
     float smax[KP], lsum[KP], pe[KP];
 #pragma unroll
@@ -400,6 +482,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     }
 
     // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
+    GA_STAMP(402);
+    ga_wait_vm<0>();  // the clamped tail DMAs still target the ring: drain them before it is reused
     __syncthreads();  // every wave is done with the ring; region 0 becomes the pooling tiles
     float* pool = (float*)(smem + wave * G::POOLW);
     float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // [KP][32 m]
@@ -446,6 +530,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             }
         }
     }
+    GA_STAMP(403);
     if constexpr (!POOL) return;
 
     // =========================================================== combine the 8 waves, publish the partial
@@ -484,6 +569,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             out[k * PS + e] = v;
         }
     }
+    GA_STAMP(404);
 }
 
 // launcher for one (ND, KP, MODE, XDT) family; pool=true -> eval variant, else the h-saving score pass.

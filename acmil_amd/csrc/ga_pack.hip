@@ -43,10 +43,12 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
             const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 16 * st + 8 * hi + 4 * half;
             *(f32x4*)dst = *(const f32x4*)src;
         } else {
-            // F16X3: row = (s*ND + d)*2 + part ; F16: row = s*ND + d ; lane holds 8 f16 W1[32d+i][16s + 8hi + j]
+            // F16X3: row = (s*2 + part)*ND + d (all "hi" fragments of a step, then all "lo") ; F16: row = s*ND + d ;
+            // lane holds 8 f16 W1[32d+i][16s + 8hi + j]
             size_t r = row; int part = 0;
+            const int d = r % ND; r /= ND;
             if (L.mode == ACMIL_MODE_F16X3) { part = r & 1; r >>= 1; }
-            const int d = r % ND, st = r / ND;
+            const int st = r;
             const float* src = a.W1 + (size_t)(32 * d + i) * L.D + 16 * st + 8 * hi;
             f16x8 v;
             for (int j = 0; j < 8; ++j) { _Float16 h, l; split_f16(src[j], h, l); v[j] = part ? l : h; }
@@ -57,23 +59,29 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
     size_t r2 = row - L.g1_rows;
     if (r2 < L.g2_rows) {
         char* dst = a.out + L.g2_off + r2 * GA_FRAG_ROW + lane * 16;
-        // GEMM2 step j = g4*(ND/2) + dp: unit block g4 (tiles at = 2*g4 + al, al = 0 tanh / 1 sigmoid branch),
-        // h tiles d = 2*dp + dd.  K-slot <-> GEMM1 accumulator register of tile d (see header comment).
+        // GEMM2 step j = 4*g4 + st (st < 4): unit block g4 (tiles at = 2*g4 + al, al = 0 tanh / 1 sigmoid branch),
+        // h tiles d = DD*st + dd with DD = ND/4.  K-slot <-> GEMM1 accumulator register of tile d (see header comment).
+        const int DD = ND / 4;
         if (L.mode == ACMIL_MODE_F32) {
-            // local row = (dd*4 + r4)*2 + al ; lane holds Wvu[at,i][32d + 8r4 + 4hi + q], q<4
-            const int loc = r2 % 16; const size_t j = r2 / 16;
+            // local row = (dd*4 + r4)*2 + al (8*DD per step) ; lane holds Wvu[at,i][32d + 8r4 + 4hi + q], q<4
+            const int per = 8 * DD;
+            const int loc = r2 % per; const size_t j = r2 / per;
             const int al = loc & 1, r4 = (loc >> 1) & 3, dd = loc >> 3;
-            const int g4 = j / (ND / 2), d = 2 * (j % (ND / 2)) + dd, at = 2 * g4 + al;
+            const int g4 = j / 4, d = DD * (j % 4) + dd, at = 2 * g4 + al;
             const float* src = vu_row(a, at, i) + 32 * d + 8 * r4 + 4 * hi;
             *(f32x4*)dst = *(const f32x4*)src;
         } else {
-            // F16X3: local row = ((dd*2 + e)*2 + al)*2 + part (16/step) ; F16: (dd*2 + e)*2 + al (8/step)
+            // F16X3: local row = (dd*2 + part)*4 + e*2 + al (8*DD per step: per h tile 4 "hi" rows then 4 "lo" rows) ;
+            // F16: dd*4 + e*2 + al (4*DD per step)
             // slot jj <-> GEMM1 accumulator register 8e+jj of tile d: di = 32d + (jj&3) + 8(2e + (jj>>2)) + 4hi
-            size_t r = r2; int part = 0;
-            if (L.mode == ACMIL_MODE_F16X3) { part = r & 1; r >>= 1; }
-            const int loc = r % 8; const size_t j = r / 8;
-            const int al = loc & 1, e = (loc >> 1) & 1, dd = loc >> 2;
-            const int g4 = j / (ND / 2), d = 2 * (j % (ND / 2)) + dd, at = 2 * g4 + al;
+            const bool split = L.mode == ACMIL_MODE_F16X3;
+            const int per = (split ? 8 : 4) * DD;
+            const int loc0 = r2 % per; const size_t j = r2 / per;
+            const int t = loc0 & 3;
+            const int part = split ? ((loc0 >> 2) & 1) : 0;
+            const int dd = split ? (loc0 >> 3) : (loc0 >> 2);
+            const int al = t & 1, e = t >> 1;
+            const int g4 = j / 4, d = DD * (j % 4) + dd, at = 2 * g4 + al;
             const float* src = vu_row(a, at, i);
             f16x8 v;
             for (int jj = 0; jj < 8; ++jj) {
