@@ -65,10 +65,21 @@ __device__ __forceinline__ void ga_glds16(const char* gsrc, unsigned ldst) {   /
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
 }
+// Same copy with the non-temporal hint.  NOT used for the bag (measured, B=8: FETCH_SIZE 534 -> 955 MB per launch and
+// 15.1k -> 13.2k slides/s): a step reads one 64-byte segment per patch row, and the second half of each 128-byte line
+// is wanted one step later -- without L2 retention it is fetched from the fabric twice.  Kept for experiments.
+__device__ __forceinline__ void ga_glds16_nt(const char* gsrc, unsigned ldst) {
+    unsigned keep;
+    const unsigned lds = __builtin_amdgcn_readfirstlane(ldst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+}
 #ifdef GA_GLDS_BUILTIN
 #define GA_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc), (lptr_t)(size_t)(ldst), 16, 0, 0)
+#define GA_GLDS16_NT(gsrc, ldst) GA_GLDS16(gsrc, ldst)
 #else
 #define GA_GLDS16(gsrc, ldst) ga_glds16((const char*)(gsrc), (unsigned)(ldst))
+#define GA_GLDS16_NT(gsrc, ldst) ga_glds16_nt((const char*)(gsrc), (unsigned)(ldst))
 #endif
 
 #ifdef GA_TRACE

@@ -35,6 +35,22 @@ N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, D_ATTN = 50000, 512, 256, 5, 2, 128
 N_BAGS = 16
 
 
+def pmc_traffic(precision, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_pmc_bench_<precision>_b<B>.json, produced by tools/pmc_ga.py: FETCH_SIZE / WRITE_SIZE in their own
+    passes, corrected by a known-byte calibration run).  PMC cannot be collected from inside the timed process, so the
+    figure is the recorded one; None when no summary exists for this precision / batch."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_bench_%s_b%d.json" % (precision, batch))), reverse=True):
+        try:
+            with open(f) as fh:
+                return int(json.load(fh)["traffic_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
+
+
 def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
     """bytes and flops of one GA eval forward."""
     p = d * di + 2 * (di * da + da) + da * k + k + (k + 1) * (di * c + c)
@@ -54,6 +70,8 @@ def main():
                     help="slides per step: bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
                          "reference's strictly per-slide call pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b1", action="store_true",
+                    help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,15 +131,17 @@ def main():
     slides_per_s = world * args.steps * B / dt
 
     # per-slide latency in the reference's B=1 call pattern (one slide per call, calls back to back)
-    n_lat = 100
-    for i in range(10):
-        ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for i in range(n_lat):
-        last1 = ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
-    torch.cuda.synchronize()
-    ms_b1 = (time.perf_counter() - t1) / n_lat * 1e3
+    ms_b1 = None
+    if not args.no_b1:
+        n_lat = 100
+        for i in range(10):
+            ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_lat):
+            ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
+        torch.cuda.synchronize()
+        ms_b1 = (time.perf_counter() - t1) / n_lat * 1e3
 
     # ---- dominant kernel alone (ga_fwd_kernel, same template instance): scores-only calls launch just it
     n_k = max(50, min(args.steps, 400))
@@ -165,7 +185,7 @@ def main():
         "bound": "mfma",
         "achieved": round(flops / t_kernel / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s",
         "frac": round(flops / t_kernel / 1e12 / mfma_peak, 4),
-        "traffic": None,
+        "traffic": pmc_traffic(args.precision, B),
         "us_per_launch": round(t_kernel * 1e6, 2),
         "executed_tflops": round(executed / t_kernel / 1e12, 1),
         "executed_frac": round(executed / t_kernel / 1e12 / mfma_peak, 4),
@@ -184,7 +204,7 @@ def main():
                                "D_inner=256, n_token=5, n_class=2, fp32 bags resident in HBM, %d bags rotated" % (B, N_BAGS),
                    "precision": args.precision, "slides_per_step": B, "sharding": "independent slides per GPU, no collective"},
         "attention_fwd_ms_per_slide": round(dt / (args.steps * B) * 1e3, 4),
-        "attention_fwd_ms_per_slide_b1": round(ms_b1, 4),
+        "attention_fwd_ms_per_slide_b1": None if ms_b1 is None else round(ms_b1, 4),
         "roofline": roofline,
     }
 

@@ -1,0 +1,93 @@
+"""Collect the PMC evidence for bench.py's roofline object on the GPU box (run through gpurun).
+
+Separate rocprofv3 --pmc passes (never combined with trace domains), as MI355X_MICROARCH.md prescribes:
+  1. calibration: build/exp/hbm_calib (tools/hbm_calib.hip) reads / writes a KNOWN byte count with the access pattern of
+     ga_fwd_kernel -> correction factors for FETCH_SIZE and WRITE_SIZE on this rocprofv3 / gfx950;
+  2. the bench command itself (python bench.py --no-b1 --no-cpu-baseline ...): FETCH_SIZE, WRITE_SIZE, SQ and GRBM passes.
+Writes gpurun_out/pmc/summary.json (copy it to profiles/); per-launch averages for the dominant kernel.
+"""
+import argparse, csv, glob, json, os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PASSES = {
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "ea_rd": ["TCC_EA0_RDREQ", "TCC_EA0_RDREQ_32B"],
+    "sq": ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
+           "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU_MFMA_MOPS_F16"],
+    "grbm": ["GRBM_GUI_ACTIVE"],
+}
+
+
+def run_pass(tag, counters, cmd, outdir):
+    d = os.path.join(outdir, tag)
+    shutil.rmtree(d, ignore_errors=True)
+    full = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd
+    r = subprocess.run(full, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        print(r.stdout[-2000:])
+        raise SystemExit("rocprofv3 pass %s failed" % tag)
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    agg = {}
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                key = (row["Kernel_Name"], row["Counter_Name"])
+                s = agg.setdefault(key, [0.0, set()])
+                s[0] += float(row["Counter_Value"])
+                s[1].add(row["Dispatch_Id"])
+    shutil.rmtree(d, ignore_errors=True)
+    return {k: (v[0] / max(1, len(v[1])), len(v[1])) for k, v in agg.items()}
+
+
+def pick(res, kernel_sub, counter):
+    for (kn, cn), (avg, n) in res.items():
+        if kernel_sub in kn and cn == counter:
+            return avg, n
+    return None, 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precision", default="f16x3")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    calib = [os.path.join(ROOT, "build", "exp", "hbm_calib"), "8"]
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--precision", args.precision, "--batch", str(args.batch),
+             "--steps", str(args.steps), "--warmup", "3", "--no-b1", "--no-cpu-baseline"]
+    summary = {"command": " ".join(["python", "bench.py"] + bench[2:]), "kernel": "ga_fwd_kernel", "per_launch_avg": {}, "calibration": {}}
+
+    known_rd, known_wr = 50000 * 512 * 4, (16 << 20) * 4
+    c_f = run_pass("cal_fetch", PASSES["fetch"], calib, args.out)
+    c_w = run_pass("cal_write", PASSES["write"], calib, args.out)
+    rd_kb, _ = pick(c_f, "calib_read", "FETCH_SIZE")
+    wr_kb, _ = pick(c_w, "calib_write", "WRITE_SIZE")
+    rd_on_wr_kb, _ = pick(c_f, "calib_write", "FETCH_SIZE")
+    k_rd = known_rd / (rd_kb * 1024.0)
+    k_wr = known_wr / (wr_kb * 1024.0)
+    summary["calibration"] = {
+        "read_known_bytes": known_rd, "FETCH_SIZE_reported_KB": rd_kb, "fetch_correction": round(k_rd, 4),
+        "write_known_bytes": known_wr, "WRITE_SIZE_reported_KB": wr_kb, "write_correction": round(k_wr, 4),
+        "FETCH_SIZE_of_pure_write_kernel_KB": rd_on_wr_kb,
+        "pattern": "LDS-DMA 16 B/lane, 16 rows x 64-B row segment per wave-instruction (ga_fwd_kernel bag tile); fp32 stores 256 B/wave-instruction",
+    }
+    for tag, counters in PASSES.items():
+        res = run_pass(tag, counters, bench, args.out)
+        for c in counters:
+            v, n = pick(res, "ga_fwd_kernel", c)
+            summary["per_launch_avg"][c] = v
+            summary["launches_seen"] = n
+    f_kb, w_kb = summary["per_launch_avg"]["FETCH_SIZE"], summary["per_launch_avg"]["WRITE_SIZE"]
+    summary["traffic_bytes_per_launch"] = int(f_kb * 1024 * k_rd + w_kb * 1024 * k_wr)
+    summary["traffic_note"] = "FETCH_SIZE x fetch_correction + WRITE_SIZE x write_correction, KB -> bytes, average over the launches of the bench command"
+    summary["precision"], summary["batch"] = args.precision, args.batch
+    with open(os.path.join(args.out, "summary_%s_b%d.json" % (args.precision, args.batch)), "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
