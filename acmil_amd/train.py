@@ -27,6 +27,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .staging import staged
+
 PRETRAIN_DIMS = {  # Step3_WSI_classification_ACMIL.py:69-87
     "medical_ssl": (384, 128), "natural_supervised": (512, 256), "path-clip-B": (512, 256), "openai-clip-B": (512, 256),
     "plip": (512, 256), "quilt-net": (512, 256), "path-clip-B-AAAI": (512, 256), "biomedclip": (512, 256),
@@ -213,10 +215,10 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     acc = torch.zeros(4, device=device)          # loss sums stay on the device: no .item() sync per step
     use_fused = fused and hasattr(model, "train_step")
     t0 = time.time()
-    for it, idx in enumerate(order):
-        item = data[idx]
-        x = item["input"].to(device, non_blocking=True)            # fp16 stays fp16: converted inside the kernel
-        labels = torch.tensor([item["label"]], device=device)
+    label_dev = torch.arange(conf.n_class, device=device)      # labels are picked on the device: no H2D per step
+    for it, item in enumerate(staged(data, order, device)):     # pinned double-buffered H2D on a copy stream (staging.py)
+        x = item["input"]                                      # fp16 stays fp16: converted inside the kernel
+        labels = label_dev[item["label"]:item["label"] + 1]
         adjust_learning_rate(optimizer, epoch + it / len(order), conf)
         if use_fused:
             losses, _ = model.train_step(x.unsqueeze(0), labels)
@@ -250,17 +252,19 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     model.eval()
     order = epoch_order(len(data), 0, 0, False, rank, world, drop_last=False)
     probs, labels, losses, divs = [], [], [], []
-    for idx in order:
-        item = data[idx]
-        x = item["input"].to(device)
-        y = torch.tensor([item["label"]], device=device)
+    label_dev = torch.arange(conf.n_class, device=device)
+    for item in staged(data, order, device):
+        x = item["input"]
+        y = label_dev[item["label"]:item["label"] + 1]
         sub_preds, slide_preds, attn = model(x.unsqueeze(0))
-        divs.append(float(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1]))
-        losses.append(float(F.cross_entropy(slide_preds, y)))
+        # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
+        divs.append(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1])
+        losses.append(F.cross_entropy(slide_preds, y))
         probs.append(torch.softmax(slide_preds, dim=-1))
         labels.append(y)
     prob = torch.cat(probs) if probs else torch.zeros(0, conf.n_class, device=device)
     lab = torch.cat(labels) if labels else torch.zeros(0, dtype=torch.long, device=device)
+    losses = torch.stack(losses).tolist() if losses else []
     if world > 1:
         import torch.distributed as dist
         gathered = [None] * world

@@ -1,0 +1,61 @@
+"""Input staging: the prefetcher must hand out exactly dataset[i] in order, on CPU and through the
+pinned-ring / copy-stream path on the GPU (ragged bags force ring regrowth and slot reuse)."""
+import pytest
+import torch
+
+from acmil_amd.staging import BagPrefetcher
+
+
+class _Bags:
+    def __init__(self, sizes, d=64, dtype=torch.float16):
+        g = torch.Generator().manual_seed(5)
+        self.items = [{"input": torch.randn(n, d, generator=g).to(dtype), "label": i % 3} for i, n in enumerate(sizes)]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def test_prefetcher_cpu_order_and_content():
+    data = _Bags([5, 1, 17, 9, 33, 2])
+    order = [3, 0, 5, 1, 4, 2]
+    got = list(BagPrefetcher(data, order, torch.device("cpu")))
+    assert [g["index"] for g in got] == order
+    for g in got:
+        assert torch.equal(g["input"], data[g["index"]]["input"]) and g["label"] == data[g["index"]]["label"]
+
+
+def test_prefetcher_propagates_reader_errors():
+    class Bad(_Bags):
+        def __getitem__(self, i):
+            if i == 2:
+                raise RuntimeError("corrupt bag")
+            return super().__getitem__(i)
+    with pytest.raises(RuntimeError, match="corrupt bag"):
+        list(BagPrefetcher(Bad([4, 4, 4, 4]), [0, 1, 2, 3], torch.device("cpu")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [2, 3, 5])
+def test_prefetcher_gpu_ring_reuse(depth):
+    sizes = [3000, 120, 9000, 9000, 1, 20000, 640, 20000, 77, 5000, 31000, 8, 31000, 2048]
+    data = _Bags(sizes, d=128)
+    order = list(range(len(sizes))) * 3
+    dev = torch.device("cuda", 0)
+    sums, refs = [], []
+    for item in BagPrefetcher(data, order, dev, depth=depth):
+        x = item["input"]
+        assert x.is_cuda and x.dtype == torch.float16 and tuple(x.shape) == tuple(data[item["index"]]["input"].shape)
+        # consume on the compute stream with a kernel that is slow relative to the copy (keeps slots busy)
+        y = x.float()
+        for _ in range(4):
+            y = y * 1.0001 + 0.0
+        sums.append((x.float().sum(), x.float().abs().max(), x[-1].float().sum()))
+        refs.append(data[item["index"]]["input"])
+    torch.cuda.synchronize()
+    for (s, m, l), r in zip(sums, refs):
+        rf = r.float().to(dev)
+        assert torch.allclose(s, rf.sum(), rtol=1e-5, atol=1e-3)
+        assert float(m) == float(rf.abs().max()) and torch.allclose(l, rf[-1].sum(), rtol=1e-5, atol=1e-3)
