@@ -237,7 +237,8 @@ def main():
         torch.set_num_threads(all_cores)
         cpu_sps = n_cpu / el
         # cross-check while we are here: GPU result of the last step vs the oracle on the same bag
-        ref = O.acmil_ga_forward(bags[(n_lat - 1) % N_BAGS].cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
+        last1 = ops.ga_forward(bags[3], packed, dims, args.precision)
+        ref = O.acmil_ga_forward(bags[3].cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
         err = max((last1["A_out"].cpu() - ref["A_out"][0]).abs().max().item(),
                   (last1["sub_preds"].cpu() - ref["sub_preds"]).abs().max().item())
         result["cpu_baseline"] = {"value": round(cpu_sps, 2), "unit": "slides/s", "cores": cores, "kind": "port",
