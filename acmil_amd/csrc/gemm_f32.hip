@@ -10,6 +10,8 @@
 // accumulator registers).  Both operand tiles are staged K-major in LDS ([k][m] / [k][n], +4 pad), so the
 // one-float-per-lane MFMA fragments A[i = lane&31][k = lane>>5] are conflict-free ds_read_b32 whatever the
 // transposition; global loads are float4 along the contiguous axis and register-prefetched one tile ahead.
+// Small problems (the m x m products of the Moore-Penrose iteration: 8 x 192^3) use a 64 x 64 x 32 tile (one MFMA tile
+// per wave) so that 72 instead of 32 workgroups share the work and a wave's serial MFMA chain is 4x shorter.
 // Tall-K problems (weight gradients: K = number of patches) are split along K over gridDim.z into a
 // workspace and reduced in a fixed order (deterministic), the epilogue then runs in the reduce kernel.
 #include "ga_common.h"
@@ -17,7 +19,6 @@
 #define GM_BM 128
 #define GM_BN 128
 #define GM_BK 32
-#define GM_LD (GM_BM + 4)
 
 struct GemmArgs {
     const float* A; const void* B; float* C; const float* bias; const float* aux; float* ws;
@@ -62,46 +63,49 @@ __device__ __forceinline__ void gm_ld4(const void* P, long long idx, bool vec, i
 // the contiguous memory axis is K (operand stored [rows][K]) or the M/N axis (operand stored [K][rows]).
 // Each thread owns 4 groups of 4 elements that are contiguous in memory: one 16-B (8-B for 16-bit B) load
 // when the matrix is vector-aligned (`vec`) and the group is interior, guarded scalar loads at the edges.
-template <bool IS_B, int BDT>
+// G = groups of 4 elements per thread: 4 for the 128-row tile, 2 for the 64-row tile (ROWS = 32 G).
+template <bool IS_B, int BDT, int G>
 __device__ __forceinline__ void gm_load_tile(const void* P, int ld, bool contig_is_k, int r0, int k0, int R, int K,
-                                             int kend, int tid, bool vec, float (&reg)[4][4]) {
+                                             int kend, int tid, bool vec, float (&reg)[G][4]) {
     if (contig_is_k) {
         // thread -> (row = tid/8 + 32*i, 4 consecutive k at 4*(tid%8))
         const int k = k0 + 4 * (tid & 7);
         const int nv = kend - k < 0 ? 0 : (kend - k > 4 ? 4 : kend - k);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G; ++i) {
             const int r = r0 + (tid >> 3) + 32 * i;
             gm_ld4<IS_B, BDT>(P, (long long)r * ld + k, vec, r < R ? nv : 0, reg[i]);
         }
     } else {
-        // thread -> (k = tid/32 + 8*i, 4 consecutive rows at 4*(tid%32))
-        const int r = r0 + 4 * (tid & 31);
+        // thread -> (k = tid/(8G) + (32/G)*i, 4 consecutive rows at 4*(tid%(8G)))
+        const int r = r0 + 4 * (tid % (8 * G));
         const int nv = R - r < 0 ? 0 : (R - r > 4 ? 4 : R - r);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (tid >> 5) + 8 * i;
+        for (int i = 0; i < G; ++i) {
+            const int k = k0 + tid / (8 * G) + (32 / G) * i;
             gm_ld4<IS_B, BDT>(P, (long long)k * ld + r, vec, k < kend ? nv : 0, reg[i]);
         }
     }
     (void)K;
 }
 
-__device__ __forceinline__ void gm_store_tile(float* S, bool contig_is_k, int tid, const float (&reg)[4][4]) {
+template <int G>
+__device__ __forceinline__ void gm_store_tile(float* S, bool contig_is_k, int tid, const float (&reg)[G][4]) {
+    constexpr int LD = 32 * G + 4;
     if (contig_is_k) {
         const int kq = 4 * (tid & 7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G; ++i) {
             const int r = (tid >> 3) + 32 * i;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) S[(kq + q) * GM_LD + r] = reg[i][q];
+            for (int q = 0; q < 4; ++q) S[(kq + q) * LD + r] = reg[i][q];
         }
     } else {
-        const int rq = 4 * (tid & 31);
+        const int rq = 4 * (tid % (8 * G));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = (tid >> 5) + 8 * i;
-            *(f32x4*)(S + k * GM_LD + rq) = f32x4{reg[i][0], reg[i][1], reg[i][2], reg[i][3]};
+        for (int i = 0; i < G; ++i) {
+            const int k = tid / (8 * G) + (32 / G) * i;
+            *(f32x4*)(S + k * LD + rq) = f32x4{reg[i][0], reg[i][1], reg[i][2], reg[i][3]};
         }
     }
 }
@@ -114,14 +118,16 @@ __device__ __forceinline__ float gm_act(float v, int act, const float* aux, long
     return v;
 }
 
-template <int BDT>
+// WT = MFMA tiles per wave and dimension: 2 -> 128 x 128 workgroup tile, 1 -> 64 x 64.
+template <int BDT, int WT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GM_BK * GM_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * GM_LD];
+    constexpr int G = 2 * WT, BT = 64 * WT, LD = BT + 4, WS = 32 * WT;   // groups/thread, tile edge, LDS row, wave tile edge
+    __shared__ __attribute__((aligned(16))) float As[GM_BK * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[GM_BK * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    const int m0 = blockIdx.y * BT, n0 = blockIdx.x * BT;
     const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const float* A = g.A + (long long)batch * g.sA;
     const char* B = (const char*)g.B + (long long)batch * g.sB * (BDT == ACMIL_DTYPE_F32 ? 4 : 2);
@@ -130,54 +136,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     // operand A is stored [M][K] (contiguous K) unless transA; operand B is stored [K][N] unless transB ([N][K])
     const bool a_ck = !g.transA, b_ck = (g.transB != 0);
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     // vector loads need 16-B (A, fp32 B) / 8-B (16-bit B) aligned groups: base and leading dimension multiples of 4 elements
     const bool va = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0) && ((kbeg & 3) == 0);
     const bool vb = ((g.ldb & 3) == 0) && ((((size_t)B) & (BDT == ACMIL_DTYPE_F32 ? 15 : 7)) == 0) && ((kbeg & 3) == 0);
-    float ra[4][4], rb[4][4];
-    gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, kbeg, g.M, g.K, kend, tid, va, ra);
-    gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, kbeg, g.N, g.K, kend, tid, vb, rb);
+    float ra[G][4], rb[G][4];
+    gm_load_tile<false, ACMIL_DTYPE_F32, G>(A, g.lda, a_ck, m0, kbeg, g.M, g.K, kend, tid, va, ra);
+    gm_load_tile<true, BDT, G>(B, g.ldb, b_ck, n0, kbeg, g.N, g.K, kend, tid, vb, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
         __syncthreads();   // previous tile fully consumed
-        gm_store_tile(As, a_ck, tid, ra);
-        gm_store_tile(Bs, b_ck, tid, rb);
+        gm_store_tile<G>(As, a_ck, tid, ra);
+        gm_store_tile<G>(Bs, b_ck, tid, rb);
         __syncthreads();
         if (k0 + GM_BK < kend) {
-            gm_load_tile<false, ACMIL_DTYPE_F32>(A, g.lda, a_ck, m0, k0 + GM_BK, g.M, g.K, kend, tid, va, ra);
-            gm_load_tile<true, BDT>(B, g.ldb, b_ck, n0, k0 + GM_BK, g.N, g.K, kend, tid, vb, rb);
+            gm_load_tile<false, ACMIL_DTYPE_F32, G>(A, g.lda, a_ck, m0, k0 + GM_BK, g.M, g.K, kend, tid, va, ra);
+            gm_load_tile<true, BDT, G>(B, g.ldb, b_ck, n0, k0 + GM_BK, g.N, g.K, kend, tid, vb, rb);
         }
-        const float* ap = As + hi * GM_LD + 64 * wm + i31;
-        const float* bp = Bs + hi * GM_LD + 64 * wn + i31;
+        const float* ap = As + hi * LD + WS * wm + i31;
+        const float* bp = Bs + hi * LD + WS * wn + i31;
 #pragma unroll
         for (int kk = 0; kk < GM_BK / 2; ++kk) {
-            const float a0 = ap[2 * kk * GM_LD], a1 = ap[2 * kk * GM_LD + 32];
-            const float b0 = bp[2 * kk * GM_LD], b1 = bp[2 * kk * GM_LD + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[WT], bv[WT];
+#pragma unroll
+            for (int t = 0; t < WT; ++t) { av[t] = ap[2 * kk * LD + 32 * t]; bv[t] = bp[2 * kk * LD + 32 * t]; }
+#pragma unroll
+            for (int a = 0; a < WT; ++a)
+#pragma unroll
+                for (int b = 0; b < WT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
-    // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + 64wm + 32a + mfma32_row(r,hi), col = n0 + 64wn + 32b + i31
+    // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + WS wm + 32a + mfma32_row(r,hi), col = n0 + WS wn + 32b + i31
     float* Cb = (g.splits > 1) ? g.ws + ((long long)batch * g.splits + split) * g.M * g.N : g.C + (long long)batch * g.sC;
     const int ldc = (g.splits > 1) ? g.N : g.ldc;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + 64 * wn + 32 * b + i31;
+        for (int b = 0; b < WT; ++b) {
+            const int col = n0 + WS * wn + 32 * b + i31;
             if (col >= g.N) continue;
             const float bias = (g.splits > 1 || !g.bias) ? 0.0f : g.bias[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + 64 * wm + 32 * a + mfma32_row(r, hi);
+                const int row = m0 + WS * wm + 32 * a + mfma32_row(r, hi);
                 if (row >= g.M) continue;
                 float* dst = Cb + (long long)row * ldc + col;
                 if (g.splits > 1) *dst = acc[a][b][r];
@@ -206,6 +213,12 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
         if (g.beta != 0.0f) v += g.beta * *dst;
         *dst = gm_act(v, g.act, g.aux + (long long)b * g.sC, idx);
     }
+}
+
+// 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle and K is too short to split
+static bool gm_small_tile(int M, int N, int K, int batch) {
+    const long long tiles = (long long)((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN) * batch;
+    return tiles < 128 && K < 4 * GM_BK * 8;
 }
 
 // choose a K split so that (tiles * splits) roughly fills the 256 CUs when the output is small and K is long
@@ -244,11 +257,14 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
     if (g.splits > 1) g.splits = (K + g.kchunk - 1) / g.kchunk;
     if (g.splits < 1) g.splits = 1;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((N + GM_BN - 1) / GM_BN, (M + GM_BM - 1) / GM_BM, g.splits * batch);
-    switch (b_dtype) {
-        case ACMIL_DTYPE_F32: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F32>, grid, dim3(256), 0, st, g); break;
-        case ACMIL_DTYPE_F16: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_F16>, grid, dim3(256), 0, st, g); break;
-        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL(gemm_f32_kernel<ACMIL_DTYPE_BF16>, grid, dim3(256), 0, st, g); break;
+    const bool small = gm_small_tile(M, N, K, batch) && g.splits == 1 && b_dtype == ACMIL_DTYPE_F32;
+    const int bt = small ? 64 : GM_BM;
+    const dim3 grid((N + bt - 1) / bt, (M + bt - 1) / bt, g.splits * batch);
+    if (small) hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 1>), grid, dim3(256), 0, st, g);
+    else switch (b_dtype) {
+        case ACMIL_DTYPE_F32: hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 2>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_F16: hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F16, 2>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_BF16, 2>), grid, dim3(256), 0, st, g); break;
         default: return ACMIL_ERR_UNSUPPORTED;
     }
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;

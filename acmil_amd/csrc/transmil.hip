@@ -283,6 +283,14 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
 #define TM_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH; } while (0)
 #define TM_GEMM(...) do { int rc_ = acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
+// out = c I - P for a batch of m x m matrices (first bracket of the Moore-Penrose iteration, nystrom_attention.py:25)
+__global__ __launch_bounds__(256) void tm_ci_minus_kernel(const float* __restrict__ P, float* __restrict__ out, int m, float c, long long total) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int rc = (int)(e % ((long long)m * m));
+    out[e] = ((rc / m == rc % m) ? c : 0.0f) - P[e];
+}
+
 static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (cols <= 64) hipLaunchKernelGGL(tm_softmax_short_kernel<1>, dim3(blocks), dim3(256), 0, st, x, rows, cols);
@@ -327,8 +335,8 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         float* spare = (zc == Z) ? T2 : Z;
         // xz = x z ; t1 = 7I - xz ; t = 15I - xz t1 ; t1 = 13I - xz t ; z' = 0.25 z t1
         TM_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 0.0f, XZ, m, mm, nullptr, 0, nullptr, H, gws, st);
-        // t1 = 7I - xz  (product with identity is wasteful: derive from xz directly with the "cI - P" epilogue on xz = x z)
-        TM_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 7.0f, T1, m, mm, nullptr, 3, nullptr, H, gws, st);
+        hipLaunchKernelGGL(tm_ci_minus_kernel, dim3((unsigned)((H * mm + 255) / 256)), dim3(256), 0, st, XZ, T1, m, 7.0f, (long long)H * mm);
+        TM_CHECK_LAUNCH();
         TM_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 15.0f, spare, m, mm, nullptr, 3, nullptr, H, gws, st);
         TM_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, spare, ACMIL_DTYPE_F32, m, mm, 13.0f, T1, m, mm, nullptr, 3, nullptr, H, gws, st);
         TM_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);
