@@ -17,6 +17,7 @@
 // the reference's association only by fp32 round-off).  Reference quirks kept: FRONT zero padding to a multiple
 // of m landmarks (padded rows take part in all three softmaxes), repeat-padding of the token grid to a square.
 #include <math.h>
+#include <stdlib.h>
 
 #include "ga_common.h"
 
@@ -238,6 +239,12 @@ __global__ void tm_copy_kernel(const float* __restrict__ src, float* __restrict_
 // ------------------------------------------------------------------------------------------------ host orchestration
 struct TmLayerW { const float *norm_w, *norm_b, *qkv_w, *out_w, *out_b, *res_w; };
 
+// fused Nystrom attention legs (transmil_attn.hip)
+int tm_attn_fused_supported(int Di);
+size_t tm_attn3_partial_bytes(int npad, int Di);
+int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st);
+int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st);
+
 struct TmGeom {
     int N, D, Di, C, side, nsq, n, m, npad, pad, l, d;
 };
@@ -254,7 +261,7 @@ static TmGeom tm_geom(int N, int D, int Di, int C) {
 
 static size_t tm_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, GEMM, total; };
+struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, GEMM, total; };
 
 static TmWs tm_ws(const TmGeom& g) {
     TmWs w; size_t off = 0;
@@ -267,6 +274,7 @@ static TmWs tm_ws(const TmGeom& g) {
     w.S2 = off; off += mm; w.Z = off; off += mm; w.XZ = off; off += mm; w.T1 = off; off += mm; w.T2 = off; off += mm;
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
+    w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
     size_t gw = acmil_gemm_workspace_bytes(g.m, g.d, g.npad, TM_HEADS);
     const size_t g2 = acmil_gemm_workspace_bytes(1, g.C, g.Di, 1);
     if (g2 > gw) gw = g2;
@@ -320,9 +328,16 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_GEMM(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
     hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, QKV, g.l, m, Di, QL, KL);
     TM_CHECK_LAUNCH();
+    // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
+    // chain below stays as the path for other widths and as the A/B reference (ACMIL_TM_UNFUSED=1)
+    static const bool force_unfused = getenv("ACMIL_TM_UNFUSED") != nullptr;
+    const bool fused = tm_attn_fused_supported(Di) && !force_unfused;
+    int rc = ACMIL_OK;
+    if (!fused) {
     // sim1 = scale q k_l^T  [H, npad, m] ; softmax over m
     TM_GEMM(0, 1, npad, m, d, scale, QKV, 3 * Di, d, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S1, m, (long long)npad * m, nullptr, 0, nullptr, H, gws, st);
-    int rc = tm_softmax_short(S1, (long long)H * npad, m, st); if (rc != ACMIL_OK) return rc;
+    rc = tm_softmax_short(S1, (long long)H * npad, m, st); if (rc != ACMIL_OK) return rc;
+    }
     // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration
     TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
     rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
@@ -342,14 +357,21 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         TM_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);
         zn = spare; float* t = zc; zc = zn; zn = t;
     }
+    if (fused) {
+        // AV = softmax_n(scale q_l k^T) v  [H, m, d]   (chunk partials in their own workspace region)
+        rc = tm_attn3_fused(QKV, QL, AV, (float*)(ws + W.PART), npad, Di, scale, st); if (rc != ACMIL_OK) return rc;
+    } else {
     // sim3 = scale q_l k^T [H, m, npad] ; softmax over npad
     TM_GEMM(0, 1, m, npad, d, scale, QL, d, md, QKV + Di, ACMIL_DTYPE_F32, 3 * Di, d, 0.0f, S3, npad, (long long)m * npad, nullptr, 0, nullptr, H, gws, st);
     if (npad <= 1024) { rc = tm_softmax_short(S3, (long long)H * m, npad, st); if (rc != ACMIL_OK) return rc; }
     else { hipLaunchKernelGGL(tm_softmax_long_kernel, dim3(H * m), dim3(1024), 0, st, S3, npad); TM_CHECK_LAUNCH(); }
-    // AV = attn3 v [H, m, d] ; W2 = attn2^+ AV ; OUT = attn1 W2 written into the merged-head layout [npad, H*d]
+    // AV = attn3 v [H, m, d]
     TM_GEMM(0, 0, m, d, npad, 1.0f, S3, npad, (long long)m * npad, QKV + 2 * Di, ACMIL_DTYPE_F32, 3 * Di, d, 0.0f, AV, d, md, nullptr, 0, nullptr, H, gws, st);
+    }
+    // W2 = attn2^+ AV ; OUT = attn1 W2 written into the merged-head layout [npad, H*d]
     TM_GEMM(0, 0, m, d, m, 1.0f, zc, m, mm, AV, ACMIL_DTYPE_F32, d, md, 0.0f, W2, d, md, nullptr, 0, nullptr, H, gws, st);
-    TM_GEMM(0, 0, npad, d, m, 1.0f, S1, m, (long long)npad * m, W2, ACMIL_DTYPE_F32, d, md, 0.0f, OUT, Di, d, nullptr, 0, nullptr, H, gws, st);
+    if (fused) { rc = tm_attn1_fused(QKV, KL, W2, OUT, npad, Di, scale, st); if (rc != ACMIL_OK) return rc; }
+    else TM_GEMM(0, 0, npad, d, m, 1.0f, S1, m, (long long)npad * m, W2, ACMIL_DTYPE_F32, d, md, 0.0f, OUT, Di, d, nullptr, 0, nullptr, H, gws, st);
     // + depth-wise residual conv of v along the sequence
     hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
     TM_CHECK_LAUNCH();

@@ -1,0 +1,291 @@
+// transmil_attn.hip -- fused Nystrom-attention kernels of the TransMIL path for gfx950 (exact-fp32 MFMA,
+// v_mfma_f32_32x32x2_f32).  They replace, per layer and without ever materialising the [heads, n', m] / [heads, m, n']
+// attention matrices (618 MB each at cfg4, written once and read 2-3 times by the unfused GEMM + softmax + GEMM chain):
+//
+//   tm_attn1_kernel : OUT[n, h*d + e] = sum_l softmax_l( scale q[n] . k_l[l] ) * W2[h][l][e]
+//                     = the `attn1 @ (attn2_inv @ (attn3 @ v))` leg      (architecture/nystrom_attention.py:113-133)
+//   tm_attn3_kernel : AV[h][l][e]     = sum_n softmax_n( scale q_l[l] . k[n] ) * v[n][e]
+//                     = `attn3 @ v` with the softmax over all n' keys    (nystrom_attention.py:115-121,131)
+//                     flash-style: keys are split into chunks, each workgroup keeps a running (max, sum, acc) per
+//                     landmark; tm_attn3_merge_kernel combines the chunk partials in a fixed order (deterministic).
+//
+// Both use the register-chaining trick of ga_forward_kernel.h: the first GEMM is computed with the softmax axis on the
+// accumulator REGISTERS (32x32 C/D layout: row = (r&3) + 8(r>>2) + 4(lane>>5), col = lane&31), so the soft-maxed
+// accumulators are directly the B operand of the second GEMM (K slot pair (r, lane>>5) <-> rows l, l+4); the matching
+// K-slot order of the A operand (W2^T resp. v^T) is produced by the LDS addressing.  K = d is consumed in the lane-half
+// split order d_idx = (d/2) * (lane>>5) + s so that every lane's operand values are contiguous in memory.
+// Geometry is fixed by TransLayer (transMIL.py:13-23): heads = 8, m = Di/2 landmarks, d = Di/8  =>  d = m/4; with
+// MT = m/32 the kernels are instantiated for MT in {2,4,6,8} (Di = 128, 256, 384, 512); other widths use the GEMM chain.
+#include "ga_common.h"
+
+#define TMA_HEADS 8
+
+__device__ __forceinline__ float tma_xor32(float v) { return __shfl_xor(v, 32); }
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int MT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void tm_attn1_kernel(const float* __restrict__ QKV, const float* __restrict__ KL,
+                                                       const float* __restrict__ W2, float* __restrict__ OUT, int npad, int Di,
+                                                       float scale) {
+    constexpr int M = 32 * MT, D = 8 * MT, DH = D / 2, ET = (D + 31) / 32, EP = 32 * ET, LDM = M + 4, LDE = EP + 8;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* KLs = sm;                  // [D][LDM]   scale * k_l, transposed: A operand of GEMM-S (lane = landmark)
+    float* W2s = sm + D * LDM;        // [M][LDE]   W2 rows, zero padded to EP columns: A operand of GEMM-PV (lane = e)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y;
+    for (int idx = tid; idx < M * D; idx += 256) {
+        const int l = idx / D, c = idx % D;
+        KLs[c * LDM + l] = KL[((size_t)h * M + l) * D + c] * scale;
+        W2s[l * LDE + c] = W2[((size_t)h * M + l) * D + c];
+    }
+    if (EP > D)
+        for (int idx = tid; idx < M * (EP - D); idx += 256) W2s[(idx / (EP - D)) * LDE + D + idx % (EP - D)] = 0.0f;
+    __syncthreads();
+
+    const int nblk = npad / 32, stride = gridDim.x * 4;
+    int rb = blockIdx.x * 4 + wave;
+    f32x4 qn[DH / 4];
+    auto load_q = [&](int b) {
+        const float* qp = QKV + (size_t)(b * 32 + i31) * 3 * Di + h * D + DH * hi;
+#pragma unroll
+        for (int j = 0; j < DH / 4; ++j) qn[j] = *(const f32x4*)(qp + 4 * j);
+    };
+    if (rb < nblk) load_q(rb);
+    for (; rb < nblk; rb += stride) {
+        float q[DH];
+#pragma unroll
+        for (int j = 0; j < DH / 4; ++j) { q[4 * j] = qn[j][0]; q[4 * j + 1] = qn[j][1]; q[4 * j + 2] = qn[j][2]; q[4 * j + 3] = qn[j][3]; }
+        if (rb + stride < nblk) load_q(rb + stride);       // prefetch the next block of queries behind the MFMA work
+
+        // GEMM-S: acc[t][r] = scale * q[n = i31] . k_l[l = 32t + row(r, hi)]
+        f32x16 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const float* ap = KLs + (DH * hi) * LDM + i31;
+#pragma unroll
+        for (int s = 0; s < DH; ++s) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * LDM + 32 * t], q[s], acc[t], 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep hipcc from hoisting all LDS reads of the unrolled loop (spills)
+        }
+
+        // softmax over the m landmarks of row n: registers of this lane + the partner half (lane ^ 32)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[t][r]);
+        mx = fmaxf(mx, tma_xor32(mx));
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float p = __expf(acc[t][r] - mx); acc[t][r] = p; sum += p; }
+        sum += tma_xor32(sum);
+
+        // GEMM-PV: o[et][r] = sum_l W2[l][e = 32et + row(r, hi)] * p[l][n]; K slot pair of (t, r): l = 32t + (r&3) + 8(r>>2) + 4hi
+        f32x16 o[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* wp = W2s + (32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi) * LDE + i31;
+#pragma unroll
+                for (int et = 0; et < ET; ++et) o[et] = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[32 * et], acc[t][r], o[et], 0, 0, 0);
+                if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+        const float inv = 1.0f / sum;
+        float* op = OUT + (size_t)(rb * 32 + i31) * Di + h * D;
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int e = 32 * et + 8 * gq + 4 * hi;
+                if (e < D) *(f32x4*)(op + e) = f32x4{o[et][4 * gq] * inv, o[et][4 * gq + 1] * inv, o[et][4 * gq + 2] * inv, o[et][4 * gq + 3] * inv};
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup = (head, key chunk), MT waves = the MT landmark tiles of the head; 32 keys per step, k / v tiles staged
+// through a double-buffered LDS pair (8 D float4 per tile = exactly one float4 of k and one of v per thread).
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void tm_attn3_kernel(const float* __restrict__ QKV, const float* __restrict__ QL,
+                                                          float* __restrict__ part_ms, float* __restrict__ part_o, int npad, int Di,
+                                                          float scale, int blocks_per_chunk) {
+    constexpr int M = 32 * MT, D = 8 * MT, DH = D / 2, ET = (D + 31) / 32, EP = 32 * ET, LDK = 36, LDE = EP + 8;
+    __shared__ __attribute__((aligned(16))) float ks[2][D * LDK];    // [d][key]  A operand of GEMM-S (lane = key)
+    __shared__ __attribute__((aligned(16))) float vs[2][32 * LDE];   // [key][e]  A operand of GEMM-PV (lane = e)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int nblk = npad / 32;
+    const int kb0 = chunk * blocks_per_chunk, kb1 = min(nblk, kb0 + blocks_per_chunk);
+
+    float ql[DH];                     // B operand of GEMM-S: scale * q_l[l = 32 wave + i31][DH hi + s]
+    {
+        const float* qp = QL + ((size_t)h * M + 32 * wave + i31) * D + DH * hi;
+#pragma unroll
+        for (int s = 0; s < DH; ++s) ql[s] = qp[s] * scale;
+    }
+    if (EP > D) {                     // zero the padded e columns of both v buffers once
+        for (int idx = tid; idx < 2 * 32 * (EP - D); idx += 64 * MT) {
+            const int b = idx / (32 * (EP - D)), rem = idx % (32 * (EP - D));
+            vs[b][(rem / (EP - D)) * LDE + D + rem % (EP - D)] = 0.0f;
+        }
+    }
+    // staging map: thread -> key row = tid / (D/4), float4 column c4 = tid % (D/4)   (64 MT == 8 D threads)
+    const int srow = tid / (D / 4), sc4 = tid % (D / 4);
+    f32x4 kreg, vreg;
+    auto load_kv = [&](int kb) {
+        const float* base = QKV + (size_t)(kb * 32 + srow) * 3 * Di + h * D + 4 * sc4;
+        kreg = *(const f32x4*)(base + Di);
+        vreg = *(const f32x4*)(base + 2 * Di);
+    };
+    float m_run = -INFINITY, s_run = 0.0f;
+    f32x16 o[ET];
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
+
+    if (kb0 < kb1) load_kv(kb0);
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int buf = (kb - kb0) & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ks[buf][(4 * sc4 + j) * LDK + srow] = kreg[j];
+        *(f32x4*)(&vs[buf][srow * LDE + 4 * sc4]) = vreg;
+        __syncthreads();              // one barrier per step: the buffer written two steps later was last read before this barrier
+        if (kb + 1 < kb1) load_kv(kb + 1);
+
+        // GEMM-S: S[r] = scale * k[n = row(r, hi)] . q_l[l = i31]
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        const float* ap = ks[buf] + (DH * hi) * LDK + i31;
+#pragma unroll
+        for (int s = 0; s < DH; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * LDK], ql[s], S, 0, 0, 0);
+
+        // online softmax over keys for landmark l (this lane + partner half hold the 32 keys of the step)
+        float bm = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) bm = fmaxf(bm, S[r]);
+        bm = fmaxf(bm, tma_xor32(bm));
+        const float mn = fmaxf(m_run, bm);
+        const float alpha = __expf(m_run - mn);      // exp(-inf) = 0 on the first step
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ps += S[r]; }
+        ps += tma_xor32(ps);
+        s_run = s_run * alpha + ps;
+        m_run = mn;
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[et][r] *= alpha;
+
+        // GEMM-PV: o[et][r] += sum_n v[n][e = 32et + row(r, hi)] * p[n][l]; K slot pair of r: n = (r&3) + 8(r>>2) + 4hi
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* vp = vs[buf] + ((r & 3) + 8 * (r >> 2) + 4 * hi) * LDE + i31;
+#pragma unroll
+            for (int et = 0; et < ET; ++et) o[et] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[32 * et], S[r], o[et], 0, 0, 0);
+        }
+    }
+    // partials: part_ms[h][chunk][l][2], part_o[h][chunk][l][D]
+    const size_t row = ((size_t)h * nchunks + chunk) * M + 32 * wave + i31;
+    if (hi == 0) { part_ms[row * 2] = m_run; part_ms[row * 2 + 1] = s_run; }
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int e = 32 * et + 8 * gq + 4 * hi;
+            if (e < D) *(f32x4*)(part_o + row * D + e) = f32x4{o[et][4 * gq], o[et][4 * gq + 1], o[et][4 * gq + 2], o[et][4 * gq + 3]};
+        }
+}
+
+// AV[h][l][e] = sum_c o_c[e] exp(m_c - M) / sum_c s_c exp(m_c - M), chunks in index order (deterministic)
+__global__ __launch_bounds__(64) void tm_attn3_merge_kernel(const float* __restrict__ part_ms, const float* __restrict__ part_o,
+                                                           float* __restrict__ AV, int M, int D, int nchunks) {
+    const int h = blockIdx.y, l = blockIdx.x;
+    float mx = -INFINITY;
+    for (int c = 0; c < nchunks; ++c) mx = fmaxf(mx, part_ms[(((size_t)h * nchunks + c) * M + l) * 2]);
+    float den = 0.0f;
+    for (int c = 0; c < nchunks; ++c) {
+        const float* p = part_ms + (((size_t)h * nchunks + c) * M + l) * 2;
+        den += p[1] * __expf(p[0] - mx);
+    }
+    for (int e = threadIdx.x; e < D; e += 64) {
+        float num = 0.0f;
+        for (int c = 0; c < nchunks; ++c) {
+            const size_t row = ((size_t)h * nchunks + c) * M + l;
+            num += part_o[row * D + e] * __expf(part_ms[row * 2] - mx);
+        }
+        AV[((size_t)h * M + l) * D + e] = num / den;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side (called from transmil.hip).  Return ACMIL_ERR_UNSUPPORTED when the geometry has no instantiation.
+int tm_attn_fused_supported(int Di) { return Di == 128 || Di == 256 || Di == 384 || Di == 512; }
+
+size_t tm_attn3_partial_bytes(int npad, int Di) {
+    const int m = Di / 2, d = Di / TMA_HEADS;
+    (void)npad;
+    return (size_t)TMA_HEADS * 64 * m * (2 + d) * sizeof(float) + 1024;   // <= 64 chunks (tm_attn3_launch)
+}
+
+template <int MT>
+static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+    constexpr int M = 32 * MT, D = 8 * MT, ET = (D + 31) / 32, EP = 32 * ET;
+    const size_t lds = ((size_t)D * (M + 4) + (size_t)M * (EP + 8)) * sizeof(float);
+    static bool attr_set = false;      // idempotent attribute; racing callers set the same value
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)tm_attn1_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nblk = npad / 32;
+    int gx = (nblk + 3) / 4; if (gx > 32) gx = 32;                 // 8 heads x 32 = 256 workgroups, each wave loops over its row blocks
+    hipLaunchKernelGGL(tm_attn1_kernel<MT>, dim3(gx, TMA_HEADS), dim3(256), lds, st, QKV, KL, W2, OUT, npad, Di, scale);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+    switch (Di) {
+        case 128: return tm_attn1_launch<2>(QKV, KL, W2, OUT, npad, Di, scale, st);
+        case 256: return tm_attn1_launch<4>(QKV, KL, W2, OUT, npad, Di, scale, st);
+        case 384: return tm_attn1_launch<6>(QKV, KL, W2, OUT, npad, Di, scale, st);
+        case 512: return tm_attn1_launch<8>(QKV, KL, W2, OUT, npad, Di, scale, st);
+    }
+    return ACMIL_ERR_UNSUPPORTED;
+}
+
+template <int MT>
+static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st) {
+    constexpr int M = 32 * MT, D = 8 * MT;
+    const int nblk = npad / 32;
+    int nchunks = nblk < 64 ? nblk : 64;
+    const int bpc = (nblk + nchunks - 1) / nchunks;
+    nchunks = (nblk + bpc - 1) / bpc;
+    float* part_ms = part;
+    float* part_o = part + (((size_t)TMA_HEADS * nchunks * M * 2 + 63) & ~(size_t)63);
+    hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(tm_attn3_merge_kernel, dim3(M, TMA_HEADS), dim3(64), 0, st, part_ms, part_o, AV, M, D, nchunks);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st) {
+    switch (Di) {
+        case 128: return tm_attn3_launch<2>(QKV, QL, AV, part, npad, Di, scale, st);
+        case 256: return tm_attn3_launch<4>(QKV, QL, AV, part, npad, Di, scale, st);
+        case 384: return tm_attn3_launch<6>(QKV, QL, AV, part, npad, Di, scale, st);
+        case 512: return tm_attn3_launch<8>(QKV, QL, AV, part, npad, Di, scale, st);
+    }
+    return ACMIL_ERR_UNSUPPORTED;
+}

@@ -36,7 +36,9 @@ def test_matches_reference_golden(name):
     np.testing.assert_allclose(logits.cpu().numpy(), case["logits"], rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("n,d,di,c", [(3000, 512, 256, 2), (777, 768, 384, 7)])
+# Di = 128 / 256 / 384 / 512 run the fused flash-style attention legs (transmil_attn.hip); Di = 768 (GigaPath width) has no
+# fused instantiation and exercises the GEMM + softmax chain
+@pytest.mark.parametrize("n,d,di,c", [(3000, 512, 256, 2), (777, 768, 384, 7), (5000, 1024, 512, 2), (400, 1536, 768, 2), (40, 384, 128, 3)])
 def test_matches_oracle_other_shapes(n, d, di, c):
     from oracle import transmil_oracle as TO
     sd = TO.default_state_dict(d, di, c, seed=3)
