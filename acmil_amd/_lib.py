@@ -38,6 +38,8 @@ SIGNATURES = {
     "acmil_gemm_workspace_bytes": (_sz, [_i] * 4),
     "acmil_gemm_f32": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
                             _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
+    "acmil_gemm_f16x3": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
+                              _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),

@@ -118,6 +118,37 @@ __device__ __forceinline__ float gm_act(float v, int act, const float* aux, long
     return v;
 }
 
+// epilogue / partial store shared by the fp32 and the split-f16 kernels
+template <int WT>
+__device__ __forceinline__ void gm_epilogue(const GemmArgs& g, const f32x16 (&acc)[WT][WT], int m0, int n0, int wm, int wn, int i31,
+                                            int hi, int batch, int split) {
+    constexpr int WS = 32 * WT;
+    // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + WS wm + 32a + mfma32_row(r,hi), col = n0 + WS wn + 32b + i31
+    float* Cb = (g.splits > 1) ? g.ws + ((long long)batch * g.splits + split) * g.M * g.N : g.C + (long long)batch * g.sC;
+    const int ldc = (g.splits > 1) ? g.N : g.ldc;
+#pragma unroll
+    for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < WT; ++b) {
+            const int col = n0 + WS * wn + 32 * b + i31;
+            if (col >= g.N) continue;
+            const float bias = (g.splits > 1 || !g.bias) ? 0.0f : g.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + WS * wm + 32 * a + mfma32_row(r, hi);
+                if (row >= g.M) continue;
+                float* dst = Cb + (long long)row * ldc + col;
+                if (g.splits > 1) *dst = acc[a][b][r];
+                else if (g.act == 3) *dst = (row == col ? g.beta : 0.0f) - g.alpha * acc[a][b][r];
+                else {
+                    float v = g.alpha * acc[a][b][r] + bias;
+                    if (g.beta != 0.0f) v += g.beta * *dst;
+                    *dst = gm_act(v, g.act, g.aux + (long long)batch * g.sC, (long long)row * ldc + col);
+                }
+            }
+        }
+}
+
 // WT = MFMA tiles per wave and dimension: 2 -> 128 x 128 workgroup tile, 1 -> 64 x 64.
 template <int BDT, int WT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -172,30 +203,88 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
                 for (int b = 0; b < WT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
-    // ---- epilogue / partial store.  acc[a][b][r]: row = m0 + WS wm + 32a + mfma32_row(r,hi), col = n0 + WS wn + 32b + i31
-    float* Cb = (g.splits > 1) ? g.ws + ((long long)batch * g.splits + split) * g.M * g.N : g.C + (long long)batch * g.sC;
-    const int ldc = (g.splits > 1) ? g.N : g.ldc;
+    gm_epilogue<WT>(g, acc, m0, n0, wm, wn, i31, hi, batch, split);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-f16 variant ("f16x3"): every fp32 operand is split a = hi + lo in f16 while it is staged into LDS and the
+// product is formed as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 3x the MFMA work on a
+// pipe that is 16x faster than the fp32 one.  Relative error ~1e-6 (22 mantissa bits) for operands inside the f16 range
+// (|v| < 65504; anything larger becomes inf and shows up loudly), values below 6e-8 flush to zero.  Used for the
+// Linear-layer products (activations x weights), where both operands are stored [rows][K] (K contiguous).
+// LDS: [plane hi|lo][row][32 k f16 + 8 pad] = 80-B rows, so the fragment ds_read_b128 of 32 consecutive rows is conflict-free.
+#define GX_LDB 80
+__device__ __forceinline__ void gx_store_split(char* S, int tid, const float (&reg)[4][4]) {
+    const int kq = 4 * (tid & 7);
 #pragma unroll
-    for (int a = 0; a < WT; ++a)
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 3) + 32 * i;
+        _Float16 h[4], l[4];
 #pragma unroll
-        for (int b = 0; b < WT; ++b) {
-            const int col = n0 + WS * wn + 32 * b + i31;
-            if (col >= g.N) continue;
-            const float bias = (g.splits > 1 || !g.bias) ? 0.0f : g.bias[col];
+        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)reg[i][q]; l[q] = (_Float16)(reg[i][q] - (float)h[q]); }
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        *(f16x4*)(S + r * GX_LDB + kq * 2) = f16x4{h[0], h[1], h[2], h[3]};
+        *(f16x4*)(S + 128 * GX_LDB + r * GX_LDB + kq * 2) = f16x4{l[0], l[1], l[2], l[3]};
+    }
+}
+
+template <int BDT>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char As[2 * 128 * GX_LDB];
+    __shared__ __attribute__((aligned(16))) char Bs[2 * 128 * GX_LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    const int batch = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
+    const float* A = g.A + (long long)batch * g.sA;
+    const char* B = (const char*)g.B + (long long)batch * g.sB * (BDT == ACMIL_DTYPE_F32 ? 4 : 2);
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + WS * wm + 32 * a + mfma32_row(r, hi);
-                if (row >= g.M) continue;
-                float* dst = Cb + (long long)row * ldc + col;
-                if (g.splits > 1) *dst = acc[a][b][r];
-                else if (g.act == 3) *dst = (row == col ? g.beta : 0.0f) - g.alpha * acc[a][b][r];
-                else {
-                    float v = g.alpha * acc[a][b][r] + bias;
-                    if (g.beta != 0.0f) v += g.beta * *dst;
-                    *dst = gm_act(v, g.act, g.aux + (long long)batch * g.sC, (long long)row * ldc + col);
-                }
-            }
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const bool va = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0) && ((kbeg & 3) == 0);
+    const bool vb = ((g.ldb & 3) == 0) && ((((size_t)B) & (BDT == ACMIL_DTYPE_F32 ? 15 : 7)) == 0) && ((kbeg & 3) == 0);
+    float ra[4][4], rb[4][4];
+    gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, kbeg, g.M, g.K, kend, tid, va, ra);
+    gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, kbeg, g.N, g.K, kend, tid, vb, rb);
+    const char* ap = As + (64 * wm + i31) * GX_LDB + hi * 16;
+    const char* bp = Bs + (64 * wn + i31) * GX_LDB + hi * 16;
+    for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
+        __syncthreads();   // previous tile fully consumed
+        gx_store_split(As, tid, ra);
+        gx_store_split(Bs, tid, rb);
+        __syncthreads();
+        if (k0 + GM_BK < kend) {
+            gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, k0 + GM_BK, g.M, g.K, kend, tid, va, ra);
+            gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, k0 + GM_BK, g.N, g.K, kend, tid, vb, rb);
         }
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = *(const f16x8*)(ap + 32 * t * GX_LDB + kh * 32);
+                al[t] = *(const f16x8*)(ap + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
+                bh[t] = *(const f16x8*)(bp + 32 * t * GX_LDB + kh * 32);
+                bl[t] = *(const f16x8*)(bp + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+    gm_epilogue<2>(g, acc, m0, n0, wm, wn, i31, hi, batch, split);
 }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) {
@@ -237,10 +326,10 @@ extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch) {
     return s > 1 ? (((size_t)s * batch * M * N * sizeof(float) + 255) & ~(size_t)255) : 256;
 }
 
-extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
-                              long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
-                              float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
-                              int batch, void* workspace, void* stream) {
+static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                  long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                  float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                  int batch, void* workspace, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
     if (!A || !B || !C) return ACMIL_ERR_NULL;
     if (act < 0 || act > 3) return ACMIL_ERR_UNSUPPORTED;
@@ -257,10 +346,18 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
     if (g.splits > 1) g.splits = (K + g.kchunk - 1) / g.kchunk;
     if (g.splits < 1) g.splits = 1;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = gm_small_tile(M, N, K, batch) && g.splits == 1 && b_dtype == ACMIL_DTYPE_F32;
+    // split-f16 products need both operands K-contiguous ([M][K] x [N][K]^T); anything else runs the exact fp32 kernel
+    const bool use_x3 = x3 && !transA && transB;
+    const bool small = !use_x3 && gm_small_tile(M, N, K, batch) && g.splits == 1 && b_dtype == ACMIL_DTYPE_F32;
     const int bt = small ? 64 : GM_BM;
     const dim3 grid((N + bt - 1) / bt, (M + bt - 1) / bt, g.splits * batch);
-    if (small) hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 1>), grid, dim3(256), 0, st, g);
+    if (use_x3) switch (b_dtype) {
+        case ACMIL_DTYPE_F32: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_F32>, grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_F16: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_F16>, grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_BF16>, grid, dim3(256), 0, st, g); break;
+        default: return ACMIL_ERR_UNSUPPORTED;
+    }
+    else if (small) hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 1>), grid, dim3(256), 0, st, g);
     else switch (b_dtype) {
         case ACMIL_DTYPE_F32: hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 2>), grid, dim3(256), 0, st, g); break;
         case ACMIL_DTYPE_F16: hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F16, 2>), grid, dim3(256), 0, st, g); break;
@@ -275,4 +372,20 @@ extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     return ACMIL_OK;
+}
+
+extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                              long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                              float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                              int batch, void* workspace, void* stream) {
+    return gm_run(0, transA, transB, M, N, K, alpha, A, lda, strideA, B, b_dtype, ldb, strideB, beta, C, ldc, strideC, bias, act,
+                  aux, batch, workspace, stream);
+}
+
+extern "C" int acmil_gemm_f16x3(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                                long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                                float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                                int batch, void* workspace, void* stream) {
+    return gm_run(1, transA, transB, M, N, K, alpha, A, lda, strideA, B, b_dtype, ldb, strideB, beta, C, ldc, strideC, bias, act,
+                  aux, batch, workspace, stream);
 }

@@ -290,6 +290,9 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
 
 #define TM_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH; } while (0)
 #define TM_GEMM(...) do { int rc_ = acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
+// nn.Linear products (activations x weights, both K-contiguous): split-f16 MFMA, ~1e-6 relative; ACMIL_TM_FP32_GEMM=1 keeps them exact
+static bool tm_linear_exact() { static const bool v = getenv("ACMIL_TM_FP32_GEMM") != nullptr; return v; }
+#define TM_LINEAR(...) do { int rc_ = tm_linear_exact() ? acmil_gemm_f32(__VA_ARGS__) : acmil_gemm_f16x3(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
 // out = c I - P for a batch of m x m matrices (first bracket of the Moore-Penrose iteration, nystrom_attention.py:25)
 __global__ __launch_bounds__(256) void tm_ci_minus_kernel(const float* __restrict__ P, float* __restrict__ out, int m, float c, long long total) {
@@ -325,7 +328,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_layernorm_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, LN, g.n, Di, p.norm_w, p.norm_b, g.pad);
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
-    TM_GEMM(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
+    TM_LINEAR(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
     hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, QKV, g.l, m, Di, QL, KL);
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
@@ -376,7 +379,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
     TM_CHECK_LAUNCH();
     // X[pad:] += OUT[pad:] Wout^T + b   (only the last n rows are kept by the reference)
-    TM_GEMM(0, 1, g.n, Di, Di, 1.0f, OUT + (size_t)g.pad * Di, Di, 0, p.out_w, ACMIL_DTYPE_F32, Di, 0, 1.0f, X + (size_t)g.pad * Di, Di, 0, p.out_b, 0, nullptr, 1, gws, st);
+    TM_LINEAR(0, 1, g.n, Di, Di, 1.0f, OUT + (size_t)g.pad * Di, Di, 0, p.out_w, ACMIL_DTYPE_F32, Di, 0, 1.0f, X + (size_t)g.pad * Di, Di, 0, p.out_b, 0, nullptr, 1, gws, st);
     return ACMIL_OK;
 }
 
@@ -400,7 +403,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     void* gws = ws + W.GEMM;
     const size_t tokbytes = (size_t)g.n * Di;
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
-    TM_GEMM(0, 1, N, Di, D, 1.0f, x, D, 0, fc1_w, ACMIL_DTYPE_F32, D, 0, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, 0, fc1_b, 1, nullptr, 1, gws, st);
+    TM_LINEAR(0, 1, N, Di, D, 1.0f, x, D, 0, fc1_w, ACMIL_DTYPE_F32, D, 0, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, 0, fc1_b, 1, nullptr, 1, gws, st);
     hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
     TM_CHECK_LAUNCH();
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};

@@ -206,9 +206,13 @@ def ga_pool(h: torch.Tensor, A: torch.Tensor, packed: torch.Tensor, dims: GaDims
 
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
          bias: Optional[torch.Tensor] = None, act: int = 0, out: Optional[torch.Tensor] = None, beta: float = 0.0,
-         aux: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """acmil_gemm_f32 on 2-D (or batched 3-D) row-major tensors: out = act(alpha * op(a) @ op(b) + bias + beta*out).
-    a fp32; b fp32/fp16/bf16; inner-most stride must be 1 (leading dimensions / batch strides are honoured)."""
+         aux: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+    """acmil_gemm_f32 / acmil_gemm_f16x3 on 2-D (or batched 3-D) row-major tensors:
+    out = act(alpha * op(a) @ op(b) + bias + beta*out).
+    a fp32; b fp32/fp16/bf16; inner-most stride must be 1 (leading dimensions / batch strides are honoured).
+    precision "fp32" = exact fp32 MFMA, "f16x3" = split-f16 products (x @ W^T layouts only, else falls back to exact)."""
+    if precision not in ("fp32", "f16x3"):
+        raise ValueError("acmil_amd.gemm: precision must be 'fp32' or 'f16x3'")
     lib = _lib.load()
     _need_cuda(a, b)
     if a.dim() == 2:
@@ -227,11 +231,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
     ws = torch.empty(lib.acmil_gemm_workspace_bytes(M, N, K, batch), dtype=torch.uint8, device=a.device)
     sb = 0 if b3.shape[0] == 1 else b3.stride(0)
-    rc = lib.acmil_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), a3.data_ptr(), a3.stride(1),
-                            a3.stride(0) if batch > 1 else 0, b3.data_ptr(), _DT[b3.dtype], b3.stride(1), sb, float(beta),
-                            o3.data_ptr(), o3.stride(1), o3.stride(0) if batch > 1 else 0, _ptr(bias), act, _ptr(aux),
-                            batch, ws.data_ptr(), _stream())
-    _lib.check(rc, "acmil_gemm_f32")
+    fn = lib.acmil_gemm_f16x3 if precision == "f16x3" else lib.acmil_gemm_f32
+    rc = fn(int(trans_a), int(trans_b), M, N, K, float(alpha), a3.data_ptr(), a3.stride(1),
+            a3.stride(0) if batch > 1 else 0, b3.data_ptr(), _DT[b3.dtype], b3.stride(1), sb, float(beta),
+            o3.data_ptr(), o3.stride(1), o3.stride(0) if batch > 1 else 0, _ptr(bias), act, _ptr(aux),
+            batch, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_gemm")
     return out
 
 

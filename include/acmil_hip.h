@@ -141,6 +141,16 @@ int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, con
                    int ldc, long long strideC, const float* bias, int act, const float* aux, int batch,
                    void* workspace, void* stream);
 
+/* Same contract, split-f16 arithmetic ("f16x3", v_mfma_f32_32x32x16_f16): each fp32 operand is split hi + lo in f16 and
+ * the product formed as hi*hi + lo*hi + hi*lo with fp32 accumulation -- relative error ~1e-6 for operands inside the f16
+ * range (|v| < 65504; larger values turn into inf), 3-4x the throughput of the exact kernel.  Applies when both operands
+ * are K-contiguous (transA = 0, transB = 1: the nn.Linear products x W^T of network.py:49-57 / transMIL.py:51,62 /
+ * nystrom_attention.py:55,59); any other layout silently runs the exact fp32 kernel. */
+int acmil_gemm_f16x3(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                     long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta, float* C,
+                     int ldc, long long strideC, const float* bias, int act, const float* aux, int batch,
+                     void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward of one training step of ACMIL_GA (the autograd graph of architecture/transformer.py:305-330,
  * reference has no explicit backward code).  Inputs: the bag x, h [N,Di] and the masked scores A_out [K,N]

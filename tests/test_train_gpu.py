@@ -25,6 +25,41 @@ def test_gemm_matches_fp64(shape, ta, tb):
     assert err <= 2e-6 * scale.max().item() + 1e-6, err
 
 
+@pytest.mark.parametrize("shape", [(300, 200, 96), (1000, 384, 768), (77, 130, 50), (4096, 1152, 384), (1, 7, 384)])
+def test_gemm_f16x3_matches_fp64(shape):
+    """Split-f16 products (x @ W^T layout): ~1e-6 relative to |a|.|b|, with bias / relu / beta, ragged edges, fp16 B, split-K."""
+    from acmil_amd import ops
+    m, n, k = shape
+    g = torch.Generator().manual_seed(m + 5 * n + k)
+    a = torch.randn(m, k, generator=g) * 3.0
+    b = torch.randn(n, k, generator=g) * 0.05
+    bias = torch.randn(n, generator=g)
+    ref = a.double() @ b.double().T + bias.double()
+    scale = (a.abs().double() @ b.abs().double().T).max().item()
+    out = ops.gemm(a.cuda(), b.cuda(), trans_b=True, bias=bias.cuda(), precision="f16x3")
+    assert (out.cpu().double() - ref).abs().max().item() <= 3e-6 * scale + 1e-6
+    out = ops.gemm(a.cuda(), b.cuda(), trans_b=True, bias=bias.cuda(), act=1, precision="f16x3")
+    assert (out.cpu().double() - ref.clamp_min(0)).abs().max().item() <= 3e-6 * scale + 1e-6
+    c0 = torch.randn(m, n, generator=g)
+    out = ops.gemm(a.cuda(), b.cuda(), trans_b=True, out=c0.cuda().clone(), beta=1.0, precision="f16x3")
+    assert (out.cpu().double() - (ref - bias.double() + c0.double())).abs().max().item() <= 3e-6 * scale + 1e-6
+    bh = b.half()
+    out = ops.gemm(a.cuda(), bh.cuda(), trans_b=True, precision="f16x3")
+    assert (out.cpu().double() - a.double() @ bh.double().T).abs().max().item() <= 3e-6 * scale + 1e-6
+    # a layout the split kernel does not take (B stored [K][N]) must still be right (exact fp32 kernel)
+    out = ops.gemm(a.cuda(), b.T.contiguous().cuda(), precision="f16x3")
+    assert (out.cpu().double() - a.double() @ b.double().T).abs().max().item() <= 2e-6 * scale + 1e-6
+
+
+def test_gemm_f16x3_tall_k_split():
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(11)
+    a, b = torch.randn(64, 20000, generator=g), torch.randn(48, 20000, generator=g)
+    out = ops.gemm(a.cuda(), b.cuda(), trans_b=True, precision="f16x3")
+    ref = a.double() @ b.double().T
+    assert (out.cpu().double() - ref).abs().max().item() <= 3e-6 * (a.abs().double() @ b.abs().double().T).max().item()
+
+
 def test_gemm_options():
     from acmil_amd import ops
     g = torch.Generator().manual_seed(3)
