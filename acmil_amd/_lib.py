@@ -40,6 +40,8 @@ SIGNATURES = {
                             _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
     "acmil_gemm_f16x3": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
                               _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
+    "acmil_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
+                               _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),
@@ -47,7 +49,7 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_ga_backward_workspace_bytes": (_sz, [_i] * 5),
     "acmil_ga_backward": (_i, [_vp, _i, _i] + [_vp] * 8 + [C.POINTER(_vp)] + [_vp] * 4 + [_vp] * 7 +
-                          [C.POINTER(_vp), C.POINTER(_vp)] + [_vp, _vp] + [_i] * 5 + [_vp, _vp]),
+                          [C.POINTER(_vp), C.POINTER(_vp)] + [_vp, _vp] + [_i] * 6 + [_vp, _vp]),
 }
 
 _lib = None

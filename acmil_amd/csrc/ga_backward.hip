@@ -241,10 +241,17 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
                                  const float* Ww, const float* const* Wc, const float* Ws, const float* d_sub,
                                  const float* d_slide, const float* d_A, float* dW1, float* dWv, float* dbv, float* dWu,
                                  float* dbu, float* dWw, float* dbw, float* const* dWc, float* const* dbc, float* dWs,
-                                 float* dbs, int D, int Di, int Da, int K, int C, void* workspace, void* stream) {
+                                 float* dbs, int D, int Di, int Da, int K, int C, int mode, void* workspace, void* stream) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (N <= 0) return ACMIL_ERR_SHAPE;
+    if (mode != ACMIL_MODE_F32 && mode != ACMIL_MODE_F16X3 && mode != ACMIL_MODE_F16) return ACMIL_ERR_UNSUPPORTED;
+    // GEMM arithmetic follows the forward mode: exact fp32 MFMA, or split products -- f16 halves for the recomputed
+    // pre-activations (forward-sized values), bf16 halves wherever an operand is a gradient (values down to 1e-8)
+    typedef int (*gemm_fn)(int, int, int, int, int, float, const float*, int, long long, const void*, int, int, long long, float,
+                           float*, int, long long, const float*, int, const float*, int, void*, void*);
+    const gemm_fn gemm_fwd = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_f16x3;
+    const gemm_fn gemm_grad = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_bf16x3;
     if (Di != 128 && Di != 256 && Di != 384 && Di != 512) return ACMIL_ERR_UNSUPPORTED;
     if (!x || !h || !A_out || !afeat || !Wv || !bv || !Wu || !bu || !Ww || !Wc || !d_sub || !workspace) return ACMIL_ERR_NULL;
     if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc) return ACMIL_ERR_NULL;
@@ -273,10 +280,10 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     hipLaunchKernelGGL(ga_bwd_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     // 3 G = h [Wv;Wu]^T + [bv;bu]
-    rc = acmil_gemm_f32(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bv, 0,
+    rc = gemm_fwd(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bv, 0,
                         nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    rc = acmil_gemm_f32(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 0.0f, G + GA_DA, 2 * GA_DA, 0, bu,
+    rc = gemm_fwd(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 0.0f, G + GA_DA, 2 * GA_DA, 0, bu,
                         0, nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
     // 4 gate pass
@@ -293,20 +300,20 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
 #undef GB_LAUNCH_GATE
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     // 5 dpre = (dh0 + dGv Wv + dGu Wu) * [h > 0]
-    rc = acmil_gemm_f32(0, 0, N, Di, GA_DA, 1.0f, G, 2 * GA_DA, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 0,
+    rc = gemm_grad(0, 0, N, Di, GA_DA, 1.0f, G, 2 * GA_DA, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 0,
                         nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    rc = acmil_gemm_f32(0, 0, N, Di, GA_DA, 1.0f, G + GA_DA, 2 * GA_DA, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0,
+    rc = gemm_grad(0, 0, N, Di, GA_DA, 1.0f, G + GA_DA, 2 * GA_DA, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0,
                         nullptr, 2, h, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
     // 6 weight gradients (contraction over the N patches, split-K)
-    rc = acmil_gemm_f32(1, 0, GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWv, Di, 0, nullptr, 0,
+    rc = gemm_grad(1, 0, GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWv, Di, 0, nullptr, 0,
                         nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    rc = acmil_gemm_f32(1, 0, GA_DA, Di, N, 1.0f, G + GA_DA, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWu, Di, 0,
+    rc = gemm_grad(1, 0, GA_DA, Di, N, 1.0f, G + GA_DA, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWu, Di, 0,
                         nullptr, 0, nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    rc = acmil_gemm_f32(1, 0, Di, D, N, 1.0f, dpre, Di, 0, x, x_dtype, D, 0, 0.0f, dW1, D, 0, nullptr, 0, nullptr, 1, gws,
+    rc = gemm_grad(1, 0, Di, D, N, 1.0f, dpre, Di, 0, x, x_dtype, D, 0, 0.0f, dW1, D, 0, nullptr, 0, nullptr, 1, gws,
                         st);
     if (rc != ACMIL_OK) return rc;
     // 7 reduce gate partials

@@ -211,25 +211,77 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // product is formed as hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 with fp32 accumulation -- 3x the MFMA work on a
 // pipe that is 16x faster than the fp32 one.  Relative error ~1e-6 (22 mantissa bits) for operands inside the f16 range
 // (|v| < 65504; anything larger becomes inf and shows up loudly), values below 6e-8 flush to zero.  Used for the
-// Linear-layer products (activations x weights), where both operands are stored [rows][K] (K contiguous).
+// Linear-layer products (activations x weights) and the weight-gradient / input-gradient products of the backward.
 // LDS: [plane hi|lo][row][32 k f16 + 8 pad] = 80-B rows, so the fragment ds_read_b128 of 32 consecutive rows is conflict-free.
 #define GX_LDB 80
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// bf16 variant ("bf16x3"): same scheme with bf16 halves -- 16 mantissa bits (relative error ~1e-5) but the full fp32
+// exponent range, so tiny operands (gradients of a softmax over 50 000 patches ~1e-7) need no scaling.  Used by the backward.
+template <bool BF> struct GxT { typedef _Float16 T; typedef f16x8 V8; };
+template <> struct GxT<true> { typedef __bf16 T; typedef bf16x8 V8; };
+template <bool BF>
+__device__ __forceinline__ f32x16 gx_mfma(typename GxT<BF>::V8 a, typename GxT<BF>::V8 b, f32x16 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+template <bool BF>
 __device__ __forceinline__ void gx_store_split(char* S, int tid, const float (&reg)[4][4]) {
+    typedef typename GxT<BF>::T T;
     const int kq = 4 * (tid & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 3) + 32 * i;
-        _Float16 h[4], l[4];
+        T h[4], l[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { h[q] = (_Float16)reg[i][q]; l[q] = (_Float16)(reg[i][q] - (float)h[q]); }
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        *(f16x4*)(S + r * GX_LDB + kq * 2) = f16x4{h[0], h[1], h[2], h[3]};
-        *(f16x4*)(S + 128 * GX_LDB + r * GX_LDB + kq * 2) = f16x4{l[0], l[1], l[2], l[3]};
+        for (int q = 0; q < 4; ++q) { h[q] = (T)reg[i][q]; l[q] = (T)(reg[i][q] - (float)h[q]); }
+        typedef T tx4 __attribute__((ext_vector_type(4)));
+        *(tx4*)(S + r * GX_LDB + kq * 2) = tx4{h[0], h[1], h[2], h[3]};
+        *(tx4*)(S + 128 * GX_LDB + r * GX_LDB + kq * 2) = tx4{l[0], l[1], l[2], l[3]};
     }
 }
 
-template <int BDT>
+// Operands stored [K][rows] (rows contiguous: transposed A, plain B): thread -> row = tid % 128, 16 consecutive k starting
+// at 16 * (tid / 128).  The 16 scalar loads are each coalesced across the lanes (consecutive rows); the thread then owns 16
+// consecutive k of one row = 32 B of the hi plane and 32 B of the lo plane, written with 2 + 2 ds_write_b128.
+template <bool IS_B, int BDT>
+__device__ __forceinline__ void gx_load_rows(const void* P, int ld, int r0, int k0, int R, int kend, int tid, float (&reg)[4][4]) {
+    const int r = r0 + (tid & 127);
+    const int kb = k0 + 16 * (tid >> 7);
+    const bool rok = r < R;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = kb + j;
+        float v = 0.0f;
+        if (rok && k < kend) {
+            const long long idx = (long long)k * ld + r;
+            if constexpr (IS_B) v = gm_ldb<BDT>(P, idx); else v = ((const float*)P)[idx];
+        }
+        reg[j >> 2][j & 3] = v;
+    }
+}
+
+template <bool BF>
+__device__ __forceinline__ void gx_store_split_rows(char* S, int tid, const float (&reg)[4][4]) {
+    typedef typename GxT<BF>::T T;
+    typedef typename GxT<BF>::V8 V8;
+    const int r = tid & 127, kb = 16 * (tid >> 7);
+    V8 h[2], l[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float v = reg[j >> 2][j & 3];
+        const T hv = (T)v;
+        h[j >> 3][j & 7] = hv;
+        l[j >> 3][j & 7] = (T)(v - (float)hv);
+    }
+    char* d = S + r * GX_LDB + kb * 2;
+    *(V8*)(d) = h[0]; *(V8*)(d + 16) = h[1];
+    *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + 16) = l[1];
+}
+
+template <int BDT, bool BF>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g) {
+    typedef typename GxT<BF>::V8 V8;
     __shared__ __attribute__((aligned(16))) char As[2 * 128 * GX_LDB];
     __shared__ __attribute__((aligned(16))) char Bs[2 * 128 * GX_LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -241,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g) {
     const char* B = (const char*)g.B + (long long)batch * g.sB * (BDT == ACMIL_DTYPE_F32 ? 4 : 2);
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
+    const bool a_ck = !g.transA, b_ck = (g.transB != 0);   // operand stored with K contiguous?
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -251,36 +304,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g) {
     const bool va = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0) && ((kbeg & 3) == 0);
     const bool vb = ((g.ldb & 3) == 0) && ((((size_t)B) & (BDT == ACMIL_DTYPE_F32 ? 15 : 7)) == 0) && ((kbeg & 3) == 0);
     float ra[4][4], rb[4][4];
-    gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, kbeg, g.M, g.K, kend, tid, va, ra);
-    gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, kbeg, g.N, g.K, kend, tid, vb, rb);
+    auto load_a = [&](int k0) {
+        if (a_ck) gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, k0, g.M, g.K, kend, tid, va, ra);
+        else gx_load_rows<false, ACMIL_DTYPE_F32>(A, g.lda, m0, k0, g.M, kend, tid, ra);
+    };
+    auto load_b = [&](int k0) {
+        if (b_ck) gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, k0, g.N, g.K, kend, tid, vb, rb);
+        else gx_load_rows<true, BDT>(B, g.ldb, n0, k0, g.N, kend, tid, rb);
+    };
+    load_a(kbeg); load_b(kbeg);
     const char* ap = As + (64 * wm + i31) * GX_LDB + hi * 16;
     const char* bp = Bs + (64 * wn + i31) * GX_LDB + hi * 16;
     for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
         __syncthreads();   // previous tile fully consumed
-        gx_store_split(As, tid, ra);
-        gx_store_split(Bs, tid, rb);
+        if (a_ck) gx_store_split<BF>(As, tid, ra); else gx_store_split_rows<BF>(As, tid, ra);
+        if (b_ck) gx_store_split<BF>(Bs, tid, rb); else gx_store_split_rows<BF>(Bs, tid, rb);
         __syncthreads();
-        if (k0 + GM_BK < kend) {
-            gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, k0 + GM_BK, g.M, g.K, kend, tid, va, ra);
-            gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, k0 + GM_BK, g.N, g.K, kend, tid, vb, rb);
-        }
+        if (k0 + GM_BK < kend) { load_a(k0 + GM_BK); load_b(k0 + GM_BK); }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            V8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                ah[t] = *(const f16x8*)(ap + 32 * t * GX_LDB + kh * 32);
-                al[t] = *(const f16x8*)(ap + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
-                bh[t] = *(const f16x8*)(bp + 32 * t * GX_LDB + kh * 32);
-                bl[t] = *(const f16x8*)(bp + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
+                ah[t] = *(const V8*)(ap + 32 * t * GX_LDB + kh * 32);
+                al[t] = *(const V8*)(ap + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
+                bh[t] = *(const V8*)(bp + 32 * t * GX_LDB + kh * 32);
+                bl[t] = *(const V8*)(bp + 128 * GX_LDB + 32 * t * GX_LDB + kh * 32);
             }
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = gx_mfma<BF>(ah[a], bh[b], acc[a][b]);
+                    acc[a][b] = gx_mfma<BF>(al[a], bh[b], acc[a][b]);
+                    acc[a][b] = gx_mfma<BF>(ah[a], bl[b], acc[a][b]);
                 }
         }
     }
@@ -293,7 +350,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
         const int b = e / per; const long long r = e % per;
         const float* src = g.ws + (long long)b * g.splits * per + r;
         float s = 0.0f;
-        for (int sp = 0; sp < g.splits; ++sp) s += src[(long long)sp * per];   // fixed order
+        int sp = 0;
+        for (; sp + 8 <= g.splits; sp += 8) {                                  // 8 loads in flight, summed in index order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(long long)(sp + j) * per];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; sp < g.splits; ++sp) s += src[(long long)sp * per];             // fixed order
         const int row = r / g.N, col = r % g.N;
         float v = g.alpha * s + (g.bias ? g.bias[col] : 0.0f);
         const long long idx = (long long)row * g.ldc + col;
@@ -346,15 +411,20 @@ static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alp
     if (g.splits > 1) g.splits = (K + g.kchunk - 1) / g.kchunk;
     if (g.splits < 1) g.splits = 1;
     hipStream_t st = (hipStream_t)stream;
-    // split-f16 products need both operands K-contiguous ([M][K] x [N][K]^T); anything else runs the exact fp32 kernel
-    const bool use_x3 = x3 && !transA && transB;
+    const bool use_x3 = x3 != 0;
     const bool small = !use_x3 && gm_small_tile(M, N, K, batch) && g.splits == 1 && b_dtype == ACMIL_DTYPE_F32;
     const int bt = small ? 64 : GM_BM;
     const dim3 grid((N + bt - 1) / bt, (M + bt - 1) / bt, g.splits * batch);
-    if (use_x3) switch (b_dtype) {
-        case ACMIL_DTYPE_F32: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_F32>, grid, dim3(256), 0, st, g); break;
-        case ACMIL_DTYPE_F16: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_F16>, grid, dim3(256), 0, st, g); break;
-        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL(gemm_f16x3_kernel<ACMIL_DTYPE_BF16>, grid, dim3(256), 0, st, g); break;
+    if (x3 == 1) switch (b_dtype) {
+        case ACMIL_DTYPE_F32: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_F32, false>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_F16: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_F16, false>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_BF16, false>), grid, dim3(256), 0, st, g); break;
+        default: return ACMIL_ERR_UNSUPPORTED;
+    }
+    else if (x3 == 2) switch (b_dtype) {
+        case ACMIL_DTYPE_F32: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_F32, true>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_F16: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_F16, true>), grid, dim3(256), 0, st, g); break;
+        case ACMIL_DTYPE_BF16: hipLaunchKernelGGL((gemm_f16x3_kernel<ACMIL_DTYPE_BF16, true>), grid, dim3(256), 0, st, g); break;
         default: return ACMIL_ERR_UNSUPPORTED;
     }
     else if (small) hipLaunchKernelGGL((gemm_f32_kernel<ACMIL_DTYPE_F32, 1>), grid, dim3(256), 0, st, g);
@@ -387,5 +457,13 @@ extern "C" int acmil_gemm_f16x3(int transA, int transB, int M, int N, int K, flo
                                 float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
                                 int batch, void* workspace, void* stream) {
     return gm_run(1, transA, transB, M, N, K, alpha, A, lda, strideA, B, b_dtype, ldb, strideB, beta, C, ldc, strideC, bias, act,
+                  aux, batch, workspace, stream);
+}
+
+extern "C" int acmil_gemm_bf16x3(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                                 long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
+                                 float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
+                                 int batch, void* workspace, void* stream) {
+    return gm_run(2, transA, transB, M, N, K, alpha, A, lda, strideA, B, b_dtype, ldb, strideB, beta, C, ldc, strideC, bias, act,
                   aux, batch, workspace, stream);
 }

@@ -41,8 +41,9 @@ def mode_id(mode) -> int:
 class GaDims:
     """Shape bundle of one gated-attention aggregator."""
 
-    def __init__(self, D: int, Di: int, K: int, C: int, has_bag_head: bool = True):
+    def __init__(self, D: int, Di: int, K: int, C: int, has_bag_head: bool = True, mode: int = 1):
         self.D, self.Di, self.K, self.C, self.has_bag_head = D, Di, K, C, bool(has_bag_head)
+        self.mode = int(mode)      # arithmetic mode the weights were packed for (ACMIL_MODE_*); the backward follows it
 
     def args(self):
         return (self.D, self.Di, GA_DA, self.K, self.C)
@@ -63,7 +64,7 @@ def ga_pack_weights(W1, Wv, bv, Wu, bu, Ww, bw, Wc: Sequence[torch.Tensor], bc: 
     K, C = Ww.shape[0], Wc[0].shape[0]
     if Wv.shape != (GA_DA, Di) or Wu.shape != (GA_DA, Di) or Ww.shape[1] != GA_DA or len(Wc) != K:
         raise RuntimeError("acmil_amd: unexpected parameter shapes")
-    dims = GaDims(D, Di, K, C, has_bag_head=Ws is not None)
+    dims = GaDims(D, Di, K, C, has_bag_head=Ws is not None, mode=mode)
     nbytes = lib.acmil_ga_packed_bytes(*dims.args(), mode)
     if nbytes == 0:
         raise RuntimeError("acmil_amd: unsupported dimensions D=%d Di=%d K=%d C=%d" % (D, Di, K, C))
@@ -210,16 +211,17 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     """acmil_gemm_f32 / acmil_gemm_f16x3 on 2-D (or batched 3-D) row-major tensors:
     out = act(alpha * op(a) @ op(b) + bias + beta*out).
     a fp32; b fp32/fp16/bf16; inner-most stride must be 1 (leading dimensions / batch strides are honoured).
-    precision "fp32" = exact fp32 MFMA, "f16x3" = split-f16 products (x @ W^T layouts only, else falls back to exact)."""
-    if precision not in ("fp32", "f16x3"):
-        raise ValueError("acmil_amd.gemm: precision must be 'fp32' or 'f16x3'")
+    precision "fp32" = exact fp32 MFMA, "f16x3" / "bf16x3" = split-f16 / split-bf16 products (~1e-6 / ~1e-5 relative)."""
+    if precision not in ("fp32", "f16x3", "bf16x3"):
+        raise ValueError("acmil_amd.gemm: precision must be 'fp32', 'f16x3' or 'bf16x3'")
     lib = _lib.load()
     _need_cuda(a, b)
     if a.dim() == 2:
         a3, b3 = a.unsqueeze(0), b.unsqueeze(0)
     else:
         a3, b3 = a, b
-    if a3.stride(-1) != 1 or b3.stride(-1) != 1 or a3.dtype != torch.float32 or b3.dtype not in _DT:
+    unit = lambda t: t.shape[-1] == 1 or t.stride(-1) == 1       # a size-1 inner dimension may carry any stride
+    if not unit(a3) or not unit(b3) or a3.dtype != torch.float32 or b3.dtype not in _DT:
         raise RuntimeError("acmil_amd.gemm: operands must have unit inner stride; A fp32")
     batch = a3.shape[0]
     M, K = (a3.shape[2], a3.shape[1]) if trans_a else (a3.shape[1], a3.shape[2])
@@ -231,7 +233,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool 
     o3 = out if out.dim() == 3 else out.unsqueeze(0)
     ws = torch.empty(lib.acmil_gemm_workspace_bytes(M, N, K, batch), dtype=torch.uint8, device=a.device)
     sb = 0 if b3.shape[0] == 1 else b3.stride(0)
-    fn = lib.acmil_gemm_f16x3 if precision == "f16x3" else lib.acmil_gemm_f32
+    fn = {"fp32": lib.acmil_gemm_f32, "f16x3": lib.acmil_gemm_f16x3, "bf16x3": lib.acmil_gemm_bf16x3}[precision]
     rc = fn(int(trans_a), int(trans_b), M, N, K, float(alpha), a3.data_ptr(), a3.stride(1),
             a3.stride(0) if batch > 1 else 0, b3.data_ptr(), _DT[b3.dtype], b3.stride(1), sb, float(beta),
             o3.data_ptr(), o3.stride(1), o3.stride(0) if batch > 1 else 0, _ptr(bias), act, _ptr(aux),
@@ -267,7 +269,7 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
                                Wv.data_ptr(), bv.data_ptr(), Wu.data_ptr(), bu.data_ptr(), Ww.data_ptr(), arr(Wc), _ptr(Ws),
                                d_sub.data_ptr(), _ptr(d_slide), _ptr(d_A), gW1.data_ptr(), gWv.data_ptr(), gbv.data_ptr(),
                                gWu.data_ptr(), gbu.data_ptr(), gWw.data_ptr(), gbw.data_ptr(), arr(gWc), arr(gbc),
-                               _ptr(gWs), _ptr(gbs), D, Di, GA_DA, K, Cc, ws.data_ptr(), _stream())
+                               _ptr(gWs), _ptr(gbs), D, Di, GA_DA, K, Cc, dims.mode, ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_backward")
     return grads
 

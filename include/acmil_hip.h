@@ -143,13 +143,20 @@ int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, con
 
 /* Same contract, split-f16 arithmetic ("f16x3", v_mfma_f32_32x32x16_f16): each fp32 operand is split hi + lo in f16 and
  * the product formed as hi*hi + lo*hi + hi*lo with fp32 accumulation -- relative error ~1e-6 for operands inside the f16
- * range (|v| < 65504; larger values turn into inf), 3-4x the throughput of the exact kernel.  Applies when both operands
- * are K-contiguous (transA = 0, transB = 1: the nn.Linear products x W^T of network.py:49-57 / transMIL.py:51,62 /
- * nystrom_attention.py:55,59); any other layout silently runs the exact fp32 kernel. */
+ * range (|v| < 65504; larger values turn into inf), 2-4x the throughput of the exact kernel.  Used for the nn.Linear
+ * products x W^T (network.py:49-57 / transMIL.py:51,62 / nystrom_attention.py:55,59) and for the weight / input gradient
+ * products of the backward. */
 int acmil_gemm_f16x3(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                      long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta, float* C,
                      int ldc, long long strideC, const float* bias, int act, const float* aux, int batch,
                      void* workspace, void* stream);
+
+/* Same contract with bf16 halves ("bf16x3", v_mfma_f32_32x32x16_bf16): 16 mantissa bits (relative error ~1e-5) but the
+ * full fp32 exponent range -- for the gradient products of the backward, whose operands reach 1e-8. */
+int acmil_gemm_bf16x3(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                      long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta, float* C,
+                      int ldc, long long strideC, const float* bias, int act, const float* aux, int batch,
+                      void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of one training step of ACMIL_GA (the autograd graph of architecture/transformer.py:305-330,
@@ -168,7 +175,7 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
                       const float* const* Wc, const float* Ws, const float* d_sub, const float* d_slide,
                       const float* d_A, float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw,
                       float* dbw, float* const* dWc, float* const* dbc, float* dWs, float* dbs, int D, int Di, int Da,
-                      int K, int C, void* workspace, void* stream);
+                      int K, int C, int mode, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216

@@ -46,9 +46,30 @@ def test_gemm_f16x3_matches_fp64(shape):
     bh = b.half()
     out = ops.gemm(a.cuda(), bh.cuda(), trans_b=True, precision="f16x3")
     assert (out.cpu().double() - a.double() @ bh.double().T).abs().max().item() <= 3e-6 * scale + 1e-6
-    # a layout the split kernel does not take (B stored [K][N]) must still be right (exact fp32 kernel)
+    # the other three operand layouts ([K][rows] staging path)
+    ref0 = a.double() @ b.double().T
     out = ops.gemm(a.cuda(), b.T.contiguous().cuda(), precision="f16x3")
-    assert (out.cpu().double() - a.double() @ b.double().T).abs().max().item() <= 2e-6 * scale + 1e-6
+    assert (out.cpu().double() - ref0).abs().max().item() <= 3e-6 * scale + 1e-6
+    out = ops.gemm(a.T.contiguous().cuda(), b.cuda(), trans_a=True, trans_b=True, precision="f16x3")
+    assert (out.cpu().double() - ref0).abs().max().item() <= 3e-6 * scale + 1e-6
+    out = ops.gemm(a.T.contiguous().cuda(), b.T.contiguous().half().cuda(), trans_a=True, precision="f16x3")
+    assert (out.cpu().double() - a.double() @ b.half().double().T).abs().max().item() <= 3e-6 * scale + 1e-6
+
+
+def test_gemm_bf16x3_tiny_operands():
+    """bf16 halves keep the fp32 exponent range: gradient-sized operands (1e-8) that f16 halves would flush."""
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(17)
+    a = torch.randn(500, 256, generator=g) * 1e-8            # dS-like
+    b = torch.randn(256, 300, generator=g) * 0.05            # weights, stored [K][N]
+    ref = a.double() @ b.double()
+    scale = (a.abs().double() @ b.abs().double()).max().item()
+    out = ops.gemm(a.cuda(), b.cuda(), precision="bf16x3")
+    assert (out.cpu().double() - ref).abs().max().item() <= 4e-5 * scale
+    out = ops.gemm(a.T.contiguous().cuda(), b.cuda(), trans_a=True, precision="bf16x3")
+    assert (out.cpu().double() - ref).abs().max().item() <= 4e-5 * scale
+    rel = ((out.cpu().double() - ref).abs().sum() / ref.abs().sum()).item()
+    assert rel < 1e-5, rel
 
 
 def test_gemm_f16x3_tall_k_split():
@@ -57,7 +78,10 @@ def test_gemm_f16x3_tall_k_split():
     a, b = torch.randn(64, 20000, generator=g), torch.randn(48, 20000, generator=g)
     out = ops.gemm(a.cuda(), b.cuda(), trans_b=True, precision="f16x3")
     ref = a.double() @ b.double().T
-    assert (out.cpu().double() - ref).abs().max().item() <= 3e-6 * (a.abs().double() @ b.abs().double().T).max().item()
+    tol = 3e-6 * (a.abs().double() @ b.abs().double().T).max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= tol
+    out = ops.gemm(a.T.contiguous().cuda(), b.T.contiguous().cuda(), trans_a=True, precision="f16x3")   # dW = dS^T h layout
+    assert (out.cpu().double() - ref).abs().max().item() <= tol
 
 
 def test_gemm_options():
