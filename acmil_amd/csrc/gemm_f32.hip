@@ -280,7 +280,7 @@ __device__ __forceinline__ void gx_store_split_rows(char* S, int tid, const floa
 }
 
 template <int BDT, bool BF>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmArgs g) {
     typedef typename GxT<BF>::V8 V8;
     __shared__ __attribute__((aligned(16))) char As[2 * 128 * GX_LDB];
     __shared__ __attribute__((aligned(16))) char Bs[2 * 128 * GX_LDB];
