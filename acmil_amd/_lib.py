@@ -42,6 +42,8 @@ SIGNATURES = {
                               _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
     "acmil_gemm_bf16x3": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
                                _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
+    "acmil_mha_workspace_bytes": (_sz, [_i] * 5),
+    "acmil_mha_forward": (_i, [_vp] + [_i] * 5 + [_vp, _vp] + [C.POINTER(_vp)] * 4 + [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),

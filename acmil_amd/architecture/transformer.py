@@ -226,3 +226,70 @@ class ACMIL_GA(_GatedBase):
             out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=False, want_preds=False,
                                  want_bag_feat=True)
         return out["bag_feat"].unsqueeze(0)
+
+
+class MutiHeadAttention(nn.Module):
+    """Parameter container with the reference's names (architecture/transformer.py:107-140): q/k/v/out projections and a
+    LayerNorm(eps=1e-6).  The arithmetic lives in acmil_mha_forward (csrc/mha.hip); dropout is eval-identity."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1, dropout: float = 0.1,
+                 n_masked_patch: int = 0, mask_drop: float = 0.0):
+        super().__init__()
+        if downsample_rate != 1 or num_heads != 8:
+            raise NotImplementedError("acmil_amd: MutiHeadAttention is built for 8 heads, downsample_rate 1 (transformer.py:55)")
+        self.n_masked_patch, self.mask_drop = n_masked_patch, mask_drop
+        self.embedding_dim = self.internal_dim = embedding_dim
+        self.num_heads = num_heads
+        self.q_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.k_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.v_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.out_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.layer_norm = nn.LayerNorm(embedding_dim, eps=1e-6)
+
+
+class MutiHeadAttention_modify(nn.Module):
+    """Parameter container of the bag attention (architecture/transformer.py:187-219): v / out projections + LayerNorm."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1, dropout: float = 0.1):
+        super().__init__()
+        if downsample_rate != 1 or num_heads != 8:
+            raise NotImplementedError("acmil_amd: MutiHeadAttention_modify is built for 8 heads, downsample_rate 1")
+        self.embedding_dim = self.internal_dim = embedding_dim
+        self.num_heads = num_heads
+        self.v_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.out_proj = nn.Linear(embedding_dim, embedding_dim)
+        self.layer_norm = nn.LayerNorm(embedding_dim, eps=1e-6)
+
+
+class ACMIL_MHA(nn.Module):
+    """Drop-in for the reference's `ACMIL_MHA` (architecture/transformer.py:49-83, `--arch mha`): same ctor, parameter names
+    and return contract `(sub_preds [K,C], slide_pred [1,C], attns [8,K,N])`.  Eval forward only: the reference's train
+    mode draws Dropout(0.1) masks after out_proj and applies STKIM per head; neither the masks nor the backward are built,
+    so a training-mode call raises instead of silently differing."""
+
+    def __init__(self, conf, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3"):
+        super().__init__()
+        self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
+        self.sub_attention = nn.ModuleList(
+            [MutiHeadAttention(conf.D_inner, 8, n_masked_patch=n_masked_patch, mask_drop=mask_drop) for _ in range(n_token)])
+        self.bag_attention = MutiHeadAttention_modify(conf.D_inner, 8)
+        self.q = nn.Parameter(torch.zeros((1, n_token, conf.D_inner)))
+        nn.init.normal_(self.q, std=1e-6)
+        self.n_class = conf.n_class
+        self.classifier = nn.ModuleList([Classifier_1fc(conf.D_inner, conf.n_class, 0.0) for _ in range(n_token)])
+        self.n_token = n_token
+        self.Slide_classifier = Classifier_1fc(conf.D_inner, conf.n_class, 0.0)
+        self.precision = precision
+
+    def forward(self, input):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("acmil_amd: ACMIL_MHA training (dropout, per-head STKIM, backward) is not built; use .eval()")
+        if input.dim() != 3 or input.shape[0] != 1:
+            raise RuntimeError("acmil_amd: ACMIL_MHA expects input [1, N, D_feat]")
+        x = input[0]
+        if not x.is_cuda:
+            raise RuntimeError("acmil_amd: ACMIL_MHA runs on an MI355X only (no CPU fallback)")
+        x = x.float().contiguous()
+        sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
+        out = ops.mha_forward(x, sd, self.n_token, self.n_class, self.precision)
+        return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["attns"]

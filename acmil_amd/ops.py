@@ -333,3 +333,43 @@ def ga_loss(sub_preds: torch.Tensor, slide_pred: Optional[torch.Tensor], A_out: 
                            losses.data_ptr(), d_sub.data_ptr(), _ptr(d_slide), d_A.data_ptr(), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_loss")
     return losses, d_sub, d_slide, d_A
+
+
+def mha_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_token: int, n_class: int, precision="f16x3") -> Dict[str, torch.Tensor]:
+    """acmil_mha_forward.  x [N,D] fp32 CUDA; sd: ACMIL_MHA parameters under the reference's state_dict names (fp32, CUDA,
+    contiguous).  Returns {'sub_preds' [K,C], 'slide_pred' [C], 'attns' [8,K,N]}."""
+    lib = _lib.load()
+    _need_cuda(x)
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("acmil_amd.mha_forward: x must be contiguous fp32 [N, D]")
+    mode = mode_id(precision)
+    N, D = x.shape
+    W1 = sd["dimreduction.fc1.weight"]
+    Di, K, C = W1.shape[0], n_token, n_class
+    keep = []
+
+    def ptr(name):
+        t = sd[name]
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("acmil_amd.mha_forward: parameter %s must be contiguous fp32 on the GPU" % name)
+        keep.append(t)
+        return t.data_ptr()
+    names = ("q_proj.weight", "q_proj.bias", "k_proj.weight", "k_proj.bias", "v_proj.weight", "v_proj.bias", "out_proj.weight",
+             "out_proj.bias", "layer_norm.weight", "layer_norm.bias")
+    branch = (ctypes.c_void_p * (10 * K))(*[ptr("sub_attention.%d.%s" % (i, nm)) for i in range(K) for nm in names])
+    bag = (ctypes.c_void_p * 6)(*[ptr("bag_attention." + nm) for nm in names[4:]])
+    Wc = (ctypes.c_void_p * K)(*[ptr("classifier.%d.fc.weight" % i) for i in range(K)])
+    bc = (ctypes.c_void_p * K)(*[ptr("classifier.%d.fc.bias" % i) for i in range(K)])
+    q = sd["q"].reshape(K, Di)
+    nbytes = lib.acmil_mha_workspace_bytes(N, D, Di, K, C)
+    if nbytes == 0:
+        raise RuntimeError("acmil_amd.mha_forward: unsupported shape (Di %% 64 == 0, Di <= 512, n_token <= 5)")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    sub = torch.empty(K, C, dtype=torch.float32, device=x.device)
+    slide = torch.empty(C, dtype=torch.float32, device=x.device)
+    attns = torch.empty(8, K, N, dtype=torch.float32, device=x.device)
+    rc = lib.acmil_mha_forward(x.data_ptr(), N, D, Di, K, C, ptr("dimreduction.fc1.weight"), q.data_ptr(), branch, bag, Wc, bc,
+                               ptr("Slide_classifier.fc.weight"), ptr("Slide_classifier.fc.bias"), mode, sub.data_ptr(),
+                               slide.data_ptr(), attns.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_mha_forward")
+    return {"sub_preds": sub, "slide_pred": slide, "attns": attns}

@@ -59,6 +59,159 @@ def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
     return nbytes, flops
 
 
+def _dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    return world, rank, dev
+
+
+def _timed(step, args, world, dev):
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def other_workloads(args):
+    """Secondary bench lines (same JSON contract): the TransMIL eval forward (configs[3]) and the ACMIL training step
+    (configs[4]).  The driver's default invocation never takes this branch."""
+    world, rank, dev = _dist_setup(args)
+    from acmil_amd import _lib
+    _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
+    if args.workload == "transmil":
+        from oracle import transmil_oracle as TO
+        from acmil_amd.architecture.transMIL import TransMIL
+        N, D, Di, C = 100000, 768, 384, 2
+
+        class Conf:
+            D_feat, D_inner, n_class = D, Di, C
+        sd = TO.default_state_dict(D, Di, C, seed=1)
+        model = TransMIL(Conf)
+        model.load_state_dict(sd)
+        model = model.to(dev).eval()
+        bags = [torch.randn(1, N, D, generator=torch.Generator().manual_seed(1000 + rank * 4 + i)).to(dev) for i in range(4)]
+        with torch.no_grad():
+            dt = _timed(lambda i: model(bags[i % 4]), args, world, dev)
+        side = int(-(-N ** 0.5 // 1)); n = side * side + 1; m = Di // 2; npad = -(-n // m) * m; h, d = 8, Di // 8
+        # SURVEY 8(d), re-associated: fc1 + 2 layers x (qkv, 4 head-batched n' x m x d products, out-proj, res-conv, pinv) + PPEG
+        flops = 2 * N * D * Di + 2 * (2 * npad * Di * 3 * Di + 4 * (2 * h * npad * m * d) + 2 * npad * Di * Di + 2 * 33 * npad * Di
+                                      + 48 * h * m ** 3) + 2 * 83 * side * side * Di
+        nbytes = N * D * 4
+        t_slide = dt / args.steps
+        result = {
+            "metric": "slides/sec (TransMIL / Nystrom-attention eval forward, N=100000 D=768)", "value": round(world * args.steps / dt, 2),
+            "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_slide * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (Linear layers as split-f16 x3 MFMA products, attention legs exact fp32 MFMA)", "data": "synthetic",
+            "config": {"workload": "TransMIL eval forward, one slide per step: N=100000 patches, D=768, D_inner=384, 8 heads, 192 landmarks, "
+                                   "n_class=2, fp32 bag resident in HBM, 4 bags rotated", "sharding": "independent slides per GPU, no collective"},
+            "roofline": {"kernel": "whole forward (42 launches: gemm_f16x3 / tm_attn1 / tm_attn3 / gemm_f32 / stencils)", "bound": "mfma",
+                         "achieved": round(flops / t_slide / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(flops / t_slide / 1e12 / 157.3, 4), "traffic": None,
+                         "note": "algorithmic flops (SURVEY 8d, re-associated) = %.1f GFLOP/slide over the end-to-end forward time; peak = dense "
+                                 "fp32 MFMA (the parity arithmetic); compulsory input %.0f MB" % (flops / 1e9, nbytes / 1e6)},
+        }
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            x = bags[0].cpu()
+            t0 = time.perf_counter()
+            ref = TO.transmil_forward(x, sd)
+            el = time.perf_counter() - t0
+            with torch.no_grad():
+                err = (model(bags[0]).cpu() - ref["logits"]).abs().max().item()
+            result["cpu_baseline"] = {"value": round(1.0 / el, 3), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
+                                      "sample": "1 forward of the same N=100000 bag (%.1f s), torch-CPU oracle" % el}
+            result["max_abs_err_vs_oracle"] = err
+        if rank == 0:
+            print(json.dumps(result))
+        return
+    # ---- training step (configs[4]): one bag per rank per step, fused HIP forward/loss/backward, ONE flat-bucket all-reduce, AdamW
+    from acmil_amd import train as T
+    from oracle import ga_oracle as O
+    N, C = args.train_n, 7
+    conf = T.Struct(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, n_class=C, n_token=N_TOKEN, n_masked_patch=10,
+                    mask_drop=0.6, arch="ga", precision=args.precision, seed=1, D_feat=D_FEAT, D_inner=D_INNER)
+    torch.manual_seed(0)
+    model = T.build_model(conf).to(dev).train()
+    T.broadcast_parameters(model, world)
+    bucket = T.GradBucket(list(model.parameters()))
+    opt = torch.optim.AdamW(model.parameters(), lr=conf.lr, weight_decay=conf.wd)
+    bags = [O.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
+    labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
+
+    def step(i):
+        model.train_step(bags[i % 8], labels[i % 8])
+        bucket.sync_from_grads()
+        bucket.allreduce_mean(world)
+        opt.step()
+    dt = _timed(step, args, world, dev)
+    _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
+    flops = fwd_flops * (1.0 + 4.0 / 3.0)       # SURVEY 8(d): backward ~ 1.33 x forward (algorithmic, no recompute counted)
+    t_step = dt / args.steps
+    result = {
+        "metric": "slides/sec (ACMIL-ga training step: fwd + STKIM + losses + bwd + grad all-reduce + AdamW, N=%d D=512 C=7)" % N,
+        "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (split-f16 / split-bf16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
+        "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
+                               "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,
+                   "sharding": "slide-level data parallel: one bag per rank, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)"},
+        "roofline": {"kernel": "whole step (~45 launches)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
+                     "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
+                     "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4), "traffic": None,
+                     "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        xs = [b.float().cpu() for b in bags[:2]]
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+
+        def cpu_step(i):
+            out = O.acmil_ga_forward(xs[i % 2], sd, n_token=N_TOKEN, n_masked_patch=10, mask_drop=0.6,
+                                     uniforms=torch.rand(N_TOKEN, 10), training=True)
+            l0, l1, dl = O.acmil_losses(out["sub_preds"], out["slide_pred"], out["A_out"], labels[i % 2].cpu(), N_TOKEN)
+            for v in sd.values():
+                v.grad = None
+            (l0 + l1 + dl).backward()
+        try:
+            cpu_step(0)
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < 10.0:
+                cpu_step(n); n += 1
+            el = time.perf_counter() - t0
+            result["cpu_baseline"] = {"value": round(n / el, 2), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
+                                      "sample": "%d forward+backward steps on the same bags (%.1f s), torch-CPU oracle + autograd, no optimizer" % (n, el)}
+        except TypeError as e:   # oracle signature drift must not kill the bench line
+            result["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
+    if rank == 0:
+        print(json.dumps(result))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,9 +223,15 @@ def main():
                     help="slides per step: bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
                          "reference's strictly per-slide call pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "transmil", "train"],
+                    help="ga_eval = the BASELINE.json headline (default); transmil = configs[3] (N=100000, D=768 TransMIL eval "
+                         "forward); train = configs[4] (ACMIL training step, slide-level DP, gradient all-reduce)")
+    ap.add_argument("--train-n", type=int, default=10000, help="patches per bag of the train workload")
     ap.add_argument("--no-b1", action="store_true",
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
     args = ap.parse_args()
+    if args.workload != "ga_eval":
+        return other_workloads(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -210,6 +210,23 @@ int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const fl
                            const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2,
                            void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ACMIL_MHA eval forward (architecture/transformer.py:49-83 with MutiHeadAttention :107-185 and
+ * MutiHeadAttention_modify :187-236).  x [N,D] fp32; W1 [Di,D]; q [K,Di];
+ * branch: K x 10 pointers {q_proj.w [Di,Di], q_proj.b, k_proj.w, k_proj.b, v_proj.w, v_proj.b, out_proj.w, out_proj.b,
+ * layer_norm.w, layer_norm.b} of sub_attention[i]; bag: 6 pointers {v_proj.w, v_proj.b, out_proj.w, out_proj.b,
+ * layer_norm.w, layer_norm.b} of bag_attention; Wc/bc: K classifier heads [C,Di]/[C]; Ws/bs: Slide_classifier.
+ * Outputs: sub_preds [K,C], slide_pred [C], attns [8,K,N] (the reference's third return value, raw scaled scores).
+ * mode: ACMIL_MODE_F32 or ACMIL_MODE_F16X3 (arithmetic of the shared projection GEMM; the score GEMM is always exact).
+ * Eval only (the reference's train mode draws Dropout(0.1) masks).  8 heads, Di % 64 == 0, Di <= 512, K <= 5.
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_mha_workspace_bytes(int N, int D, int Di, int K, int C);
+
+int acmil_mha_forward(const float* x, int N, int D, int Di, int K, int C, const float* W1, const float* q,
+                      const float* const* branch, const float* const* bag, const float* const* Wc,
+                      const float* const* bc, const float* Ws, const float* bs, int mode, float* sub_preds,
+                      float* slide_pred, float* attns, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
