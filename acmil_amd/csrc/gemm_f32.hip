@@ -245,27 +245,53 @@ __device__ __forceinline__ void gx_store_split(char* S, int tid, const float (&r
 // at 16 * (tid / 128).  The 16 scalar loads are each coalesced across the lanes (consecutive rows); the thread then owns 16
 // consecutive k of one row = 32 B of the hi plane and 32 B of the lo plane, written with 2 + 2 ds_write_b128.
 template <bool IS_B, int BDT>
-__device__ __forceinline__ void gx_load_rows(const void* P, int ld, int r0, int k0, int R, int kend, int tid, float (&reg)[4][4]) {
-    const int r = r0 + (tid & 127);
-    const int kb = k0 + 16 * (tid >> 7);
-    const bool rok = r < R;
+__device__ __forceinline__ void gx_load_rows(const void* P, int ld, int r0, int k0, int R, int kend, int tid, bool vec, float (&reg)[4][4]) {
+    if constexpr (IS_B && BDT != ACMIL_DTYPE_F32) {
+        // 16-bit operand: thread -> row PAIR 2 * (tid % 64), 8 consecutive k at 8 * (tid / 64); one 4-byte load per k
+        // (256 B per wave-instruction) when the pair is aligned and interior.  reg index = 8 * (row in pair) + k.
+        const int r = r0 + 2 * (tid & 63);
+        const int kb = k0 + 8 * (tid >> 6);
+        const bool pair = vec && (r + 1 < R);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int k = kb + j;
-        float v = 0.0f;
-        if (rok && k < kend) {
-            const long long idx = (long long)k * ld + r;
-            if constexpr (IS_B) v = gm_ldb<BDT>(P, idx); else v = ((const float*)P)[idx];
+        for (int j = 0; j < 8; ++j) {
+            const int k = kb + j;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (k < kend) {
+                const long long idx = (long long)k * ld + r;
+                if (pair) {
+                    const uint32_t w = *(const uint32_t*)((const uint16_t*)P + idx);
+                    if constexpr (BDT == ACMIL_DTYPE_F16) {
+                        v0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); v1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16));
+                    } else { v0 = __builtin_bit_cast(float, w << 16); v1 = __builtin_bit_cast(float, w & 0xffff0000u); }
+                } else {
+                    if (r < R) v0 = gm_ldb<BDT>(P, idx);
+                    if (r + 1 < R) v1 = gm_ldb<BDT>(P, idx + 1);
+                }
+            }
+            reg[j >> 2][j & 3] = v0;
+            reg[2 + (j >> 2)][j & 3] = v1;
         }
-        reg[j >> 2][j & 3] = v;
+    } else {
+        const int r = r0 + (tid & 127);
+        const int kb = k0 + 16 * (tid >> 7);
+        const bool rok = r < R;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = kb + j;
+            float v = 0.0f;
+            if (rok && k < kend) {
+                const long long idx = (long long)k * ld + r;
+                if constexpr (IS_B) v = gm_ldb<BDT>(P, idx); else v = ((const float*)P)[idx];
+            }
+            reg[j >> 2][j & 3] = v;
+        }
     }
 }
 
-template <bool BF>
+template <bool BF, bool PAIRS>
 __device__ __forceinline__ void gx_store_split_rows(char* S, int tid, const float (&reg)[4][4]) {
     typedef typename GxT<BF>::T T;
     typedef typename GxT<BF>::V8 V8;
-    const int r = tid & 127, kb = 16 * (tid >> 7);
     V8 h[2], l[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -274,9 +300,15 @@ __device__ __forceinline__ void gx_store_split_rows(char* S, int tid, const floa
         h[j >> 3][j & 7] = hv;
         l[j >> 3][j & 7] = (T)(v - (float)hv);
     }
-    char* d = S + r * GX_LDB + kb * 2;
-    *(V8*)(d) = h[0]; *(V8*)(d + 16) = h[1];
-    *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + 16) = l[1];
+    if constexpr (PAIRS) {       // registers 0-7: row r, k 0..7; 8-15: row r + 1 (see gx_load_rows, 16-bit operand)
+        char* d = S + 2 * (tid & 63) * GX_LDB + 8 * (tid >> 6) * 2;
+        *(V8*)(d) = h[0]; *(V8*)(d + GX_LDB) = h[1];
+        *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + GX_LDB) = l[1];
+    } else {
+        char* d = S + (tid & 127) * GX_LDB + 16 * (tid >> 7) * 2;
+        *(V8*)(d) = h[0]; *(V8*)(d + 16) = h[1];
+        *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + 16) = l[1];
+    }
 }
 
 template <int BDT, bool BF>
@@ -303,22 +335,23 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     const bool va = ((g.lda & 3) == 0) && ((((size_t)A) & 15) == 0) && ((kbeg & 3) == 0);
     const bool vb = ((g.ldb & 3) == 0) && ((((size_t)B) & (BDT == ACMIL_DTYPE_F32 ? 15 : 7)) == 0) && ((kbeg & 3) == 0);
+    const bool vb2 = ((g.ldb & 1) == 0) && ((((size_t)B) & 3) == 0) && ((n0 & 1) == 0);   // aligned row pairs of a 16-bit [K][N] operand
     float ra[4][4], rb[4][4];
     auto load_a = [&](int k0) {
         if (a_ck) gm_load_tile<false, ACMIL_DTYPE_F32, 4>(A, g.lda, true, m0, k0, g.M, g.K, kend, tid, va, ra);
-        else gx_load_rows<false, ACMIL_DTYPE_F32>(A, g.lda, m0, k0, g.M, kend, tid, ra);
+        else gx_load_rows<false, ACMIL_DTYPE_F32>(A, g.lda, m0, k0, g.M, kend, tid, false, ra);
     };
     auto load_b = [&](int k0) {
         if (b_ck) gm_load_tile<true, BDT, 4>(B, g.ldb, true, n0, k0, g.N, g.K, kend, tid, vb, rb);
-        else gx_load_rows<true, BDT>(B, g.ldb, n0, k0, g.N, kend, tid, rb);
+        else gx_load_rows<true, BDT>(B, g.ldb, n0, k0, g.N, kend, tid, vb2, rb);
     };
     load_a(kbeg); load_b(kbeg);
     const char* ap = As + (64 * wm + i31) * GX_LDB + hi * 16;
     const char* bp = Bs + (64 * wn + i31) * GX_LDB + hi * 16;
     for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
         __syncthreads();   // previous tile fully consumed
-        if (a_ck) gx_store_split<BF>(As, tid, ra); else gx_store_split_rows<BF>(As, tid, ra);
-        if (b_ck) gx_store_split<BF>(Bs, tid, rb); else gx_store_split_rows<BF>(Bs, tid, rb);
+        if (a_ck) gx_store_split<BF>(As, tid, ra); else gx_store_split_rows<BF, false>(As, tid, ra);
+        if (b_ck) gx_store_split<BF>(Bs, tid, rb); else gx_store_split_rows<BF, (BDT != ACMIL_DTYPE_F32)>(Bs, tid, rb);
         __syncthreads();
         if (k0 + GM_BK < kend) { load_a(k0 + GM_BK); load_b(k0 + GM_BK); }
 #pragma unroll
