@@ -165,13 +165,22 @@ int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& 
                            (float*)((char*)workspace + poff), st);
 }
 
-static int ga_pick_waves(int maxN) {
-    // tile geometry: 8-wave (256-patch) workgroups stream the weights once per 256 patches; small bags use
-    // 4-wave (128-patch) workgroups, two per CU, to spread over more CUs.  ACMIL_GA_WAVES=4|8 overrides (tuning).
-    int w = (maxN >= 32768) ? 8 : 4;
+static int ga_pick_waves(int maxN, long long total_patches = 0) {
+    // tile geometry: 8-wave (256-patch) workgroups stream the weights once per 256 patches and give the lowest latency for
+    // one large bag; 4-wave (128-patch) workgroups, two per CU, spread small bags over more CUs and -- measured, 8 x 50 000
+    // patches per launch: 524 vs 548 us -- balance better once a launch holds several rounds of tiles (>= 1024 of them).
+    // ACMIL_GA_WAVES=4|8 overrides (tuning).
+    int w = (maxN >= 32768 && total_patches < 1024LL * 128) ? 8 : 4;
     const char* e = getenv("ACMIL_GA_WAVES");
     if (e && (atoi(e) == 4 || atoi(e) == 8)) w = atoi(e);
     return w;
+}
+
+// Two 4-wave workgroups share a CU and start in lockstep, so their MFMA-idle phases (relu/convert, scores, pooling, combine)
+// coincide for the whole launch; delaying the second slot once by about half a tile keeps them out of phase afterwards.
+static int ga_pick_stagger() {
+    const char* e = getenv("ACMIL_GA_STAGGER");
+    return e ? atoi(e) : 0;
 }
 
 extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D, int Di, int K, int C, int mode) {
@@ -200,7 +209,10 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         if (!xs[b]) return ACMIL_ERR_NULL;
         if (Ns[b] > maxN) maxN = Ns[b];
     }
-    a.waves = ga_pick_waves(maxN);
+    long long total_patches = 0;
+    for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
+    a.waves = ga_pick_waves(maxN, total_patches);
+    a.stagger = ga_pick_stagger();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
         a.xs[b] = b < nbags ? xs[b] : nullptr;
@@ -274,6 +286,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
     a.waves = ga_pick_waves(N);
+    a.stagger = ga_pick_stagger();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);

@@ -44,6 +44,7 @@ struct GaFwdArgs {
     float* part;     // workspace partials [total tiles][K][2+Di]
     float* h_save;   // [N,Di] or null (single-bag score pass only)
     int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
+    int stagger;     // 4-wave mode: start delay (units of s_sleep 127 ~ 8k cycles) of the second workgroup slot of every CU
 #ifdef GA_TRACE
     unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0
 #endif
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     const int m0 = ((int)blockIdx.x - a.tile_start[bag]) * G::ROWS + wave * 32;
     const int row = m0 + i31;
     const bool valid = row < N;
+    if (WAVES == 4 && a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);   // de-phase the two co-resident workgroups (see ga_pick_stagger)
 
     const char* wstream = a.packed + L.g1_off;   // GEMM1 rows then GEMM2 rows, contiguous: step u starts at u * WROWS rows
     const int S1 = D / 16;                 // GEMM1 steps

@@ -340,7 +340,8 @@ def main():
     mfma_peak = 2500.0 if args.precision == "f16x3" else 157.3  # TFLOP/s dense: f16 MFMA / fp32 MFMA
     executed = flops * (3.0 if args.precision == "f16x3" else 1.0)
     roofline = {
-        "kernel": "ga_fwd_kernel<ND=8,KP=5,%s,x=f32,waves=8>, %d bags per launch" % (args.precision, B),
+        "kernel": "ga_fwd_kernel<ND=8,KP=5,%s,x=f32,waves=%d>, %d bags per launch" % (
+            args.precision, 4 if (B * N_PATCH >= 1024 * 128 or N_PATCH < 32768) else 8, B),
         "bound": "mfma",
         "achieved": round(flops / t_kernel / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s",
         "frac": round(flops / t_kernel / 1e12 / mfma_peak, 4),
