@@ -7,7 +7,7 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json metric): ACMIL-ga eval forward, N=50 000 patches, D=512, D_inner=256, K=5 branches,
 C=2 classes, fp32 bag resident in HBM, weights = torch default nn.Linear init (random), synthetic randn bags.
-A "step" is one pass of the hot path over one batch of --batch slides (default 8; every bag is still an independent
+A "step" is one pass of the hot path over one batch of --batch slides (default 16 = the most one launch takes; every bag is still an independent
 B=1 problem exactly as in the reference, the batch only shares one launch: acmil_ga_forward_batch): weight stream
 already packed, fused forward + merge + heads through the C ABI, 16 distinct bags rotated so neither L2 nor the
 256 MB Infinity Cache holds the working set.  The strictly per-slide (B=1 call) latency is reported next to it.  Slides shard across GPUs with no data-path collective
@@ -219,7 +219,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
                     help="arithmetic of the two projection GEMMs; both are inside the 1e-4 fp32 parity bound")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="slides per step: bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
                          "reference's strictly per-slide call pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
