@@ -35,13 +35,14 @@ struct GaBwdHeadArgs {
     int K, C, Di;
 };
 
-// one workgroup; thread = feature di (looped)
+// grid K + 1: workgroup k < K = branch k, workgroup K = bag head; thread = feature di (looped)
 __global__ __launch_bounds__(256) void ga_bwd_heads_kernel(GaBwdHeadArgs a) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, C = a.C, Di = a.Di;
     const float invK = 1.0f / (float)K;
-    for (int k = 0; k < K; ++k) {
+    if ((int)blockIdx.x < K) {
+        const int k = blockIdx.x;
         float cpart = 0.0f;
         for (int di = tid; di < Di; di += 256) {
             float s = 0.0f;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void ga_bwd_heads_kernel(GaBwdHeadArgs a) {
         __syncthreads();
         if (tid == 0) a.ck[k] = (red[0] + red[1]) + (red[2] + red[3]);
         if (tid < C) a.dbc[k][tid] = a.d_sub[k * C + tid];
+        return;
     }
     if (a.Ws) {
         for (int di = tid; di < Di; di += 256) {
@@ -275,7 +277,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
         ha.Wc[k] = k < K ? Wc[k] : nullptr; ha.dWc[k] = k < K ? dWc[k] : nullptr; ha.dbc[k] = k < K ? dbc[k] : nullptr;
         if (k < K && (!ha.Wc[k] || !ha.dWc[k] || !ha.dbc[k])) return ACMIL_ERR_NULL;
     }
-    hipLaunchKernelGGL(ga_bwd_heads_kernel, dim3(1), dim3(256), 0, st, ha);
+    hipLaunchKernelGGL(ga_bwd_heads_kernel, dim3(K + 1), dim3(256), 0, st, ha);
     // 2 stats
     hipLaunchKernelGGL(ga_bwd_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;

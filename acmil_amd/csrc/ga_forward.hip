@@ -71,9 +71,10 @@ __global__ __launch_bounds__(1024) void ga_merge_kernel(const float* __restrict_
 // heads: sub_preds[k] = Wc[k] afeat[k] + bc[k]  (transformer.py:325-327, network.py:14-19)
 //        bag_feat = mean_k afeat[k]             (== mm(softmax(A).mean(0), h), transformer.py:328-329)
 //        slide_pred = Ws bag_feat + bs          (transformer.py:330)
-// one workgroup; each wave takes outputs o = wave, wave+4, ...; lanes stride the Di-long dot product.
+// one workgroup of 16 waves per bag; each wave takes outputs o = wave, wave+16, ...; lanes stride the Di-long dot product
+// (K*C + C outputs: 4 waves made this a 25 us serial chain of dependent global loads at C = 7).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ga_heads_kernel(const float* __restrict__ afeat, const char* __restrict__ packed,
+__global__ __launch_bounds__(1024) void ga_heads_kernel(const float* __restrict__ afeat, const char* __restrict__ packed,
                                                        GaLayout L, int has_bag_head, float* __restrict__ sub_preds,
                                                        float* __restrict__ slide_pred, float* __restrict__ bag_feat) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256) void ga_heads_kernel(const float* __restrict__
     if (sub_preds) sub_preds += (size_t)bag * K * C;
     if (slide_pred) slide_pred += (size_t)bag * C;
     if (bag_feat) bag_feat += (size_t)bag * Di;
-    for (int e = tid; e < K * Di; e += 256) af[e] = afeat[e];
+    for (int e = tid; e < K * Di; e += 1024) af[e] = afeat[e];
     __syncthreads();
-    for (int di = tid; di < Di; di += 256) {
+    for (int di = tid; di < Di; di += 1024) {
         float s = 0.0f;
         for (int k = 0; k < K; ++k) s += af[k * Di + di];
         s = s / (float)K;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void ga_heads_kernel(const float* __restrict__
     const float* ws = (const float*)(packed + L.ws_off);
     const float* bs = (const float*)(packed + L.bs_off);
     const int nout = K * C + (has_bag_head ? C : 0);
-    for (int o = wave; o < nout; o += 4) {
+    for (int o = wave; o < nout; o += 16) {
         const float* w; const float* v; float b; float* dst;
         if (o < K * C) { w = wc + (size_t)o * Di; v = af + (size_t)(o / C) * Di; b = bc[o]; dst = sub_preds ? sub_preds + o : nullptr; }
         else { const int c = o - K * C; w = ws + (size_t)c * Di; v = bf; b = bs[c]; dst = slide_pred ? slide_pred + c : nullptr; }
@@ -150,7 +151,7 @@ static int ga_finish_batch(const float* part, const int* tile_start, int nbags, 
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     if (sub_preds || slide_pred || bag_feat) {
         const size_t lds = ((size_t)K * Di + Di) * sizeof(float);
-        hipLaunchKernelGGL(ga_heads_kernel, dim3(nbags), dim3(256), lds, st, af, (const char*)packed, L, has_bag_head,
+        hipLaunchKernelGGL(ga_heads_kernel, dim3(nbags), dim3(1024), lds, st, af, (const char*)packed, L, has_bag_head,
                            sub_preds, slide_pred, bag_feat);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }

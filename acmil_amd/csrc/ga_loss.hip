@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void gl_scalar_kernel(const float* __restrict_
                                                        float* __restrict__ d_sub, float* __restrict__ d_slide,
                                                        float* __restrict__ coef) {
     __shared__ float S[KP * KP];
+    __shared__ float lsub[ACMIL_MAX_TOKENS * ACMIL_MAX_CLASSES], lslide[ACMIL_MAX_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // logits -> LDS with one parallel load (thread 0 below would otherwise chain ~40 dependent global loads)
+    if (tid < K * C) lsub[tid] = sub[tid];
+    if (slide && tid < C) lslide[tid] = slide[tid];
     // wave w reduces Gram entries w, w+4, ...: lanes stride the block partials, then a fixed shuffle tree
     for (int e = wave; e < KP * KP; e += 4) {
         float s = 0.0f;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void gl_scalar_kernel(const float* __restrict_
     // cross entropies
     float loss0 = 0.0f;
     for (int k = 0; k < K; ++k) {
-        const float* r = sub + k * C;
+        const float* r = lsub + k * C;
         float mx = r[0];
         for (int c = 1; c < C; ++c) mx = fmaxf(mx, r[c]);
         float se = 0.0f;
@@ -111,13 +115,13 @@ __global__ __launch_bounds__(256) void gl_scalar_kernel(const float* __restrict_
     loss0 = (K > 1) ? loss0 / (float)K : 0.0f;
     float loss1 = 0.0f;
     if (slide) {
-        float mx = slide[0];
-        for (int c = 1; c < C; ++c) mx = fmaxf(mx, slide[c]);
+        float mx = lslide[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, lslide[c]);
         float se = 0.0f;
-        for (int c = 0; c < C; ++c) se += expf(slide[c] - mx);
+        for (int c = 0; c < C; ++c) se += expf(lslide[c] - mx);
         const float lse = mx + logf(se);
-        loss1 = lse - slide[y];
-        for (int c = 0; c < C; ++c) d_slide[c] = expf(slide[c] - lse) - (c == y ? 1.0f : 0.0f);
+        loss1 = lse - lslide[y];
+        for (int c = 0; c < C; ++c) d_slide[c] = expf(lslide[c] - lse) - (c == y ? 1.0f : 0.0f);
     }
     // diversity loss
     float diff = 0.0f;

@@ -160,7 +160,7 @@ def other_workloads(args):
     model = T.build_model(conf).to(dev).train()
     T.broadcast_parameters(model, world)
     bucket = T.GradBucket(list(model.parameters()))
-    opt = torch.optim.AdamW(model.parameters(), lr=conf.lr, weight_decay=conf.wd)
+    opt = torch.optim.AdamW(model.parameters(), lr=conf.lr, weight_decay=conf.wd, fused=True)   # one multi-tensor kernel
     bags = [O.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
 
