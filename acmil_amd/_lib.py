@@ -44,6 +44,11 @@ SIGNATURES = {
                                _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
     "acmil_mha_workspace_bytes": (_sz, [_i] * 5),
     "acmil_mha_forward": (_i, [_vp] + [_i] * 5 + [_vp, _vp] + [C.POINTER(_vp)] * 4 + [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "acmil_gated_scores_workspace_bytes": (_sz, [_i] * 4),
+    "acmil_gated_scores": (_i, [_vp] + [_i] * 4 + [_vp] * 6 + [_i, _vp, _vp, _vp]),
+    "acmil_attn_pool_workspace_bytes": (_sz, [_i] * 3),
+    "acmil_attn_pool": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "acmil_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),

@@ -1,0 +1,50 @@
+"""DTFD-style attention blocks on an already projected bag, same names / ctor signatures / state_dict keys as the
+reference's `architecture/Attention.py` (Attention_Gated :29-57, Attention_with_Classifier :60-70).
+Arithmetic: acmil_gated_scores / acmil_attn_pool / acmil_softmax_rows / acmil_gemm (csrc/attn_generic.hip).  Eval forward
+only (no backward is built for these modules): a call that would need gradients raises."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .network import Classifier_1fc
+
+
+def _no_grad_path(name, *params):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise NotImplementedError("acmil_amd: %s has an eval forward only; wrap the call in torch.no_grad()" % name)
+
+
+class Attention_Gated(nn.Module):
+    def __init__(self, L=512, D=128, K=1, *, precision="f16x3"):
+        super().__init__()
+        self.L, self.D, self.K = L, D, K
+        self.attention_V = nn.Sequential(nn.Linear(L, D), nn.Tanh())
+        self.attention_U = nn.Sequential(nn.Linear(L, D), nn.Sigmoid())
+        self.attention_weights = nn.Linear(D, K)
+        self.precision = precision
+
+    def scores(self, x):
+        v, u, w = self.attention_V[0], self.attention_U[0], self.attention_weights
+        _no_grad_path("Attention_Gated", v.weight, u.weight, w.weight)
+        if not x.is_cuda:
+            raise RuntimeError("acmil_amd: Attention_Gated runs on an MI355X only (no CPU fallback)")
+        return ops.gated_scores(x.float().contiguous(), v.weight, v.bias, u.weight, u.bias, w.weight, w.bias, self.precision)
+
+    def forward(self, x, isNorm=True):   # x: N x L -> K x N   (Attention.py:47-57)
+        A = self.scores(x)
+        return ops.softmax_rows(A) if isNorm else A
+
+
+class Attention_with_Classifier(nn.Module):
+    def __init__(self, L=512, D=128, K=1, num_cls=2, droprate=0, *, precision="f16x3"):
+        super().__init__()
+        if droprate != 0:
+            raise NotImplementedError("acmil_amd: classifier dropout is a train-time feature; the eval forward has none")
+        self.attention = Attention_Gated(L, D, K, precision=precision)
+        self.classifier = Classifier_1fc(L, num_cls, droprate)
+
+    def forward(self, x):   # x: N x L -> K x num_cls   (Attention.py:66-70)
+        _no_grad_path("Attention_with_Classifier", self.classifier.fc.weight)
+        x = x.float().contiguous()
+        afeat = ops.attn_pool(x, self.attention.scores(x))          # softmax over N fused into the pooling pass
+        return ops.gemm(afeat, self.classifier.fc.weight.detach(), trans_b=True, bias=self.classifier.fc.bias.detach())

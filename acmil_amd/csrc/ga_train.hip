@@ -231,3 +231,33 @@ extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     return ga_finish(part, tiles, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head, workspace, st);
 }
+
+// Attention pooling without heads: afeat [K, Di] = softmax_N(A) h for raw scores A [K, N] (not modified) -- the
+// `F.softmax(A, dim=1); torch.mm(A, h)` pair of the other gated-attention consumers (architecture/Attention.py:67-68,
+// ibmil.py:73-74, clam.py:163-190).  Same tile partials + fixed-order merge as acmil_ga_pool.
+extern "C" size_t acmil_attn_pool_workspace_bytes(int N, int Di, int K) {
+    if (N <= 0 || Di <= 0 || K <= 0) return 0;
+    return (((size_t)ga_pool_tiles(N) * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255) + (size_t)K * Di * sizeof(float) + 256;
+}
+
+extern "C" int acmil_attn_pool(const float* h, const float* A, int N, int Di, int K, float* afeat, void* workspace, void* stream) {
+    if (N <= 0 || Di <= 0 || K <= 0) return ACMIL_ERR_SHAPE;
+    if (Di % 64 != 0 || Di > 1024 || K > 8) return ACMIL_ERR_UNSUPPORTED;
+    if (!h || !A || !afeat || !workspace) return ACMIL_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = ga_pool_tiles(N);
+    float* part = (float*)workspace;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
+    if (Di / 4 > 256) return ACMIL_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
+    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
+    void (*kern)(const float*, const float*, int, int, int, float*) =
+        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, h, A, N, K, Di, part);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    GaLayout L; L.K = K; L.Di = Di; L.C = 1; L.D = 0; L.ND = Di / 32; L.mode = 0;
+    return ga_finish(part, tiles, nullptr, L, nullptr, nullptr, afeat, nullptr, 0, workspace, st);
+}

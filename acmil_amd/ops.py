@@ -373,3 +373,51 @@ def mha_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_token: int, n_cl
                                slide.data_ptr(), attns.data_ptr(), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_mha_forward")
     return {"sub_preds": sub, "slide_pred": slide, "attns": attns}
+
+
+def gated_scores(h: torch.Tensor, Wv, bv, Wu, bu, Ww, bw, precision="f16x3") -> torch.Tensor:
+    """acmil_gated_scores: raw gated-attention scores A [K,N] of an already projected bag h [N,L] (any attention width Da)."""
+    lib = _lib.load()
+    ts = [h, Wv, bv, Wu, bu, Ww, bw]
+    _need_cuda(*ts)
+    ts = [t.detach() for t in ts]
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("acmil_amd.gated_scores: operands must be contiguous fp32")
+    h, Wv, bv, Wu, bu, Ww, bw = ts
+    N, L = h.shape
+    Da, K = Wv.shape[0], Ww.shape[0]
+    A = torch.empty(K, N, dtype=torch.float32, device=h.device)
+    ws = torch.empty(lib.acmil_gated_scores_workspace_bytes(N, L, Da, K), dtype=torch.uint8, device=h.device)
+    rc = lib.acmil_gated_scores(h.data_ptr(), N, L, Da, K, Wv.data_ptr(), bv.data_ptr(), Wu.data_ptr(), bu.data_ptr(), Ww.data_ptr(),
+                                bw.data_ptr(), mode_id(precision), A.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_gated_scores")
+    return A
+
+
+def attn_pool(h: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
+    """acmil_attn_pool: softmax over N of the raw scores A [K,N], then the weighted sum afeat [K,Di] = P h."""
+    lib = _lib.load()
+    _need_cuda(h, A)
+    h, A = h.detach(), A.detach()
+    if h.dtype != torch.float32 or A.dtype != torch.float32 or not h.is_contiguous() or not A.is_contiguous():
+        raise RuntimeError("acmil_amd.attn_pool: h and A must be contiguous fp32")
+    N, Di = h.shape
+    K = A.shape[0]
+    nbytes = lib.acmil_attn_pool_workspace_bytes(N, Di, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    af = torch.empty(K, Di, dtype=torch.float32, device=h.device)
+    _lib.check(lib.acmil_attn_pool(h.data_ptr(), A.data_ptr(), N, Di, K, af.data_ptr(), ws.data_ptr(), _stream()), "acmil_attn_pool")
+    return af
+
+
+def softmax_rows(S: torch.Tensor) -> torch.Tensor:
+    """acmil_softmax_rows: softmax over the last axis of a 2-D fp32 tensor (long rows: the attention maps [K,N])."""
+    lib = _lib.load()
+    _need_cuda(S)
+    S = S.detach()
+    if S.dim() != 2 or S.dtype != torch.float32 or not S.is_contiguous():
+        raise RuntimeError("acmil_amd.softmax_rows: S must be contiguous fp32 [rows, cols]")
+    P = torch.empty_like(S)
+    _lib.check(lib.acmil_softmax_rows(S.data_ptr(), P.data_ptr(), S.shape[0], S.shape[1], _stream()), "acmil_softmax_rows")
+    return P

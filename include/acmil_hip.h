@@ -227,6 +227,26 @@ int acmil_mha_forward(const float* x, int N, int D, int Di, int K, int C, const 
                       const float* const* bc, const float* Ws, const float* bs, int mode, float* sub_preds,
                       float* slide_pred, float* attns, void* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Gated attention on an already projected bag (the other gated-attention consumers).
+ *   acmil_gated_scores: A [K,N] = ((tanh(h Wv^T + bv) * sigmoid(h Wu^T + bu)) Ww^T + bw)^T for h [N,L] fp32, Wv/Wu [Da,L],
+ *     Ww [K,Da]; any Da, K <= 5.  Replaces Attention_Gated.forward (architecture/Attention.py:47-57, ibmil.py:27-35) and
+ *     Attn_Net_Gated.forward (clam.py:62-67).  mode: ACMIL_MODE_F32 / ACMIL_MODE_F16X3 (GEMM arithmetic).
+ *   acmil_attn_pool: afeat [K,Di] = softmax_N(A) h  (Attention.py:67-68, ibmil.py:73-74, clam.py:163,190); A is not modified.
+ *   acmil_softmax_rows: P = softmax over each row of S [rows, cols] (the normalised attention map these modules return).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_gated_scores_workspace_bytes(int N, int L, int Da, int K);
+
+int acmil_gated_scores(const float* h, int N, int L, int Da, int K, const float* Wv, const float* bv, const float* Wu,
+                       const float* bu, const float* Ww, const float* bw, int mode, float* A, void* workspace,
+                       void* stream);
+
+size_t acmil_attn_pool_workspace_bytes(int N, int Di, int K);
+
+int acmil_attn_pool(const float* h, const float* A, int N, int Di, int K, float* afeat, void* workspace, void* stream);
+
+int acmil_softmax_rows(const float* S, float* P, int rows, int cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
