@@ -288,6 +288,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
         GA_STAMP(4 * s + 1);
         __builtin_amdgcn_s_barrier();
         GA_STAMP(4 * s + 2);
+#if defined(GA_EXP) && (GA_EXP & 4)
+        if constexpr (G::ALT) { if ((wave >> 2) == (s & 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#endif
+#if defined(GA_EXP) && (GA_EXP & 8)
+        if constexpr (G::ALT) { if ((wave >> 2) != (s & 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#endif
+#if defined(GA_EXP) && (GA_EXP & 16)
+        if constexpr (G::ALT) { if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(3); }   // the younger wave of every SIMD pair always high
+#endif
         if constexpr (G::ALT) issue_step(s + G::PD);   // issuing wave: DMA first, while its partner owns the matrix pipe
         // (non-ALT: the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
         //  VALU, M0 writes, ~100 cycles per instruction -- then overlaps matrix-core work instead of delaying it)

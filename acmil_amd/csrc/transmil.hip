@@ -41,17 +41,22 @@ __global__ __launch_bounds__(256) void tm_layernorm_kernel(const float* __restri
     float* o = out + r * dim;
     if (r < zero_rows) { for (int c = lane; c < dim; c += 64) o[c] = 0.0f; return; }
     const float* x = in + r * dim;
+    // the row is read ONCE into registers (dim <= 1024: 16 values per lane), statistics and output come from there
+    float v[16];
     float s = 0.0f;
-    for (int c = lane; c < dim; c += 64) s += x[c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; v[i] = c < dim ? x[c] : 0.0f; s += v[i]; }
 #pragma unroll
     for (int o2 = 32; o2 >= 1; o2 >>= 1) s += __shfl_xor(s, o2);
     const float mean = s / dim;
-    float v = 0.0f;
-    for (int c = lane; c < dim; c += 64) { const float d = x[c] - mean; v = fmaf(d, d, v); }
+    float q = 0.0f;
 #pragma unroll
-    for (int o2 = 32; o2 >= 1; o2 >>= 1) v += __shfl_xor(v, o2);
-    const float rstd = 1.0f / sqrtf(v / dim + 1e-5f);
-    for (int c = lane; c < dim; c += 64) o[c] = (x[c] - mean) * rstd * gamma[c] + beta[c];
+    for (int i = 0; i < 16; ++i) { const float d = (lane + 64 * i < dim) ? v[i] - mean : 0.0f; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) q += __shfl_xor(q, o2);
+    const float rstd = 1.0f / sqrtf(q / dim + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < dim) o[c] = (v[i] - mean) * rstd * gamma[c] + beta[c]; }
 }
 
 // token assembly after fc1: cls row, wrap-around rows (repeat the first tokens), zero front padding
@@ -65,18 +70,35 @@ __global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int ns
     }
 }
 
-// landmark means of q and k: QL/KL [h][m][d] = mean over l consecutive rows of the q / k column slices of QKV [npad][3Di]
-__global__ __launch_bounds__(256) void tm_landmark_kernel(const float* __restrict__ qkv, int l, int m, int Di, float* __restrict__ QL,
-                                                         float* __restrict__ KL) {
-    const int j = blockIdx.x;           // landmark
+// landmark means of q and k: QL/KL [h][m][d] = mean over l consecutive rows of the q / k column slices of QKV [npad][3Di].
+// grid (m, 2): workgroup = (landmark j, q or k half); thread = (float4 column, row phase): `phases` threads share a column and
+// take rows phase, phase + phases, ... (float4 loads, 4 in flight), then a fixed-order LDS reduce over the phases.
+__global__ __launch_bounds__(1024) void tm_landmark_kernel(const float* __restrict__ qkv, int l, int m, int Di, int phases,
+                                                          float* __restrict__ QL, float* __restrict__ KL) {
+    extern __shared__ __attribute__((aligned(16))) float lm_red[];   // [phases][Di]
+    const int j = blockIdx.x, half = blockIdx.y;
+    const int c4n = Di / 4;
+    const int c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n;
     const int d = Di / TM_HEADS;
+    if (ph < phases) {
+        const f32x4* src = (const f32x4*)(qkv + (size_t)j * l * 3 * Di + (size_t)half * Di) + c4;
+        const size_t rs = (size_t)3 * Di / 4;      // row stride in float4
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        int t = ph;
+        for (; t + 3 * phases < l; t += 4 * phases) {
+            const f32x4 v0 = src[(size_t)t * rs], v1 = src[(size_t)(t + phases) * rs], v2 = src[(size_t)(t + 2 * phases) * rs],
+                        v3 = src[(size_t)(t + 3 * phases) * rs];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; t < l; t += phases) s += src[(size_t)t * rs];
+        *(f32x4*)(lm_red + (size_t)ph * Di + 4 * c4) = s;
+    }
+    __syncthreads();
     const float inv = 1.0f / (float)l;
-    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < 2 * Di; c += gridDim.y * blockDim.x) {   // c < Di: q column, else k column
-        const float* src = qkv + (size_t)j * l * 3 * Di + c;
+    for (int c = threadIdx.x; c < Di; c += blockDim.x) {
         float s = 0.0f;
-        for (int t = 0; t < l; ++t) s += src[(size_t)t * 3 * Di];
-        const int cc = c % Di, h = cc / d, dd = cc % d;
-        (c < Di ? QL : KL)[((size_t)h * m + j) * d + dd] = s * inv;
+        for (int p2 = 0; p2 < phases; ++p2) s += lm_red[(size_t)p2 * Di + c];
+        (half ? KL : QL)[((size_t)(c / d) * m + j) * d + c % d] = s * inv;
     }
 }
 
@@ -157,13 +179,18 @@ __global__ void tm_pinv_init_kernel(const float* __restrict__ x, int m, const un
 #define TM_CONV_ROWS 64
 __global__ __launch_bounds__(256) void tm_seqconv_kernel(const float* __restrict__ qkv, float* __restrict__ out, int npad, int Di,
                                                         const float* __restrict__ w) {
-    __shared__ float tile[(TM_CONV_ROWS + TM_RES - 1) * 64];
+    __shared__ __attribute__((aligned(16))) float tile[(TM_CONV_ROWS + TM_RES - 1) * 64];
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * TM_CONV_ROWS;
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int d = Di / TM_HEADS;
-    for (int rr = rg; rr < TM_CONV_ROWS + TM_RES - 1; rr += 4) {
+    // halo tile -> LDS with float4 loads over the channels (16 lanes per row: one wave instruction = 4 rows x 256 B)
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < (TM_CONV_ROWS + TM_RES - 1) * 16; idx += 256) {
+        const int rr = idx >> 4, c4 = idx & 15;
         const int r = r0 + rr - TM_RES / 2;
-        tile[rr * 64 + cl] = (r >= 0 && r < npad && c0 + cl < Di) ? qkv[(size_t)r * 3 * Di + 2 * Di + c0 + cl] : 0.0f;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r >= 0 && r < npad && c0 + 4 * c4 < Di) v = *(const f32x4*)(qkv + (size_t)r * 3 * Di + 2 * Di + c0 + 4 * c4);
+        *(f32x4*)(tile + rr * 64 + 4 * c4) = v;
     }
     __syncthreads();
     if (c0 + cl >= Di) return;
@@ -171,13 +198,23 @@ __global__ __launch_bounds__(256) void tm_seqconv_kernel(const float* __restrict
     float wr[TM_RES];
 #pragma unroll
     for (int t = 0; t < TM_RES; ++t) wr[t] = wh[t];
-    for (int rr = rg; rr < TM_CONV_ROWS; rr += 4) {
-        const int r = r0 + rr;
-        if (r >= npad) break;
-        float s = 0.0f;
+    // register blocking: 4 consecutive rows per pass share a 36-value window (36 instead of 132 LDS reads per 132 FMAs);
+    // wave rg takes rows 16 rg .. 16 rg + 15
+#pragma unroll 1
+    for (int blk = 0; blk < TM_CONV_ROWS / 16; ++blk) {
+        const int rr0 = 16 * rg + 4 * blk;
+        if (r0 + rr0 >= npad) break;
+        float in[TM_RES + 3];
 #pragma unroll
-        for (int t = 0; t < TM_RES; ++t) s = fmaf(wr[t], tile[(rr + t) * 64 + cl], s);
-        out[(size_t)r * Di + c0 + cl] += s;
+        for (int i = 0; i < TM_RES + 3; ++i) in[i] = tile[(rr0 + i) * 64 + cl];
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < TM_RES; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wr[t], in[j + t], acc[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (r0 + rr0 + j < npad) out[(size_t)(r0 + rr0 + j) * Di + c0 + cl] += acc[j];
     }
 }
 
@@ -200,18 +237,28 @@ __global__ void tm_ppeg_pack_kernel(const float* w7, const float* b7, const floa
 // depth-wise 7x7 on the [side x side] token grid, channels-last (token p = y*side + x lives at row p of `in`).
 // One workgroup = 64 channels x an 8 x 8 pixel tile: the 14 x 14 halo tile is staged in LDS (lane = channel, so
 // every LDS access is conflict-free and every global row read is a coalesced 256-B segment); thread (c, g)
-// computes pixels g, g+4, ... of the tile with its 49 taps in registers.
+// computes rows 2g, 2g+1 of the tile with its 49 taps in registers.
 #define TM_PT 8
 __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
                                                      const float* __restrict__ weff, const float* __restrict__ beff) {
-    __shared__ float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
+    __shared__ __attribute__((aligned(16))) float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
     const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int tiles_x = (side + TM_PT - 1) / TM_PT;
     const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
-    for (int e = grp; e < (TM_PT + 6) * (TM_PT + 6); e += 4) {
-        const int yy = ty0 + e / (TM_PT + 6) - 3, xx = tx0 + e % (TM_PT + 6) - 3;
-        tile[e * 64 + cl] = (c < C && yy >= 0 && yy < side && xx >= 0 && xx < side) ? in[((size_t)yy * side + xx) * C + c] : 0.0f;
+    // halo tile -> LDS: thread = (pixel e, float4 of channels); 16 lanes cover the 64 channels of a pixel, so one wave
+    // instruction fetches 4 pixels x 256 B (4x fewer, 4x wider loads than one channel per lane); C % 4 == 0
+    {
+        const int cb = blockIdx.x * 64;
+#pragma unroll 4
+        for (int idx = threadIdx.x; idx < (TM_PT + 6) * (TM_PT + 6) * 16; idx += 256) {
+            const int e = idx >> 4, c4 = idx & 15;
+            const int yy = ty0 + e / (TM_PT + 6) - 3, xx = tx0 + e % (TM_PT + 6) - 3;
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (cb + 4 * c4 < C && yy >= 0 && yy < side && xx >= 0 && xx < side)
+                v = *(const f32x4*)(in + ((size_t)yy * side + xx) * C + cb + 4 * c4);
+            *(f32x4*)(tile + e * 64 + 4 * c4) = v;
+        }
     }
     __syncthreads();
     if (c >= C) return;
@@ -219,16 +266,28 @@ __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 49; ++t) w[t] = weff[(size_t)t * C + c];
     const float b = beff[c];
-    for (int p = grp; p < TM_PT * TM_PT; p += 4) {
-        const int py = p / TM_PT, px = p % TM_PT;
-        const int y = ty0 + py, x = tx0 + px;
-        if (y >= side || x >= side) continue;
-        float s = b;
+    // register blocking: a thread produces whole rows of 8 pixels (rows 2 grp, 2 grp + 1): per kernel row it reads the 14
+    // halo values once and reuses each for up to 7 taps -> 196 instead of 784 LDS reads per 16 outputs
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky)
+    for (int r = 0; r < TM_PT / 4; ++r) {
+        const int py = (TM_PT / 4) * grp + r, y = ty0 + py;
+        if (y >= side) continue;
+        float acc[TM_PT];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) s = fmaf(w[ky * 7 + kx], tile[((py + ky) * (TM_PT + 6) + px + kx) * 64 + cl], s);
-        out[((size_t)y * side + x) * C + c] = s;
+        for (int px = 0; px < TM_PT; ++px) acc[px] = b;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            float in[TM_PT + 6];
+#pragma unroll
+            for (int i = 0; i < TM_PT + 6; ++i) in[i] = tile[((py + ky) * (TM_PT + 6) + i) * 64 + cl];
+#pragma unroll
+            for (int px = 0; px < TM_PT; ++px)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) acc[px] = fmaf(w[ky * 7 + kx], in[px + kx], acc[px]);
+        }
+#pragma unroll
+        for (int px = 0; px < TM_PT; ++px)
+            if (tx0 + px < side) out[((size_t)y * side + tx0 + px) * C + c] = acc[px];
     }
 }
 
@@ -329,7 +388,11 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
     TM_LINEAR(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
-    hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, QKV, g.l, m, Di, QL, KL);
+    {
+        int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
+        const int threads = ((Di / 4) * phases + 63) / 64 * 64;
+        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL);
+    }
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
     // chain below stays as the path for other widths and as the A/B reference (ACMIL_TM_UNFUSED=1)

@@ -209,24 +209,33 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3_kernel(const float* __restri
         }
 }
 
-// AV[h][l][e] = sum_c o_c[e] exp(m_c - M) / sum_c s_c exp(m_c - M), chunks in index order (deterministic)
-__global__ __launch_bounds__(64) void tm_attn3_merge_kernel(const float* __restrict__ part_ms, const float* __restrict__ part_o,
-                                                           float* __restrict__ AV, int M, int D, int nchunks) {
-    const int h = blockIdx.y, l = blockIdx.x;
-    float mx = -INFINITY;
-    for (int c = 0; c < nchunks; ++c) mx = fmaxf(mx, part_ms[(((size_t)h * nchunks + c) * M + l) * 2]);
-    float den = 0.0f;
-    for (int c = 0; c < nchunks; ++c) {
-        const float* p = part_ms + (((size_t)h * nchunks + c) * M + l) * 2;
-        den += p[1] * __expf(p[0] - mx);
+// AV[h][l][e] = sum_c o_c[e] exp(m_c - M) / sum_c s_c exp(m_c - M), chunks in index order (deterministic).
+// One wave per landmark row: lane c first loads the chunk statistics (<= 64 chunks), the wave agrees on M and the scale
+// factors, then lane e accumulates its feature over the chunks with the factors read through LDS.
+__global__ __launch_bounds__(256) void tm_attn3_merge_kernel(const float* __restrict__ part_ms, const float* __restrict__ part_o,
+                                                            float* __restrict__ AV, int M, int D, int nchunks) {
+    __shared__ float fac[4][64];
+    const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + wave;
+    if (l >= M) return;
+    float mc = -INFINITY, sc = 0.0f;
+    if (lane < nchunks) {
+        const float* p = part_ms + (((size_t)h * nchunks + lane) * M + l) * 2;
+        mc = p[0]; sc = p[1];
     }
-    for (int e = threadIdx.x; e < D; e += 64) {
+    float mx = mc;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float f = (lane < nchunks) ? __expf(mc - mx) : 0.0f;
+    fac[wave][lane] = f;
+    float den = sc * f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) den += __shfl_xor(den, o);       // fixed shuffle tree: deterministic
+    const float inv = 1.0f / den;
+    for (int e = lane; e < D; e += 64) {
         float num = 0.0f;
-        for (int c = 0; c < nchunks; ++c) {
-            const size_t row = ((size_t)h * nchunks + c) * M + l;
-            num += part_o[row * D + e] * __expf(part_ms[row * 2] - mx);
-        }
-        AV[((size_t)h * M + l) * D + e] = num / den;
+        for (int c = 0; c < nchunks; ++c) num += part_o[(((size_t)h * nchunks + c) * M + l) * D + e] * fac[wave][c];
+        AV[((size_t)h * M + l) * D + e] = num * inv;
     }
 }
 
@@ -276,7 +285,7 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     float* part_o = part + (((size_t)TMA_HEADS * nchunks * M * 2 + 63) & ~(size_t)63);
     hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(tm_attn3_merge_kernel, dim3(M, TMA_HEADS), dim3(64), 0, st, part_ms, part_o, AV, M, D, nchunks);
+    hipLaunchKernelGGL(tm_attn3_merge_kernel, dim3((M + 3) / 4, TMA_HEADS), dim3(256), 0, st, part_ms, part_o, AV, M, D, nchunks);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
