@@ -16,6 +16,7 @@
 // split order d_idx = (d/2) * (lane>>5) + s so that every lane's operand values are contiguous in memory.
 // Geometry is fixed by TransLayer (transMIL.py:13-23): heads = 8, m = Di/2 landmarks, d = Di/8  =>  d = m/4; with
 // MT = m/32 the kernels are instantiated for MT in {2,4,6,8} (Di = 128, 256, 384, 512); other widths use the GEMM chain.
+#include <stdlib.h>
 #include "ga_common.h"
 
 #define TMA_HEADS 8
@@ -239,6 +240,262 @@ __global__ __launch_bounds__(256) void tm_attn3_merge_kernel(const float* __rest
     }
 }
 
+// ===============================================================================================================
+// Split-f16 ("f16x3") variants of the two legs: every fp32 operand is split hi + lo in f16 and each product is formed as
+// hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16 (fp32 accumulate, ~1e-6 relative) -- 5.3x fewer matrix-pipe cycles than
+// the 32x32x2 fp32 form.  Same register chaining: the 16 accumulator registers of a 32x32 tile, taken 8 at a time, are the
+// K slots of the next MFMA; K slot (hi, j) of register group g is row 16 g + 4 hi + (j & 3) + 8 (j >> 2), and the LDS
+// images of W2^T / v^T are written pre-permuted in that order so a lane reads its 8 slots as one ds_read_b128.
+// W2 = attn2^+ (attn3 v) is rescaled by a power of two per head (|W2| <= 1024) before the split: a pseudo-inverse can be
+// large, and f16 halves overflow at 65504.
+typedef _Float16 tma_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 tma_h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void tma_split8(const float (&v)[8], tma_h8& h, tma_h8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const _Float16 x = (_Float16)v[j]; h[j] = x; l[j] = (_Float16)(v[j] - (float)x); }
+}
+#define TMA_MFMA3(acc, ah, al, bh, bl)                                         \
+    do {                                                                      \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);   \
+    } while (0)
+// K slot -> position inside the permuted 32-row group: row lr = 16 e2 + 4 hi + (j & 3) + 8 (j >> 2)
+__device__ __forceinline__ int tma_perm_index(int lr, int EP, int e) {   // f16 index of (row lr, column e) inside one 32-row group image
+    const int e2 = lr >> 4, hi_n = (lr >> 2) & 1, j = (lr & 3) + 4 * ((lr >> 3) & 1);
+    return (((e2 * EP + e) * 2 + hi_n) * 8) + j;
+}
+
+template <int MT>
+__global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict__ QKV, const float* __restrict__ KL,
+                                                        const float* __restrict__ W2, float* __restrict__ OUT, int npad, int Di,
+                                                        float scale) {
+    constexpr int M = 32 * MT, D = 8 * MT, KS = D / 16, ET = (D + 31) / 32, EP = 32 * ET, LD = D + 8;
+    constexpr int KLN = M * LD, W2N = MT * 2 * EP * 16;      // f16 elements per plane
+    extern __shared__ __attribute__((aligned(16))) char smx[];
+    _Float16* KLh = (_Float16*)smx; _Float16* KLl = KLh + KLN;
+    _Float16* W2h = KLl + KLN;      _Float16* W2l = W2h + W2N;
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y;
+    // power-of-two scale of W2 (per head)
+    float mx = 0.0f;
+    for (int idx = tid; idx < M * D; idx += 512) mx = fmaxf(mx, fabsf(W2[(size_t)h * M * D + idx]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) mx = fmaxf(mx, red[w]);
+    const float s2 = (mx > 0.0f && mx < INFINITY) ? exp2f(10.0f - ceilf(log2f(mx))) : 1.0f;
+    const float inv_s2 = 1.0f / s2;
+    for (int idx = tid; idx < M * D; idx += 512) {
+        const int l = idx / D, c = idx % D;
+        const float v = KL[((size_t)h * M + l) * D + c] * scale;
+        const _Float16 x = (_Float16)v;
+        KLh[l * LD + c] = x; KLl[l * LD + c] = (_Float16)(v - (float)x);
+    }
+    for (int idx = tid; idx < M * EP; idx += 512) {
+        const int l = idx / EP, e = idx % EP;
+        const float v = e < D ? W2[((size_t)h * M + l) * D + e] * s2 : 0.0f;
+        const _Float16 x = (_Float16)v;
+        const int p = (l >> 5) * 2 * EP * 16 + tma_perm_index(l & 31, EP, e);
+        W2h[p] = x; W2l[p] = (_Float16)(v - (float)x);
+    }
+    __syncthreads();
+
+    const int nblk = npad / 32, stride = gridDim.x * 8;
+    int rb = blockIdx.x * 8 + wave;
+    f32x4 qn[KS][2];
+    auto load_q = [&](int b) {
+        const float* qp = QKV + (size_t)(b * 32 + i31) * 3 * Di + h * D + 8 * hi;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) { qn[st][0] = *(const f32x4*)(qp + 16 * st); qn[st][1] = *(const f32x4*)(qp + 16 * st + 4); }
+    };
+    if (rb < nblk) load_q(rb);
+    for (; rb < nblk; rb += stride) {
+        tma_h8 qh[KS], ql[KS];
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const float v[8] = {qn[st][0][0], qn[st][0][1], qn[st][0][2], qn[st][0][3], qn[st][1][0], qn[st][1][1], qn[st][1][2], qn[st][1][3]};
+            tma_split8(v, qh[st], ql[st]);
+        }
+        if (rb + stride < nblk) load_q(rb + stride);
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int off = (32 * t + i31) * LD + 16 * st + 8 * hi;
+                const tma_h8 ah = *(const tma_h8*)(KLh + off), al = *(const tma_h8*)(KLl + off);
+                TMA_MFMA3(acc[t], ah, al, qh[st], ql[st]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float m2 = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m2 = fmaxf(m2, acc[t][r]);
+        m2 = fmaxf(m2, tma_xor32(m2));
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float p = __expf(acc[t][r] - m2); acc[t][r] = p; sum += p; }
+        sum += tma_xor32(sum);
+
+        f32x16 o[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = acc[t][8 * e2 + j];
+                tma_h8 ph, pl;
+                tma_split8(pv, ph, pl);
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    const int off = t * 2 * EP * 16 + (((e2 * EP + 32 * et + i31) * 2 + hi) * 8);
+                    const tma_h8 wh = *(const tma_h8*)(W2h + off), wl = *(const tma_h8*)(W2l + off);
+                    TMA_MFMA3(o[et], wh, wl, ph, pl);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = inv_s2 / sum;
+        float* op = OUT + (size_t)(rb * 32 + i31) * Di + h * D;
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int e = 32 * et + 8 * gq + 4 * hi;
+                if (e < D) *(f32x4*)(op + e) = f32x4{o[et][4 * gq] * inv, o[et][4 * gq + 1] * inv, o[et][4 * gq + 2] * inv, o[et][4 * gq + 3] * inv};
+            }
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restrict__ QKV, const float* __restrict__ QL,
+                                                           float* __restrict__ part_ms, float* __restrict__ part_o, int npad, int Di,
+                                                           float scale, int blocks_per_chunk) {
+    constexpr int M = 32 * MT, D = 8 * MT, KS = D / 16, ET = (D + 31) / 32, EP = 32 * ET, LDK = D + 8, VN = 2 * EP * 16;
+    __shared__ __attribute__((aligned(16))) _Float16 kh[2][32 * LDK], kl[2][32 * LDK];   // [key][d]       A operand of GEMM-S
+    __shared__ __attribute__((aligned(16))) _Float16 vh[2][VN], vl[2][VN];                // permuted v^T  A operand of GEMM-PV
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    const int nblk = npad / 32;
+    const int kb0 = chunk * blocks_per_chunk, kb1 = min(nblk, kb0 + blocks_per_chunk);
+
+    tma_h8 qh[KS], ql[KS];            // B operand of GEMM-S: scale * q_l[l = 32 wave + i31][16 st + 8 hi + j]
+    {
+        const float* qp = QL + ((size_t)h * M + 32 * wave + i31) * D + 8 * hi;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = qp[16 * st + j] * scale;
+            tma_split8(v, qh[st], ql[st]);
+        }
+    }
+    for (int idx = tid; idx < 2 * VN; idx += 64 * MT) { vh[idx / VN][idx % VN] = (_Float16)0.0f; vl[idx / VN][idx % VN] = (_Float16)0.0f; }
+    __syncthreads();                  // the padded e columns stay zero; real columns are overwritten every step
+    const int srow = tid / (D / 4), sc4 = tid % (D / 4);
+    f32x4 kreg, vreg;
+    auto load_kv = [&](int kb) {
+        const float* base = QKV + (size_t)(kb * 32 + srow) * 3 * Di + h * D + 4 * sc4;
+        kreg = *(const f32x4*)(base + Di);
+        vreg = *(const f32x4*)(base + 2 * Di);
+    };
+    float m_run = -INFINITY, s_run = 0.0f;
+    f32x16 o[ET];
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
+
+    if (kb0 < kb1) load_kv(kb0);
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int buf = (kb - kb0) & 1;
+        {
+            tma_h4 h4, l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const _Float16 x = (_Float16)kreg[j]; h4[j] = x; l4[j] = (_Float16)(kreg[j] - (float)x); }
+            *(tma_h4*)(&kh[buf][srow * LDK + 4 * sc4]) = h4;
+            *(tma_h4*)(&kl[buf][srow * LDK + 4 * sc4]) = l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const _Float16 x = (_Float16)vreg[j];
+                const int p = tma_perm_index(srow, EP, 4 * sc4 + j);
+                vh[buf][p] = x; vl[buf][p] = (_Float16)(vreg[j] - (float)x);
+            }
+        }
+        __syncthreads();
+        if (kb + 1 < kb1) load_kv(kb + 1);
+
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < KS; ++st) {
+            const int off = i31 * LDK + 16 * st + 8 * hi;
+            const tma_h8 ah = *(const tma_h8*)(&kh[buf][off]), al = *(const tma_h8*)(&kl[buf][off]);
+            TMA_MFMA3(S, ah, al, qh[st], ql[st]);
+        }
+        float bm = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) bm = fmaxf(bm, S[r]);
+        bm = fmaxf(bm, tma_xor32(bm));
+        const float mn = fmaxf(m_run, bm);
+        const float alpha = __expf(m_run - mn);
+        float ps = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ps += S[r]; }
+        ps += tma_xor32(ps);
+        s_run = s_run * alpha + ps;
+        m_run = mn;
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[et][r] *= alpha;
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = S[8 * e2 + j];
+            tma_h8 ph, pl;
+            tma_split8(pv, ph, pl);
+#pragma unroll
+            for (int et = 0; et < ET; ++et) {
+                const int off = ((e2 * EP + 32 * et + i31) * 2 + hi) * 8;
+                const tma_h8 wh = *(const tma_h8*)(&vh[buf][off]), wl = *(const tma_h8*)(&vl[buf][off]);
+                TMA_MFMA3(o[et], wh, wl, ph, pl);
+            }
+        }
+    }
+    const size_t row = ((size_t)h * nchunks + chunk) * M + 32 * wave + i31;
+    if (hi == 0) { part_ms[row * 2] = m_run; part_ms[row * 2 + 1] = s_run; }
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int e = 32 * et + 8 * gq + 4 * hi;
+            if (e < D) *(f32x4*)(part_o + row * D + e) = f32x4{o[et][4 * gq], o[et][4 * gq + 1], o[et][4 * gq + 2], o[et][4 * gq + 3]};
+        }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side (called from transmil.hip).  Return ACMIL_ERR_UNSUPPORTED when the geometry has no instantiation.
 int tm_attn_fused_supported(int Di) { return Di == 128 || Di == 256 || Di == 384 || Di == 512; }
@@ -249,8 +506,27 @@ size_t tm_attn3_partial_bytes(int npad, int Di) {
     return (size_t)TMA_HEADS * 64 * m * (2 + d) * sizeof(float) + 1024;   // <= 64 chunks (tm_attn3_launch)
 }
 
+// ACMIL_TM_ATTN_FP32=1 selects the exact-fp32 MFMA kernels (A/B reference); default = split-f16
+static bool tm_attn_exact() { static const bool v = getenv("ACMIL_TM_ATTN_FP32") != nullptr; return v; }
+
+template <int MT>
+static int tm_attn1x_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+    constexpr int M = 32 * MT, D = 8 * MT, ET = (D + 31) / 32, EP = 32 * ET;
+    const size_t lds = ((size_t)2 * M * (D + 8) + (size_t)2 * MT * 2 * EP * 16) * sizeof(_Float16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)tm_attn1x_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nblk = npad / 32;
+    int gx = (nblk + 7) / 8; if (gx > 32) gx = 32;
+    hipLaunchKernelGGL(tm_attn1x_kernel<MT>, dim3(gx, TMA_HEADS), dim3(512), lds, st, QKV, KL, W2, OUT, npad, Di, scale);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
 template <int MT>
 static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+    if (!tm_attn_exact()) return tm_attn1x_launch<MT>(QKV, KL, W2, OUT, npad, Di, scale, st);
     constexpr int M = 32 * MT, D = 8 * MT, ET = (D + 31) / 32, EP = 32 * ET;
     const size_t lds = ((size_t)D * (M + 4) + (size_t)M * (EP + 8)) * sizeof(float);
     static bool attr_set = false;      // idempotent attribute; racing callers set the same value
@@ -283,7 +559,8 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     nchunks = (nblk + bpc - 1) / bpc;
     float* part_ms = part;
     float* part_o = part + (((size_t)TMA_HEADS * nchunks * M * 2 + 63) & ~(size_t)63);
-    hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
+    if (tm_attn_exact()) hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
+    else hipLaunchKernelGGL(tm_attn3x_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(tm_attn3_merge_kernel, dim3((M + 3) / 4, TMA_HEADS), dim3(256), 0, st, part_ms, part_o, AV, M, D, nchunks);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
