@@ -177,13 +177,6 @@ static int ga_pick_waves(int maxN, long long total_patches = 0) {
     return w;
 }
 
-// Two 4-wave workgroups share a CU and start in lockstep, so their MFMA-idle phases (relu/convert, scores, pooling, combine)
-// coincide for the whole launch; delaying the second slot once by about half a tile keeps them out of phase afterwards.
-static int ga_pick_stagger() {
-    const char* e = getenv("ACMIL_GA_STAGGER");
-    return e ? atoi(e) : 0;
-}
-
 extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D, int Di, int K, int C, int mode) {
     (void)D; (void)C; (void)mode;
     if (nbags <= 0 || nbags > GA_MAX_BATCH || !Ns || Di <= 0 || K <= 0) return 0;
@@ -213,7 +206,6 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
     a.waves = ga_pick_waves(maxN, total_patches);
-    a.stagger = ga_pick_stagger();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
         a.xs[b] = b < nbags ? xs[b] : nullptr;
@@ -287,7 +279,6 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
     a.waves = ga_pick_waves(N);
-    a.stagger = ga_pick_stagger();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);

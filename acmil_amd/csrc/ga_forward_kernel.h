@@ -44,7 +44,6 @@ struct GaFwdArgs {
     float* part;     // workspace partials [total tiles][K][2+Di]
     float* h_save;   // [N,Di] or null (single-bag score pass only)
     int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
-    int stagger;     // 4-wave mode: start delay (units of s_sleep 127 ~ 8k cycles) of the second workgroup slot of every CU
 #ifdef GA_TRACE
     unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0
 #endif
@@ -66,21 +65,12 @@ __device__ __forceinline__ void ga_glds16(const char* gsrc, unsigned ldst) {   /
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
 }
-// Same copy with the non-temporal hint.  NOT used for the bag (measured, B=8: FETCH_SIZE 534 -> 955 MB per launch and
-// 15.1k -> 13.2k slides/s): a step reads one 64-byte segment per patch row, and the second half of each 128-byte line
-// is wanted one step later -- without L2 retention it is fetched from the fabric twice.  Kept for experiments.
-__device__ __forceinline__ void ga_glds16_nt(const char* gsrc, unsigned ldst) {
-    unsigned keep;
-    const unsigned lds = __builtin_amdgcn_readfirstlane(ldst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
-}
+// (A non-temporal variant of this copy was measured for the bag and rejected: a step reads one 64-byte segment per patch
+//  row and the other half of each 128-byte line is wanted one step later; without L2 retention FETCH_SIZE rose by 79 %.)
 #ifdef GA_GLDS_BUILTIN
 #define GA_GLDS16(gsrc, ldst) __builtin_amdgcn_global_load_lds((gptr_t)(gsrc), (lptr_t)(size_t)(ldst), 16, 0, 0)
-#define GA_GLDS16_NT(gsrc, ldst) GA_GLDS16(gsrc, ldst)
 #else
 #define GA_GLDS16(gsrc, ldst) ga_glds16((const char*)(gsrc), (unsigned)(ldst))
-#define GA_GLDS16_NT(gsrc, ldst) ga_glds16_nt((const char*)(gsrc), (unsigned)(ldst))
 #endif
 
 #ifdef GA_TRACE
@@ -150,8 +140,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     const int m0 = ((int)blockIdx.x - a.tile_start[bag]) * G::ROWS + wave * 32;
     const int row = m0 + i31;
     const bool valid = row < N;
-    if (WAVES == 4 && a.stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);   // de-phase the two co-resident workgroups (see ga_pick_stagger)
 
     const char* wstream = a.packed + L.g1_off;   // GEMM1 rows then GEMM2 rows, contiguous: step u starts at u * WROWS rows
     const int S1 = D / 16;                 // GEMM1 steps
@@ -186,15 +174,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
         const unsigned slot = lds_base + (u % G::NB) * G::SLOT;
         const int ux = u < S1 ? u : S1 - 1;
         const int uw = u < SL ? u : SL;
-#if !defined(GA_EXP) || !(GA_EXP & 1)
 #pragma unroll
         for (int t = 0; t < NXT; ++t) {                           // x first (see the waits)
             const unsigned xdst = slot + G::WSLOT + (t ? (wave ^ 4) : wave) * G::XB;
 #pragma unroll
             for (int q = 0; q < G::XG; ++q) GA_GLDS16(xsrc[t][q] + (size_t)ux * 16 * G::XE, xdst + q * 1024);
         }
-#endif
-#if !defined(GA_EXP) || !(GA_EXP & 2)
         const char* src = wsrc + (size_t)uw * G::WROWS * GA_FRAG_ROW;
         constexpr int RSTRIDE = G::ALT ? 4 : WAVES;
         constexpr int NW = G::ALT ? G::WGA : G::WG1;
@@ -203,8 +188,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             const int r = wrow0 + q * RSTRIDE;                    // rows beyond WROWS (padding) re-fetch a valid row
             GA_GLDS16(src + (size_t)(r % G::WROWS) * GA_FRAG_ROW, slot + r * GA_FRAG_ROW);
         }
-#endif
-        (void)ux; (void)uw;
     };
 
     // epilogue vectors bv, bu, Ww -> LDS (rows K..KP-1 of Ww zero); visible after the first step barrier
@@ -288,15 +271,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
         GA_STAMP(4 * s + 1);
         __builtin_amdgcn_s_barrier();
         GA_STAMP(4 * s + 2);
-#if defined(GA_EXP) && (GA_EXP & 4)
-        if constexpr (G::ALT) { if ((wave >> 2) == (s & 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-#endif
-#if defined(GA_EXP) && (GA_EXP & 8)
-        if constexpr (G::ALT) { if ((wave >> 2) != (s & 1)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
-#endif
-#if defined(GA_EXP) && (GA_EXP & 16)
-        if constexpr (G::ALT) { if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(3); }   // the younger wave of every SIMD pair always high
-#endif
         if constexpr (G::ALT) issue_step(s + G::PD);   // issuing wave: DMA first, while its partner owns the matrix pipe
         // (non-ALT: the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
         //  VALU, M0 writes, ~100 cycles per instruction -- then overlaps matrix-core work instead of delaying it)

@@ -351,6 +351,9 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
 #define TM_GEMM(...) do { int rc_ = acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 // nn.Linear products (activations x weights, both K-contiguous): split-f16 MFMA, ~1e-6 relative; ACMIL_TM_FP32_GEMM=1 keeps them exact
 static bool tm_linear_exact() { static const bool v = getenv("ACMIL_TM_FP32_GEMM") != nullptr; return v; }
+// Moore-Penrose products: exact fp32 by default; ACMIL_TM_PINV_X3=1 runs them as split-f16 (experiment)
+static bool tm_pinv_x3() { static const bool v = getenv("ACMIL_TM_PINV_X3") != nullptr; return v; }
+#define TM_PINV_GEMM(...) do { int rc_ = tm_pinv_x3() ? acmil_gemm_f16x3(__VA_ARGS__) : acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 #define TM_LINEAR(...) do { int rc_ = tm_linear_exact() ? acmil_gemm_f32(__VA_ARGS__) : acmil_gemm_f16x3(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
 // out = c I - P for a batch of m x m matrices (first bracket of the Moore-Penrose iteration, nystrom_attention.py:25)
@@ -415,12 +418,12 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     for (int it = 0; it < 6; ++it) {
         float* spare = (zc == Z) ? T2 : Z;
         // xz = x z ; t1 = 7I - xz ; t = 15I - xz t1 ; t1 = 13I - xz t ; z' = 0.25 z t1
-        TM_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 0.0f, XZ, m, mm, nullptr, 0, nullptr, H, gws, st);
+        TM_PINV_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 0.0f, XZ, m, mm, nullptr, 0, nullptr, H, gws, st);
         hipLaunchKernelGGL(tm_ci_minus_kernel, dim3((unsigned)((H * mm + 255) / 256)), dim3(256), 0, st, XZ, T1, m, 7.0f, (long long)H * mm);
         TM_CHECK_LAUNCH();
-        TM_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 15.0f, spare, m, mm, nullptr, 3, nullptr, H, gws, st);
-        TM_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, spare, ACMIL_DTYPE_F32, m, mm, 13.0f, T1, m, mm, nullptr, 3, nullptr, H, gws, st);
-        TM_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);
+        TM_PINV_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 15.0f, spare, m, mm, nullptr, 3, nullptr, H, gws, st);
+        TM_PINV_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, spare, ACMIL_DTYPE_F32, m, mm, 13.0f, T1, m, mm, nullptr, 3, nullptr, H, gws, st);
+        TM_PINV_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);
         zn = spare; float* t = zc; zc = zn; zn = t;
     }
     if (fused) {
