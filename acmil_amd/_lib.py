@@ -49,6 +49,21 @@ SIGNATURES = {
     "acmil_attn_pool_workspace_bytes": (_sz, [_i] * 3),
     "acmil_attn_pool": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "acmil_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "acmil_layernorm_fwd": (_i, [_vp, C.c_longlong, _i, _vp, _vp, C.c_float, _vp, _vp, _vp]),
+    "acmil_layernorm_bwd_workspace_bytes": (_sz, [C.c_longlong, _i]),
+    "acmil_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),
+    "acmil_softmax_rows_bwd": (_i, [_vp, _vp, _vp, C.c_longlong, _i, _vp]),
+    "acmil_seqconv": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "acmil_seqconv_bwd_w_workspace_bytes": (_sz, [_i, _i]),
+    "acmil_seqconv_bwd_w": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "acmil_dwconv7": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "acmil_dwconv7_bwd_w_workspace_bytes": (_sz, [_i, _i]),
+    "acmil_dwconv7_bwd_w": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "acmil_landmark_mean": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "acmil_landmark_mean_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "acmil_relu_bwd": (_i, [_vp, _vp, _vp, C.c_longlong, _vp]),
+    "acmil_colsum_workspace_bytes": (_sz, [C.c_longlong, _i]),
+    "acmil_colsum": (_i, [_vp, C.c_longlong, _i, _vp, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),

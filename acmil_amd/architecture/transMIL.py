@@ -4,12 +4,18 @@ Mirrors `architecture/transMIL.py` of dazhangyu123/ACMIL: `TransLayer` (:8-28), 
 (:48-91) and the `NystromAttention` parameter layout of the pip package it imports (vendored fork:
 `architecture/nystrom_attention.py:29-65`) -- same constructor `TransMIL(conf)`, `forward(input [B,N,D_feat]) ->
 logits [B,C]`, same `state_dict()` keys.  All arithmetic runs in `acmil_transmil_forward` (acmil_amd/csrc/
-transmil.hip); the nn.Modules below are parameter containers.  Not implemented: training (the Dropout(0.1) of
-`to_out` and the backward) and B > 1 (the reference's pinv couples batch rows; its shipped configs use B = 1).
+transmil.hip) in eval mode; the nn.Modules below are parameter containers.  With gradients enabled the module runs the same
+mathematics op by op through `acmil_amd.autograd` (HIP forward + backward kernels per op: GEMMs, LayerNorm, row softmax,
+sequence conv, depth-wise 7x7, landmark means), in the reference's association, so `loss.backward()` works.
+Not implemented: B > 1 (the reference's pinv couples batch rows; its shipped configs use B = 1).
 """
+import math
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as AG
 from .. import ops
 
 
@@ -54,12 +60,68 @@ class TransMIL(nn.Module):
         self.norm = nn.LayerNorm(conf.D_inner)
         self._fc2 = nn.Linear(conf.D_inner, conf.n_class)
 
+    # ------------------------------------------------------------------------------------------ training path
+    def _attention(self, x, layer, precision):
+        """NystromAttention.forward (nystrom_attention.py:67-149) on x [n, Di], op by op with autograd."""
+        a = layer.attn
+        n, di = x.shape
+        h, m = 8, di // 2
+        d = di // h
+        scale = d ** -0.5
+        rem = n % m
+        if rem > 0:
+            x = F.pad(x, (0, 0, m - rem, 0), value=0.0)                       # FRONT zero padding (:72-75)
+        npad = x.shape[0]
+        l = math.ceil(n / m)
+        qkv = AG.linear(x, a.to_qkv.weight, None, precision=precision)        # [npad, 3 Di]
+        q, k, v = qkv[:, :di], qkv[:, di:2 * di], qkv[:, 2 * di:]
+        heads = lambda t: t.reshape(npad, h, d).permute(1, 0, 2)             # [h, npad, d] strided views of qkv
+        qh, kh, vh = heads(q), heads(k), heads(v)
+        q_l, k_l = AG.landmark_mean(q, l), AG.landmark_mean(k, l)             # [h, m, d]   (scale folded into the products)
+        attn1 = AG.softmax_rows(AG.matmul(qh, k_l, trans_b=True, alpha=scale))            # [h, npad, m]
+        attn2 = AG.softmax_rows(AG.matmul(q_l, k_l, trans_b=True, alpha=scale))           # the reference scales q once (:91)
+        attn3 = AG.softmax_rows(AG.matmul(q_l, kh, trans_b=True, alpha=scale))            # [h, m, npad]
+        # Moore-Penrose iteration (nystrom_attention.py:12-27): tiny [h, m, m] tensors, products on the exact GEMM
+        abs_x = attn2.abs()
+        z = attn2.transpose(-1, -2) / (abs_x.sum(dim=-1).max() * abs_x.sum(dim=-2).max())
+        eye = torch.eye(m, device=x.device, dtype=x.dtype).unsqueeze(0)
+        for _ in range(6):
+            xz = AG.matmul(attn2, z)
+            z = 0.25 * AG.matmul(z, 13 * eye - AG.matmul(xz, 15 * eye - AG.matmul(xz, 7 * eye - xz)))
+        out = AG.matmul(AG.matmul(attn1, z), AG.matmul(attn3, vh))                          # reference association (:133)
+        out = out.permute(1, 0, 2).reshape(npad, di) + AG.seq_conv(v, a.res_conv.weight)
+        out = AG.linear(out, a.to_out[0].weight, a.to_out[0].bias, precision=precision)
+        out = F.dropout(out, a.to_out[1].p, self.training)
+        return out[-n:]
+
+    def _forward_train(self, x, precision="f16x3"):
+        """transMIL.py:60-91 with autograd-capable ops; x [N, D_feat] -> logits [1, C]"""
+        di = self._fc1[0].out_features
+        h = AG.linear(x.float().contiguous(), self._fc1[0].weight, self._fc1[0].bias, relu=True, precision=precision)
+        n0 = h.shape[0]
+        side = int(math.ceil(math.sqrt(n0)))
+        h = torch.cat([self.cls_token.reshape(1, di), h, h[:side * side - n0]], dim=0)   # cls + tokens + wrap-around padding (:64-72)
+        h = h + self._attention(AG.layer_norm(h, self.layer1.norm.weight, self.layer1.norm.bias), self.layer1, precision)
+        p = self.pos_layer                                                    # PPEG: one folded depth-wise 7x7 (:38-45)
+        weff = p.proj.weight[:, 0] + F.pad(p.proj1.weight[:, 0], (1, 1, 1, 1)) + F.pad(p.proj2.weight[:, 0], (2, 2, 2, 2))
+        ident = torch.zeros(7, 7, device=x.device); ident[3, 3] = 1.0
+        weff = (weff + ident).reshape(di, 49).t().contiguous()                # [49, C] tap-major
+        beff = p.proj.bias + p.proj1.bias + p.proj2.bias
+        h = torch.cat([h[:1], AG.dwconv7(h[1:], weff, beff, side)], dim=0)
+        h = h + self._attention(AG.layer_norm(h, self.layer2.norm.weight, self.layer2.norm.bias), self.layer2, precision)
+        cls = AG.layer_norm(h[:1], self.norm.weight, self.norm.bias)
+        return AG.linear(cls, self._fc2.weight, self._fc2.bias, precision="fp32")
+
     def forward(self, input, debug=False):
         """input [B=1, N, D_feat] -> logits [1, C]  (transMIL.py:60-91)."""
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("acmil_amd: TransMIL training (dropout + backward) is not built yet; use .eval()")
         if input.dim() != 3 or input.shape[0] != 1:
             raise RuntimeError("acmil_amd: TransMIL expects input [1, N, D_feat]")
+        if not input.is_cuda:
+            raise RuntimeError("acmil_amd: TransMIL runs on an MI355X only (no CPU fallback)")
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(input[0])
+        if self.training:
+            raise NotImplementedError("acmil_amd: train-mode TransMIL draws dropout masks; call it with gradients enabled or use .eval()")
         sd = dict(self.named_parameters())
         out = ops.transmil_forward(input[0], sd, self.n_classes, debug=debug)
         self._last = out

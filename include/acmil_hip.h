@@ -247,6 +247,40 @@ int acmil_attn_pool(const float* h, const float* A, int N, int Di, int K, float*
 
 int acmil_softmax_rows(const float* S, float* P, int rows, int cols, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Op-level forward / backward kernels for TRAINING the TransMIL / Nystrom path (csrc/transmil_train.hip).  The eval forward
+ * is acmil_transmil_forward; training runs op by op as torch.autograd Functions (acmil_amd/autograd.py) over these entry
+ * points and the GEMMs above.  All tensors fp32, row-major, caller-owned.
+ *   acmil_layernorm_fwd/_bwd   nn.LayerNorm(dim, eps) (transMIL.py:12,27,57,85); stats [rows,2] = (mean, rstd)
+ *   acmil_softmax_rows_bwd     dS = P * (dP - sum(dP * P)) per row (backward of the three softmaxes, nystrom_attention.py:115)
+ *   acmil_seqconv              out[i][c] = sum_t w[c/d][t] v[i+t-16][c]: Conv2d(8, 8, (33,1), groups=8, no bias) (nystrom_attention.py:38,135-136);
+ *                              v may be a column block of a wider matrix (ldv); its input gradient is the same conv with the flipped kernel
+ *   acmil_seqconv_bwd_w        dw [8,33]
+ *   acmil_dwconv7              depth-wise 7x7 on the [side,side] token grid, channels-last, weff [49,C] (+ beff [C] or NULL):
+ *                              the folded PPEG stencil (transMIL.py:33-45)
+ *   acmil_dwconv7_bwd_w        dweff [49,C], dbeff [C]
+ *   acmil_landmark_mean/_bwd   out [8, n/l, Di/8] = means over l consecutive rows of src [n, Di] (ld) (nystrom_attention.py:95-111)
+ * ------------------------------------------------------------------------------------------- */
+int acmil_layernorm_fwd(const float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, float* y,
+                        float* stats, void* stream);
+size_t acmil_layernorm_bwd_workspace_bytes(long long rows, int dim);
+int acmil_layernorm_bwd(const float* x, const float* dy, const float* stats, const float* gamma, long long rows, int dim,
+                        float* dx, float* dgamma, float* dbeta, void* workspace, void* stream);
+int acmil_softmax_rows_bwd(const float* P, const float* dP, float* dS, long long rows, int cols, void* stream);
+int acmil_seqconv(const float* v, int ldv, int n, int Di, const float* w, float* out, void* stream);
+size_t acmil_seqconv_bwd_w_workspace_bytes(int n, int Di);
+int acmil_seqconv_bwd_w(const float* dout, const float* v, int ldv, int n, int Di, float* dw, void* workspace, void* stream);
+int acmil_dwconv7(const float* x, int side, int C, const float* weff, const float* beff, float* y, void* stream);
+size_t acmil_dwconv7_bwd_w_workspace_bytes(int side, int C);
+int acmil_dwconv7_bwd_w(const float* dy, const float* x, int side, int C, float* dweff, float* dbeff, void* workspace,
+                        void* stream);
+int acmil_landmark_mean(const float* src, int ld, int n, int l, int Di, float* out, void* stream);
+int acmil_landmark_mean_bwd(const float* dout, int n, int l, int Di, float* dsrc, void* stream);
+/* dx = dy where y > 0 (ReLU backward on the saved output); out[c] = sum_rows x[row][c] (bias gradients, fixed-order reduce) */
+int acmil_relu_bwd(const float* dy, const float* y, float* dx, long long total, void* stream);
+size_t acmil_colsum_workspace_bytes(long long rows, int cols);
+int acmil_colsum(const float* x, long long rows, int cols, float* out, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
