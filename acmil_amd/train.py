@@ -1,4 +1,4 @@
-"""Step3-style trainer for the MI355X aggregation path (`--arch ga | abmil`).
+"""Step3-style trainer for the MI355X aggregation path (`--arch ga | abmil | transmil`).
 
 Own-code counterpart of the reference's `Step3_WSI_classification_ACMIL.py` (main :59-173,
 train_one_epoch :175-235, evaluate :242-286) and of the helpers it takes from `utils/utils.py`
@@ -224,8 +224,13 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
             losses, _ = model.train_step(x.unsqueeze(0), labels)
             acc += losses
         else:
-            sub_preds, slide_preds, attn = model(x.unsqueeze(0))
-            loss0, loss1, diff_loss = acmil_losses(sub_preds, slide_preds, attn, labels, conf.n_token)
+            out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
+            if isinstance(out, tuple):                       # ACMIL: (sub_preds, slide_preds, attn)
+                sub_preds, slide_preds, attn = out
+                loss0, loss1, diff_loss = acmil_losses(sub_preds, slide_preds, attn, labels, conf.n_token)
+            else:                                            # single-head models (abmil, transmil): criterion(output, label),
+                zero = torch.zeros((), device=device)        # Step3_WSI_classification.py / engine.py:19-21
+                loss0, loss1, diff_loss = zero, F.cross_entropy(out, labels), zero
             loss = diff_loss + loss0 + loss1
             optimizer.zero_grad(set_to_none=False)
             loss.backward()
@@ -256,9 +261,13 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     for item in staged(data, order, device):
         x = item["input"]
         y = label_dev[item["label"]:item["label"] + 1]
-        sub_preds, slide_preds, attn = model(x.unsqueeze(0))
-        # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
-        divs.append(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1])
+        out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
+        if isinstance(out, tuple):
+            sub_preds, slide_preds, attn = out
+            # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
+            divs.append(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1])
+        else:
+            slide_preds = out
         losses.append(F.cross_entropy(slide_preds, y))
         probs.append(torch.softmax(slide_preds, dim=-1))
         labels.append(y)
@@ -287,7 +296,10 @@ def build_model(conf):
                         precision=conf.precision)
     if conf.arch == "abmil":
         return ABMIL(conf, precision=conf.precision)
-    raise SystemExit("--arch %s is not on the MI355X path yet (ga, abmil)" % conf.arch)
+    if conf.arch == "transmil":
+        from .architecture.transMIL import TransMIL
+        return TransMIL(conf)
+    raise SystemExit("--arch %s is not on the MI355X path yet (ga, abmil, transmil)" % conf.arch)
 
 
 def get_arguments(argv=None):
@@ -297,7 +309,7 @@ def get_arguments(argv=None):
     p.add_argument("--n_token", type=int, default=1)
     p.add_argument("--n_masked_patch", type=int, default=0)
     p.add_argument("--mask_drop", type=float, default=0.6)
-    p.add_argument("--arch", default="ga", choices=["ga", "abmil"])
+    p.add_argument("--arch", default="ga", choices=["ga", "abmil", "transmil"])
     p.add_argument("--pretrain", default="medical_ssl", choices=sorted(PRETRAIN_DIMS))
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16"])

@@ -37,3 +37,22 @@ def test_training_reduces_loss_and_checkpoints():
             a = model.eval()(x)[1]
             b = m2(x)[1]
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch", ["transmil", "abmil"])
+def test_single_head_archs_train(arch):
+    """`--arch transmil` / `--arch abmil`: criterion(output, label) loop (Step3_WSI_classification.py / engine.py:19-21)."""
+    from acmil_amd import train as T
+    conf = T.Struct(train_epoch=3, warmup_epoch=0, wd=1e-5, lr=1e-3, min_lr=0, n_class=2, n_token=1, n_masked_patch=0,
+                    mask_drop=0.0, arch=arch, precision="f16x3", seed=1, D_feat=384, D_inner=128)
+    T.set_seed(2)
+    device = torch.device("cuda", 0)
+    train = T.SyntheticBags(16, (200, 400), 384, 2, seed=3)
+    model = T.build_model(conf).to(device)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=conf.wd)
+    first = T.train_one_epoch(model, train, opt, device, 0, conf, log_every=0, fused=False)
+    for epoch in (1, 2):
+        last = T.train_one_epoch(model, train, opt, device, epoch, conf, log_every=0, fused=False)
+    assert last["slide_loss"] == last["slide_loss"] and last["slide_loss"] < first["slide_loss"], (first, last)
+    auroc, acc, f1, loss = T.evaluate(model, train, device, conf, "Train")
+    assert 0.0 <= auroc <= 1.0 and loss == loss
