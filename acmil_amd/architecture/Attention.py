@@ -1,17 +1,18 @@
 """DTFD-style attention blocks on an already projected bag, same names / ctor signatures / state_dict keys as the
 reference's `architecture/Attention.py` (Attention_Gated :29-57, Attention_with_Classifier :60-70).
-Arithmetic: acmil_gated_scores / acmil_attn_pool / acmil_softmax_rows / acmil_gemm (csrc/attn_generic.hip).  Eval forward
-only (no backward is built for these modules): a call that would need gradients raises."""
+Arithmetic: acmil_gated_scores / acmil_attn_pool / acmil_softmax_rows / acmil_gemm (csrc/attn_generic.hip) under
+torch.no_grad(); with gradients enabled the same mathematics runs op by op through acmil_amd.autograd (Linear GEMMs, gate
+kernel, row softmax, pooling GEMM, each with a HIP backward), so the modules can be trained."""
 import torch
 import torch.nn as nn
 
+from .. import autograd as AG
 from .. import ops
 from .network import Classifier_1fc
 
 
-def _no_grad_path(name, *params):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        raise NotImplementedError("acmil_amd: %s has an eval forward only; wrap the call in torch.no_grad()" % name)
+def _needs_grad(x, *params):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
 
 
 class Attention_Gated(nn.Module):
@@ -25,14 +26,17 @@ class Attention_Gated(nn.Module):
 
     def scores(self, x):
         v, u, w = self.attention_V[0], self.attention_U[0], self.attention_weights
-        _no_grad_path("Attention_Gated", v.weight, u.weight, w.weight)
         if not x.is_cuda:
             raise RuntimeError("acmil_amd: Attention_Gated runs on an MI355X only (no CPU fallback)")
+        if _needs_grad(x, v.weight, u.weight, w.weight):
+            return AG.gated_scores(x.float(), v.weight, v.bias, u.weight, u.bias, w.weight, w.bias, self.precision)
         return ops.gated_scores(x.float().contiguous(), v.weight, v.bias, u.weight, u.bias, w.weight, w.bias, self.precision)
 
     def forward(self, x, isNorm=True):   # x: N x L -> K x N   (Attention.py:47-57)
         A = self.scores(x)
-        return ops.softmax_rows(A) if isNorm else A
+        if not isNorm:
+            return A
+        return AG.softmax_rows(A.contiguous()) if A.requires_grad else ops.softmax_rows(A)
 
 
 class Attention_with_Classifier(nn.Module):
@@ -44,7 +48,10 @@ class Attention_with_Classifier(nn.Module):
         self.classifier = Classifier_1fc(L, num_cls, droprate)
 
     def forward(self, x):   # x: N x L -> K x num_cls   (Attention.py:66-70)
-        _no_grad_path("Attention_with_Classifier", self.classifier.fc.weight)
         x = x.float().contiguous()
-        afeat = ops.attn_pool(x, self.attention.scores(x))          # softmax over N fused into the pooling pass
+        A = self.attention.scores(x)
+        if A.requires_grad or _needs_grad(x, self.classifier.fc.weight):
+            afeat = AG.attn_pool(x, A)
+            return AG.linear(afeat, self.classifier.fc.weight, self.classifier.fc.bias, precision="fp32")
+        afeat = ops.attn_pool(x, A)                                  # softmax over N fused into the pooling pass
         return ops.gemm(afeat, self.classifier.fc.weight.detach(), trans_b=True, bias=self.classifier.fc.bias.detach())

@@ -3,6 +3,7 @@ reference's `architecture/ibmil.py:38-113`.  Structurally it is ABMIL (DimReduct
 Classifier_1fc), so it runs on the fully fused forward kernel; only the returned attention map needs one extra row softmax."""
 import torch
 
+from .. import autograd as AG
 from .. import ops
 from .network import Classifier_1fc, DimReduction
 from .transformer import Attention_Gated, _GatedBase
@@ -23,9 +24,17 @@ class IBMIL(_GatedBase):
     def _heads(self):
         return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
 
-    @torch.no_grad()
     def forward(self, x):   # x [1,N,D_feat] -> (Y_prob [1,C], M [1,Di], A [1,N] softmax over N)   (ibmil.py:69-113)
         xb = self._bag(x)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: op by op through acmil_amd.autograd (all three outputs are differentiable)
+            a = self.attention
+            h = AG.linear(xb.float(), self.dimreduction.fc1.weight, None, relu=True, precision=self.precision)
+            A = AG.softmax_rows(AG.gated_scores(h, a.attention_V[0].weight, a.attention_V[0].bias, a.attention_U[0].weight,
+                                                a.attention_U[0].bias, a.attention_weights.weight, a.attention_weights.bias,
+                                                self.precision).contiguous())
+            M = AG.matmul(A, h)
+            return AG.linear(M, self.classifier.fc.weight, self.classifier.fc.bias, precision="fp32"), M, A
         packed, dims = self._packed()
         out = ops.ga_forward(xb, packed, dims, self.precision, want_afeat=True)
         return out["sub_preds"], out["afeat"], ops.softmax_rows(out["A_out"])

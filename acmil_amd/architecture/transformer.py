@@ -14,9 +14,13 @@ from __future__ import annotations
 
 from typing import Optional
 
+import math
+
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from .. import autograd as AG
 from .. import ops
 from .network import Classifier_1fc, DimReduction
 
@@ -263,9 +267,9 @@ class MutiHeadAttention_modify(nn.Module):
 
 class ACMIL_MHA(nn.Module):
     """Drop-in for the reference's `ACMIL_MHA` (architecture/transformer.py:49-83, `--arch mha`): same ctor, parameter names
-    and return contract `(sub_preds [K,C], slide_pred [1,C], attns [8,K,N])`.  Eval forward only: the reference's train
-    mode draws Dropout(0.1) masks after out_proj and applies STKIM per head; neither the masks nor the backward are built,
-    so a training-mode call raises instead of silently differing."""
+    and return contract `(sub_preds [K,C], slide_pred [1,C], attns [8,K,N])`.  Under torch.no_grad() in eval mode: one C call
+    (acmil_mha_forward).  With gradients enabled: the same folded mathematics through acmil_amd.autograd (trainable; the
+    reference's Dropout(0.1) after out_proj and the per-row top-k mask-drop are applied in train mode)."""
 
     def __init__(self, conf, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3"):
         super().__init__()
@@ -281,15 +285,60 @@ class ACMIL_MHA(nn.Module):
         self.Slide_classifier = Classifier_1fc(conf.D_inner, conf.n_class, 0.0)
         self.precision = precision
 
+    def _post(self, att, out1):
+        """out_proj, dropout, LayerNorm(1e-6) of one attention module on the [Di] pooled projection (transformer.py:179-183)"""
+        o = F.linear(out1, att.out_proj.weight, att.out_proj.bias)
+        o = F.dropout(o, 0.1, self.training)
+        return F.layer_norm(o, (o.shape[-1],), att.layer_norm.weight, att.layer_norm.bias, 1e-6)
+
+    def _forward_train(self, x):
+        """Differentiable forward in the single-query folded form (see csrc/mha.hip): the O(N) passes -- projection, score
+        GEMM, row softmax, pooling GEMM -- are acmil_amd.autograd Functions with HIP backward kernels; the per-branch Di x Di
+        glue, the top-k mask bookkeeping and dropout are torch ops on small tensors."""
+        K, H = self.n_token, 8
+        h = AG.linear(x, self.dimreduction.fc1.weight, None, relu=True, precision=self.precision)     # [N, Di]
+        n, di = h.shape
+        c = di // H
+        rows, csts = [], []
+        for i, att in enumerate(self.sub_attention):
+            qp = F.linear(self.q[0, i], att.q_proj.weight, att.q_proj.bias).view(H, c, 1)          # q' per head
+            rows.append((att.k_proj.weight.view(H, c, di) * qp).sum(1) / math.sqrt(c))            # [H, Di]
+            csts.append((att.k_proj.bias.view(H, c) * qp[..., 0]).sum(1) / math.sqrt(c))           # [H]
+        MT, cst = torch.stack(rows, 1).reshape(H * K, di), torch.stack(csts, 1).reshape(H * K)    # row = j*K + i
+        S = AG.matmul(MT, h, trans_b=True) + cst[:, None]                                          # [H*K, N] = attns
+        attns = S.view(H, K, n)
+        masked = S
+        k_mask = min(self.sub_attention[0].n_masked_patch, n) if self.training else 0
+        if k_mask > 0:                                                                            # transformer.py:162-171, per (head, branch) row
+            drop = int(k_mask * self.sub_attention[0].mask_drop)
+            _, idx = torch.topk(S, k_mask, dim=-1)
+            sel = torch.argsort(torch.rand(idx.shape, device=S.device), dim=-1)[:, :drop]
+            midx = idx[torch.arange(idx.shape[0], device=S.device).unsqueeze(-1), sel]
+            mask = torch.ones_like(S).scatter_(-1, midx, 0)
+            masked = S.masked_fill(mask == 0, -1e9)
+            attns = masked.view(H, K, n)
+        P = AG.softmax_rows(masked.contiguous())
+        pooled = AG.matmul(P, h).view(H, K, di)                                                    # sum_n P h
+        outs = []
+        for i, att in enumerate(self.sub_attention):
+            out1 = ((att.v_proj.weight.view(H, c, di) * pooled[:, i].unsqueeze(1)).sum(-1) + att.v_proj.bias.view(H, c)).reshape(1, di)
+            outs.append(self.classifier[i](self._post(att, out1)))
+        bag = self.bag_attention
+        pb = pooled.mean(1)                                                                        # mean_i softmax(.) is linear in P
+        out1 = ((bag.v_proj.weight.view(H, c, di) * pb.unsqueeze(1)).sum(-1) + bag.v_proj.bias.view(H, c)).reshape(1, di)
+        return torch.cat(outs, 0), self.Slide_classifier(self._post(bag, out1)), attns
+
     def forward(self, input):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("acmil_amd: ACMIL_MHA training (dropout, per-head STKIM, backward) is not built; use .eval()")
         if input.dim() != 3 or input.shape[0] != 1:
             raise RuntimeError("acmil_amd: ACMIL_MHA expects input [1, N, D_feat]")
         x = input[0]
         if not x.is_cuda:
             raise RuntimeError("acmil_amd: ACMIL_MHA runs on an MI355X only (no CPU fallback)")
         x = x.float().contiguous()
+        if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x)
+        if self.training:
+            raise NotImplementedError("acmil_amd: train-mode ACMIL_MHA draws dropout / mask-drop randomness; enable gradients or use .eval()")
         sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
         out = ops.mha_forward(x, sd, self.n_token, self.n_class, self.precision)
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["attns"]

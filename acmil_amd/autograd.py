@@ -258,3 +258,38 @@ class _LandmarkMean(torch.autograd.Function):
 
 def landmark_mean(src, l):
     return _LandmarkMean.apply(src, l)
+
+
+class _Gate(torch.autograd.Function):
+    """G [N, 2 Da] -> tanh(G[:, :Da]) * sigmoid(G[:, Da:])"""
+
+    @staticmethod
+    def forward(ctx, G):
+        lib = _lib.load()
+        G = _c(G.detach()).contiguous()
+        n, da = G.shape[0], G.shape[1] // 2
+        y = torch.empty(n, da, dtype=torch.float32, device=G.device)
+        _lib.check(lib.acmil_gate_fwd(G.data_ptr(), y.data_ptr(), n, da, _stream()), "acmil_gate_fwd")
+        ctx.save_for_backward(G)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (G,) = ctx.saved_tensors
+        dy = _c(dy).contiguous()
+        dG = torch.empty_like(G)
+        _lib.check(lib.acmil_gate_bwd(G.data_ptr(), dy.data_ptr(), dG.data_ptr(), G.shape[0], G.shape[1] // 2, _stream()), "acmil_gate_bwd")
+        return dG
+
+
+def gated_scores(h, Wv, bv, Wu, bu, Ww, bw, precision="f16x3"):
+    """Differentiable gated-attention scores A [K, N] of a projected bag h [N, L] (Attention_Gated / Attn_Net_Gated):
+    two Linear products into the halves of G, the gate kernel, one Linear, a transpose."""
+    G = torch.cat([linear(h, Wv, bv, precision=precision), linear(h, Wu, bu, precision=precision)], dim=1)
+    return linear(_Gate.apply(G), Ww, bw, precision="fp32").t()
+
+
+def attn_pool(h, A):
+    """softmax over N of A [K, N], then P @ h -> [K, Di] (differentiable)"""
+    return matmul(softmax_rows(A.contiguous()), h)

@@ -354,6 +354,27 @@ __global__ __launch_bounds__(256) void tt_colsum_kernel(const float* __restrict_
         part[(size_t)blockIdx.x * cols + c] = (tt_cs_sm[c] + tt_cs_sm[cols + c]) + (tt_cs_sm[2 * cols + c] + tt_cs_sm[3 * cols + c]);
 }
 
+// y[n][u] = tanh(G[n][u]) * sigmoid(G[n][Da + u])   (the gate of Attention_Gated / Attn_Net_Gated); G is [N, 2 Da]
+__global__ __launch_bounds__(256) void tt_gate_fwd_kernel(const float* __restrict__ G, float* __restrict__ y, long long N, int Da) {
+    const long long total = N * Da;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long n = e / Da; const int u = (int)(e % Da);
+        y[e] = tanhf(G[n * 2 * Da + u]) * (1.0f / (1.0f + expf(-G[n * 2 * Da + Da + u])));
+    }
+}
+
+// dG[n][u] = dy * sig(b) * (1 - tanh(a)^2) ; dG[n][Da + u] = dy * tanh(a) * sig(b) * (1 - sig(b))
+__global__ __launch_bounds__(256) void tt_gate_bwd_kernel(const float* __restrict__ G, const float* __restrict__ dy, float* __restrict__ dG,
+                                                         long long N, int Da) {
+    const long long total = N * Da;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long n = e / Da; const int u = (int)(e % Da);
+        const float t = tanhf(G[n * 2 * Da + u]), sg = 1.0f / (1.0f + expf(-G[n * 2 * Da + Da + u])), g = dy[e];
+        dG[n * 2 * Da + u] = g * sg * (1.0f - t * t);
+        dG[n * 2 * Da + Da + u] = g * t * sg * (1.0f - sg);
+    }
+}
+
 // ==================================================================================================== C ABI
 static size_t tt_al(size_t b) { return (b + 255) & ~(size_t)255; }
 #define TT_LAUNCH_OK() (hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH)
@@ -503,5 +524,23 @@ extern "C" int acmil_colsum(const float* x, long long rows, int cols, float* out
     hipLaunchKernelGGL(tt_colsum_kernel, dim3(chunks), dim3(256), (size_t)4 * cols * sizeof(float), st, x, rows, cols, rpb, part);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(tt_colsum_reduce_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, chunks, (size_t)cols, cols, out);
+    return TT_LAUNCH_OK();
+}
+
+extern "C" int acmil_gate_fwd(const float* G, float* y, long long N, int Da, void* stream) {
+    if (N <= 0 || Da <= 0) return ACMIL_ERR_SHAPE;
+    if (!G || !y) return ACMIL_ERR_NULL;
+    const long long total = N * Da;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tt_gate_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, y, N, Da);
+    return TT_LAUNCH_OK();
+}
+
+extern "C" int acmil_gate_bwd(const float* G, const float* dy, float* dG, long long N, int Da, void* stream) {
+    if (N <= 0 || Da <= 0) return ACMIL_ERR_SHAPE;
+    if (!G || !dy || !dG) return ACMIL_ERR_NULL;
+    const long long total = N * Da;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tt_gate_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, dy, dG, N, Da);
     return TT_LAUNCH_OK();
 }

@@ -280,6 +280,10 @@ int acmil_landmark_mean_bwd(const float* dout, int n, int l, int Di, float* dsrc
 int acmil_relu_bwd(const float* dy, const float* y, float* dx, long long total, void* stream);
 size_t acmil_colsum_workspace_bytes(long long rows, int cols);
 int acmil_colsum(const float* x, long long rows, int cols, float* out, void* workspace, void* stream);
+/* y [N,Da] = tanh(G[:, :Da]) * sigmoid(G[:, Da:]) for G [N, 2 Da], and its backward dG [N, 2 Da] (the gate of Attention_Gated,
+ * transformer.py:262-264 / Attention.py:49-51 / clam.py:63-65, when the module is trained op by op) */
+int acmil_gate_fwd(const float* G, float* y, long long N, int Da, void* stream);
+int acmil_gate_bwd(const float* G, const float* dy, float* dG, long long N, int Da, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,8 +20,9 @@ def test_dtfd_attention_with_classifier(precision):
         np.testing.assert_allclose(m(x).cpu().numpy(), case["pred"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(m.attention(x).cpu().numpy(), case["A_norm"], rtol=0, atol=1e-6)
         np.testing.assert_allclose(m.attention(x, isNorm=False).cpu().numpy(), case["A_raw"], rtol=0, atol=1e-5)
-    with pytest.raises(NotImplementedError):
-        m(x)          # gradients enabled: there is no backward for this module
+    out = m(x)        # gradients enabled: the differentiable op-by-op path gives the same prediction
+    assert out.requires_grad
+    np.testing.assert_allclose(out.detach().cpu().numpy(), case["pred"], rtol=0, atol=1e-4)
 
 
 def test_ibmil():
@@ -33,7 +34,10 @@ def test_ibmil():
     m = IBMIL(Conf)
     assert set(m.state_dict()) == set(sd)
     m.load_state_dict(sd); m = m.cuda().eval()
-    y, mm, a = m(torch.from_numpy(case["x"]).cuda())
+    with torch.no_grad():                                    # fused forward kernel
+        y, mm, a = m(torch.from_numpy(case["x"]).cuda())
+    y2, mm2, a2 = m(torch.from_numpy(case["x"]).cuda())        # gradients enabled: differentiable op-by-op path, same values
+    assert y2.requires_grad and (y2.detach() - y).abs().max() < 1e-4 and (a2.detach() - a).abs().max() < 1e-6
     assert y.shape == (1, 3) and mm.shape == (1, 128) and a.shape == (1, 900)
     np.testing.assert_allclose(y.cpu().numpy(), case["Y_prob"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(mm.cpu().numpy(), case["M"], rtol=0, atol=1e-5)

@@ -1,0 +1,79 @@
+"""Training paths of ACMIL_MHA, the DTFD attention block and IBMIL: gradients against fixtures from the real reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_grads(model, case, rel=3e-3):
+    for name, p in model.named_parameters():
+        ref = case["grad." + name]
+        assert p.grad is not None, name
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        assert err <= rel * max(1e-3, np.abs(ref).max()), "%s: %.3e vs max %.3e" % (name, err, np.abs(ref).max())
+
+
+def test_mha_gradients_match_reference():
+    from acmil_amd.architecture.transformer import ACMIL_MHA
+    case, sd = load_golden("train_mha_n400_d384_k3_c2")
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 384, 128, 2, 3
+    m = ACMIL_MHA(Conf, n_token=3, n_masked_patch=0, mask_drop=0.0)
+    m.load_state_dict(sd); m = m.cuda().eval()          # eval + gradients: dropout inactive, as in the fixture (p = 0)
+    sub, slide, attns = m(torch.from_numpy(case["x"]).cuda())
+    label = torch.tensor([1]).cuda()
+    loss = F.cross_entropy(sub, label.repeat(3)) + F.cross_entropy(slide, label) + 0.5 * attns.pow(2).mean()
+    loss.backward()
+    np.testing.assert_allclose(sub.detach().cpu().numpy(), case["sub_preds"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(attns.detach().cpu().numpy(), case["attns"], rtol=0, atol=1e-5)
+    assert abs(loss.item() - float(case["loss"])) < 1e-4
+    _check_grads(m, case)
+
+
+def test_mha_train_mode_masks_and_dropout_run():
+    from acmil_amd.architecture.transformer import ACMIL_MHA
+    from oracle import mha_oracle as MO
+    sd = MO.default_state_dict(384, 128, 2, 2, seed=1)
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 384, 128, 2, 2
+    m = ACMIL_MHA(Conf, n_token=2, n_masked_patch=10, mask_drop=0.6)
+    m.load_state_dict(sd); m = m.cuda().train()
+    sub, slide, attns = m(torch.randn(1, 300, 384, device="cuda"))
+    assert attns.shape == (8, 2, 300) and int((attns == -1e9).sum()) == 8 * 2 * 6      # 6 of the top-10 masked per row
+    (sub.sum() + slide.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_dtfd_block_gradients_match_reference():
+    from acmil_amd.architecture.Attention import Attention_with_Classifier
+    case, sd = load_golden("train_dtfd_n500_l256_k3_c4")
+    m = Attention_with_Classifier(L=256, D=128, K=3, num_cls=4)
+    m.load_state_dict(sd); m = m.cuda().train()
+    pred = m(torch.from_numpy(case["x"]).cuda())
+    loss = F.cross_entropy(pred, torch.tensor([0, 3, 1]).cuda())
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), case["pred"], rtol=0, atol=1e-4)
+    _check_grads(m, case)
+
+
+def test_ibmil_gradients_match_reference():
+    from acmil_amd.architecture.ibmil import IBMIL
+    case, sd = load_golden("train_ibmil_n600_d384_c2")
+
+    class Conf:
+        D_feat, D_inner, n_class, c_path = 384, 128, 2, None
+    m = IBMIL(Conf)
+    m.load_state_dict(sd); m = m.cuda().train()
+    y, mm, a = m(torch.from_numpy(case["x"]).cuda())
+    loss = F.cross_entropy(y, torch.tensor([1]).cuda()) + 0.01 * mm.sum() + 10.0 * (a * a).sum()
+    loss.backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), case["Y_prob"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(a.detach().cpu().numpy(), case["A"], rtol=0, atol=1e-6)
+    assert abs(loss.item() - float(case["loss"])) < 1e-4
+    _check_grads(m, case)
