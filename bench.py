@@ -105,13 +105,13 @@ def other_workloads(args):
     from acmil_amd import _lib
     _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
     if args.workload == "transmil":
-        from oracle import transmil_oracle as TO
+        from acmil_amd import synthetic as S
         from acmil_amd.architecture.transMIL import TransMIL
         N, D, Di, C = 100000, 768, 384, 2
 
         class Conf:
             D_feat, D_inner, n_class = D, Di, C
-        sd = TO.default_state_dict(D, Di, C, seed=1)
+        sd = S.transmil_state_dict(D, Di, C, seed=1)
         model = TransMIL(Conf)
         model.load_state_dict(sd)
         model = model.to(dev).eval()
@@ -138,6 +138,7 @@ def other_workloads(args):
                                  "fp32 MFMA (the parity arithmetic); compulsory input %.0f MB" % (flops / 1e9, nbytes / 1e6)},
         }
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import transmil_oracle as TO          # the oracle is only ever the CPU baseline / checker
             x = bags[0].cpu()
             t0 = time.perf_counter()
             ref = TO.transmil_forward(x, sd)
@@ -151,8 +152,8 @@ def other_workloads(args):
             print(json.dumps(result))
         return
     # ---- training step (configs[4]): one bag per rank per step, fused HIP forward/loss/backward, ONE flat-bucket all-reduce, AdamW
+    from acmil_amd import synthetic as S
     from acmil_amd import train as T
-    from oracle import ga_oracle as O
     N, C = args.train_n, 7
     conf = T.Struct(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, n_class=C, n_token=N_TOKEN, n_masked_patch=10,
                     mask_drop=0.6, arch="ga", precision=args.precision, seed=1, D_feat=D_FEAT, D_inner=D_INNER)
@@ -161,7 +162,7 @@ def other_workloads(args):
     T.broadcast_parameters(model, world)
     bucket = T.GradBucket(list(model.parameters()))
     opt = torch.optim.AdamW(model.parameters(), lr=conf.lr, weight_decay=conf.wd, fused=True)   # one multi-tensor kernel
-    bags = [O.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
+    bags = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
 
     def step(i):
@@ -187,6 +188,7 @@ def other_workloads(args):
                      "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ga_oracle as O                     # the oracle is only ever the CPU baseline / checker
         sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
         xs = [b.float().cpu() for b in bags[:2]]
         torch.set_num_threads(min(16, torch.get_num_threads()))
@@ -247,10 +249,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from acmil_amd import _lib, ops
-    from oracle import ga_oracle as O
+    from acmil_amd import synthetic as S
 
     _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
-    sd_cpu = O.default_state_dict(D_FEAT, D_INNER, N_CLASS, N_TOKEN, seed=0)
+    sd_cpu = S.ga_state_dict(D_FEAT, D_INNER, N_CLASS, N_TOKEN, seed=0)
     sd = {k: v.to(dev) for k, v in sd_cpu.items()}
     packed, dims = ops.ga_pack_weights(
         sd["dimreduction.fc1.weight"], sd["attention.attention_V.0.weight"], sd["attention.attention_V.0.bias"],
@@ -260,7 +262,7 @@ def main():
         [sd["classifier.%d.fc.bias" % i] for i in range(N_TOKEN)],
         sd["Slide_classifier.fc.weight"], sd["Slide_classifier.fc.bias"], args.precision)
     # resident synthetic bags: slide index = rank * N_BAGS + i (disjoint across ranks)
-    bags = [O.synthetic_bag(N_PATCH, D_FEAT, slide_idx=rank * N_BAGS + i)[0].to(dev) for i in range(N_BAGS)]
+    bags = [S.synthetic_bag(N_PATCH, D_FEAT, slide_idx=rank * N_BAGS + i)[0].to(dev) for i in range(N_BAGS)]
     torch.cuda.synchronize()
 
     B = max(1, min(16, args.batch))
@@ -370,6 +372,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference's PyTorch-CPU forward), host cores of this box, rank 0, N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ga_oracle as O                     # the oracle is only ever the CPU baseline / checker
         all_cores = torch.get_num_threads()
         xs = [b.cpu().unsqueeze(0) for b in bags[:4]]
 

@@ -166,39 +166,12 @@ def adjust_learning_rate(epoch: float, lr: float, min_lr: float, warmup_epoch: f
 
 
 # --------------------------------------------------------------------------- helpers for tests / bench
-def default_state_dict(d_feat: int, d_inner: int, n_class: int, n_token: int, d_attn: int = 128,
-                       seed: int = 0, abmil: bool = False) -> Dict[str, Tensor]:
-    """Weights with torch's default nn.Linear init (kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in),
-    +1/sqrt(fan_in)) for weight and bias), which is what the reference modules use (no custom
-    init on this path).  Deterministic in `seed`; NOT draw-for-draw identical to
-    constructing the reference module (golden fixtures carry the reference's own weights)."""
-    g = torch.Generator().manual_seed(seed)
-
-    def lin(out_f, in_f, bias=True):
-        bound = 1.0 / math.sqrt(in_f)
-        w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
-        b = (torch.rand(out_f, generator=g) * 2 - 1) * bound if bias else None
-        return w, b
-
-    sd: Dict[str, Tensor] = {}
-    sd["dimreduction.fc1.weight"], _ = lin(d_inner, d_feat, bias=False)
-    sd["attention.attention_V.0.weight"], sd["attention.attention_V.0.bias"] = lin(d_attn, d_inner)
-    sd["attention.attention_U.0.weight"], sd["attention.attention_U.0.bias"] = lin(d_attn, d_inner)
-    sd["attention.attention_weights.weight"], sd["attention.attention_weights.bias"] = lin(n_token, d_attn)
-    if abmil:
-        sd["classifier.fc.weight"], sd["classifier.fc.bias"] = lin(n_class, d_inner)
-    else:
-        for i in range(n_token):
-            sd["classifier.%d.fc.weight" % i], sd["classifier.%d.fc.bias" % i] = lin(n_class, d_inner)
-        sd["Slide_classifier.fc.weight"], sd["Slide_classifier.fc.bias"] = lin(n_class, d_inner)
-    return sd
+def default_state_dict(*args, **kwargs) -> Dict[str, Tensor]:
+    """Synthetic GA / ABMIL parameters (generator shared with the benchmarks: acmil_amd/synthetic.py)."""
+    from acmil_amd.synthetic import ga_state_dict
+    return ga_state_dict(*args, **kwargs)
 
 
-def synthetic_bag(n: int, d: int, slide_idx: int = 0, fp16_exact: bool = False) -> Tensor:
-    """Synthetic bag of SURVEY.md 8(d): randn(N,D) fp32 from manual_seed(1000+slide_idx);
-    the data-faithful variant rounds through fp16 (what Step2 stores, Step2_feature_extract.py:165)."""
-    g = torch.Generator().manual_seed(1000 + slide_idx)
-    x = torch.randn(n, d, generator=g)
-    if fp16_exact:
-        x = x.half().float()
-    return x.unsqueeze(0)
+def synthetic_bag(*args, **kwargs) -> Tensor:
+    from acmil_amd.synthetic import synthetic_bag as _bag
+    return _bag(*args, **kwargs)

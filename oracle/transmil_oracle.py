@@ -114,22 +114,7 @@ def transmil_forward(x: Tensor, sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
     return {"logits": logits, "h1": h1, "hp": hp, "h2": h2}
 
 
-def default_state_dict(d_feat: int, d_inner: int, n_class: int, seed: int = 0) -> Dict[str, Tensor]:
-    """Random weights with the shapes / init families of the reference modules (nn.Linear / nn.Conv2d defaults,
-    LayerNorm ones/zeros, cls_token ~ randn).  Deterministic in `seed`; not draw-identical to the reference ctor."""
-    g = torch.Generator().manual_seed(seed)
-    u = lambda shape, bound: (torch.rand(*shape, generator=g) * 2 - 1) * bound
-    sd: Dict[str, Tensor] = {}
-    sd["_fc1.0.weight"], sd["_fc1.0.bias"] = u((d_inner, d_feat), d_feat ** -0.5), u((d_inner,), d_feat ** -0.5)
-    sd["cls_token"] = torch.randn(1, 1, d_inner, generator=g)
-    for name, ksz in (("pos_layer.proj", 7), ("pos_layer.proj1", 5), ("pos_layer.proj2", 3)):
-        bound = (ksz * ksz) ** -0.5
-        sd[name + ".weight"], sd[name + ".bias"] = u((d_inner, 1, ksz, ksz), bound), u((d_inner,), bound)
-    for layer in ("layer1", "layer2"):
-        sd[layer + ".norm.weight"], sd[layer + ".norm.bias"] = torch.ones(d_inner), torch.zeros(d_inner)
-        sd[layer + ".attn.to_qkv.weight"] = u((3 * d_inner, d_inner), d_inner ** -0.5)
-        sd[layer + ".attn.to_out.0.weight"], sd[layer + ".attn.to_out.0.bias"] = u((d_inner, d_inner), d_inner ** -0.5), u((d_inner,), d_inner ** -0.5)
-        sd[layer + ".attn.res_conv.weight"] = u((HEADS, 1, RES_KERNEL, 1), RES_KERNEL ** -0.5)
-    sd["norm.weight"], sd["norm.bias"] = torch.ones(d_inner), torch.zeros(d_inner)
-    sd["_fc2.weight"], sd["_fc2.bias"] = u((n_class, d_inner), d_inner ** -0.5), u((n_class,), d_inner ** -0.5)
-    return sd
+def default_state_dict(*args, **kwargs) -> Dict[str, Tensor]:
+    """Synthetic TransMIL parameters (generator shared with the benchmarks: acmil_amd/synthetic.py)."""
+    from acmil_amd.synthetic import transmil_state_dict
+    return transmil_state_dict(*args, **kwargs)
