@@ -214,7 +214,18 @@ __global__ __launch_bounds__(256) void ga_bwd_reduce_kernel(const float* __restr
 
 static size_t gb_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, gemm, total; };
+// [Wv; Wu] -> one [2 Da, Di] matrix and [bv; bu] -> [2 Da] (so the three products with the attention weights are single GEMMs),
+// and the inverse split of the concatenated weight gradient
+__global__ __launch_bounds__(256) void gb_concat_kernel(const float* __restrict__ Wv, const float* __restrict__ Wu, const float* __restrict__ bv,
+                                                       const float* __restrict__ bu, int per, float* __restrict__ Wcat, float* __restrict__ bcat) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * per; e += gridDim.x * 256) Wcat[e] = e < per ? Wv[e] : Wu[e - per];
+    if (blockIdx.x == 0 && threadIdx.x < 2 * GA_DA) bcat[threadIdx.x] = threadIdx.x < GA_DA ? bv[threadIdx.x] : bu[threadIdx.x - GA_DA];
+}
+__global__ __launch_bounds__(256) void gb_split_kernel(const float* __restrict__ dWcat, int per, float* __restrict__ dWv, float* __restrict__ dWu) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * per; e += gridDim.x * 256) (e < per ? dWv : dWu)[e < per ? e : e - per] = dWcat[e];
+}
+
+struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, total; };
 
 static GbWs gb_layout(int N, int D, int Di, int K) {
     GbWs w; size_t off = 0;
@@ -225,8 +236,11 @@ static GbWs gb_layout(int N, int D, int Di, int K) {
     w.ck = off;      off += 256;
     w.stats = off;   off += 256;
     w.part = off;    off += gb_align((size_t)GB_GATE_BLOCKS * (KP * GA_DA + KP + 2 * GA_DA) * 4);
+    w.wcat = off;    off += gb_align((size_t)2 * GA_DA * Di * 4);     // [Wv; Wu] as one [2 Da, Di] matrix
+    w.bcat = off;    off += gb_align((size_t)2 * GA_DA * 4);
+    w.dwcat = off;   off += gb_align((size_t)2 * GA_DA * Di * 4);
     size_t g = acmil_gemm_workspace_bytes(Di, D, N, 1);
-    size_t g2 = acmil_gemm_workspace_bytes(GA_DA, Di, N, 1);
+    size_t g2 = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1);
     w.gemm = off;    off += gb_align(g > g2 ? g : g2);
     w.total = off;
     return w;
@@ -268,6 +282,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     float* stats = (float*)(ws + L.stats);
     float* part = (float*)(ws + L.part);
     void* gws = ws + L.gemm;
+    float* Wcat = (float*)(ws + L.wcat); float* bcat = (float*)(ws + L.bcat); float* dWcat = (float*)(ws + L.dwcat);
 
     // 1 heads
     GaBwdHeadArgs ha;
@@ -281,12 +296,10 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     // 2 stats
     hipLaunchKernelGGL(ga_bwd_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // 3 G = h [Wv;Wu]^T + [bv;bu]
-    rc = gemm_fwd(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bv, 0,
-                        nullptr, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
-    rc = gemm_fwd(0, 1, N, GA_DA, Di, 1.0f, h, Di, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 0.0f, G + GA_DA, 2 * GA_DA, 0, bu,
-                        0, nullptr, 1, gws, st);
+    // 3 G = h [Wv;Wu]^T + [bv;bu]   (one GEMM on the concatenated weights)
+    hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, Wv, Wu, bv, bu, GA_DA * Di, Wcat, bcat);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    rc = gemm_fwd(0, 1, N, 2 * GA_DA, Di, 1.0f, h, Di, 0, Wcat, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bcat, 0, nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
     // 4 gate pass
     GaBwdGateArgs ga;
@@ -301,20 +314,14 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     else return ACMIL_ERR_UNSUPPORTED;
 #undef GB_LAUNCH_GATE
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // 5 dpre = (dh0 + dGv Wv + dGu Wu) * [h > 0]
-    rc = gemm_grad(0, 0, N, Di, GA_DA, 1.0f, G, 2 * GA_DA, 0, Wv, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 0,
-                        nullptr, 1, gws, st);
+    // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
+    rc = gemm_grad(0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, 0, Wcat, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 2, h, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    rc = gemm_grad(0, 0, N, Di, GA_DA, 1.0f, G + GA_DA, 2 * GA_DA, 0, Wu, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0,
-                        nullptr, 2, h, 1, gws, st);
+    // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
+    rc = gemm_grad(1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWcat, Di, 0, nullptr, 0, nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
-    // 6 weight gradients (contraction over the N patches, split-K)
-    rc = gemm_grad(1, 0, GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWv, Di, 0, nullptr, 0,
-                        nullptr, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
-    rc = gemm_grad(1, 0, GA_DA, Di, N, 1.0f, G + GA_DA, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWu, Di, 0,
-                        nullptr, 0, nullptr, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
+    hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, dWcat, GA_DA * Di, dWv, dWu);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     rc = gemm_grad(1, 0, Di, D, N, 1.0f, dpre, Di, 0, x, x_dtype, D, 0, 0.0f, dW1, D, 0, nullptr, 0, nullptr, 1, gws,
                         st);
     if (rc != ACMIL_OK) return rc;
