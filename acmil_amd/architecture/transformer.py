@@ -102,6 +102,10 @@ class _GatedBase(nn.Module):
             self._pack_cache = cache
         return cache[1], cache[2]
 
+    def invalidate_packed(self):
+        """Drop the packed-weight cache (for optimizers that update the parameters outside torch's version counters)."""
+        self._pack_cache = None
+
     def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
         """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
         n = xb.shape[0]

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gl_gram_kernel(const float* __restrict__ 
 // one workgroup: reduce Gram partials (fixed order), cross-entropy terms, loss values, coefficient table for the elementwise pass
 // coef[i][j] (i != j) = c / (n_i n_j) ; coef[i][i] = -c * sum_{j != i} S_ij / (n_i^3 n_j)
 template <int KP>
-__global__ __launch_bounds__(256) void gl_scalar_kernel(const float* __restrict__ part, int nblocks, int K, int C,
+__global__ __launch_bounds__(1024) void gl_scalar_kernel(const float* __restrict__ part, int nblocks, int K, int C,
                                                        const float* __restrict__ sub, const float* __restrict__ slide,
                                                        const int64_t* __restrict__ label, float* __restrict__ losses,
                                                        float* __restrict__ d_sub, float* __restrict__ d_slide,
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(256) void gl_scalar_kernel(const float* __restrict_
     // logits -> LDS with one parallel load (thread 0 below would otherwise chain ~40 dependent global loads)
     if (tid < K * C) lsub[tid] = sub[tid];
     if (slide && tid < C) lslide[tid] = slide[tid];
-    // wave w reduces Gram entries w, w+4, ...: lanes stride the block partials, then a fixed shuffle tree
-    for (int e = wave; e < KP * KP; e += 4) {
+    // wave w reduces Gram entries w, w+16, ...: lanes stride the block partials, then a fixed shuffle tree
+    for (int e = wave; e < KP * KP; e += 16) {
         float s = 0.0f;
         for (int b = lane; b < nblocks; b += 64) s += part[(size_t)b * KP * KP + e];
 #pragma unroll
@@ -189,11 +189,11 @@ extern "C" int acmil_ga_loss(const float* sub_preds, const float* slide_pred, co
     hipLaunchKernelGGL(gl_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (KP == 1) {
         hipLaunchKernelGGL(gl_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, part);
-        hipLaunchKernelGGL(gl_scalar_kernel<1>, dim3(1), dim3(256), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
+        hipLaunchKernelGGL(gl_scalar_kernel<1>, dim3(1), dim3(1024), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
         hipLaunchKernelGGL(gl_dA_kernel<1>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, coef, d_A);
     } else if (KP == 5) {
         hipLaunchKernelGGL(gl_gram_kernel<5>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, part);
-        hipLaunchKernelGGL(gl_scalar_kernel<5>, dim3(1), dim3(256), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
+        hipLaunchKernelGGL(gl_scalar_kernel<5>, dim3(1), dim3(1024), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
         hipLaunchKernelGGL(gl_dA_kernel<5>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, coef, d_A);
     } else return ACMIL_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;

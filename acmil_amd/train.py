@@ -289,6 +289,17 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     return auroc, acc, f1, loss
 
 
+def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, lr: float = 0.001):
+    """AdamW as in Step3_WSI_classification_ACMIL.py:139.  On the GPU: acmil_amd.optim.FlatAdamW (same update rule, parameters /
+    gradients / moments in flat buffers, ONE launch per step; shares the DP gradient bucket); on CPU (gloo tests): torch's."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    if device.type == "cuda" and not getattr(conf, "torch_optimizer", False):
+        from .optim import FlatAdamW
+        return FlatAdamW(params, lr=lr, weight_decay=conf.wd, grad_buffer=None if bucket is None else bucket.flat,
+                         on_step=getattr(model, "invalidate_packed", None))
+    return torch.optim.AdamW(params, lr=lr, weight_decay=conf.wd)
+
+
 def build_model(conf):
     from .architecture.transformer import ABMIL, ACMIL_GA
     if conf.arch == "ga":
@@ -351,9 +362,8 @@ def main(argv=None):
     broadcast_parameters(model, world)
     # same update rule as the reference's torch.optim.AdamW (Step3_WSI_classification_ACMIL.py:139); fused=True runs it as ONE
     # multi-tensor kernel instead of ~10 foreach launches (the training step is launch-bound at small bags)
-    optimizer = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=0.001, weight_decay=conf.wd,
-                                  fused=(device.type == "cuda"))
     bucket = GradBucket(list(model.parameters())) if world > 1 else None
+    optimizer = make_optimizer(model, conf, device, bucket)
     os.makedirs(conf.out_dir, exist_ok=True)
     best = {"epoch": -1, "val_acc": 0, "val_auc": 0, "val_f1": 0, "test_acc": 0, "test_auc": 0, "test_f1": 0}
     for epoch in range(conf.train_epoch):

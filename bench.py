@@ -161,7 +161,7 @@ def other_workloads(args):
     model = T.build_model(conf).to(dev).train()
     T.broadcast_parameters(model, world)
     bucket = T.GradBucket(list(model.parameters()))
-    opt = torch.optim.AdamW(model.parameters(), lr=conf.lr, weight_decay=conf.wd, fused=True)   # one multi-tensor kernel
+    opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)          # FlatAdamW: one launch, shares the gradient bucket
     bags = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
 

@@ -285,6 +285,12 @@ int acmil_colsum(const float* x, long long rows, int cols, float* out, void* wor
 int acmil_gate_fwd(const float* G, float* y, long long N, int Da, void* stream);
 int acmil_gate_bwd(const float* G, const float* dy, float* dG, long long N, int Da, void* stream);
 
+/* AdamW over one flat fp32 buffer (params, grads, both moments contiguous, n elements), torch.optim.AdamW update rule with
+ * decoupled weight decay -- the optimizer.step() of Step3_WSI_classification_ACMIL.py:139,219 as ONE launch.
+ * bias_correction{1,2} = 1 - beta{1,2}^t for the current step t >= 1 (computed by the caller). */
+int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

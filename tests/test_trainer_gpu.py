@@ -56,3 +56,25 @@ def test_single_head_archs_train(arch):
     assert last["slide_loss"] == last["slide_loss"] and last["slide_loss"] < first["slide_loss"], (first, last)
     auroc, acc, f1, loss = T.evaluate(model, train, device, conf, "Train")
     assert 0.0 <= auroc <= 1.0 and loss == loss
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """acmil_amd.optim.FlatAdamW (one launch over flat buffers) against torch.optim.AdamW over 25 steps with a varying lr."""
+    from acmil_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(256, 512), (128,), (5, 128), (7, 256), (1,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g).cuda()) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, lr=1e-3, weight_decay=1e-2)
+    mine = FlatAdamW(my_p, lr=1e-3, weight_decay=1e-2)
+    for step in range(25):
+        lr = 1e-3 * (0.5 + 0.5 * (step % 5) / 5)
+        ref.param_groups[0]["lr"] = lr; mine.param_groups[0]["lr"] = lr
+        for a, b in zip(ref_p, my_p):
+            grad = torch.randn(a.shape, generator=g).cuda() * (10.0 ** (-(step % 4)))
+            a.grad = grad.clone(); b.grad.copy_(grad)
+        ref.step(); mine.step()
+    for a, b in zip(ref_p, my_p):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    sd = mine.state_dict()
+    assert sd["step"] == 25 and sd["exp_avg"].numel() == sum(p.numel() for p in my_p)

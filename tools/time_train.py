@@ -9,7 +9,7 @@ conf = T.Struct(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, n_cl
                 mask_drop=0.6, arch="ga", precision=args.precision, seed=1, D_feat=512, D_inner=256)
 dev = torch.device("cuda", 0)
 model = T.build_model(conf).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-5, fused=True)
+opt = T.make_optimizer(model, conf, dev, None, lr=1e-4)
 xs = [torch.randn(1, args.n, 512, device=dev).half() for _ in range(8)]
 y = torch.tensor([1], device=dev)
 import os as _os
