@@ -335,7 +335,7 @@ def get_arguments(argv=None):
 
 def main(argv=None):
     args = get_arguments(argv)
-    c = dict(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, dataset="synthetic", B=1, n_class=2)
+    c = dict(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, dataset="synthetic", B=1, n_class=2, data_dir=None, config=None)
     if args.config:
         import yaml
         with open(args.config) as f:
@@ -360,14 +360,12 @@ def main(argv=None):
         train, val, test = mk(conf.synthetic_slides, 1), mk(max(8, conf.synthetic_slides // 4), 2), mk(max(8, conf.synthetic_slides // 4), 3)
     model = build_model(conf).to(device)
     broadcast_parameters(model, world)
-    # same update rule as the reference's torch.optim.AdamW (Step3_WSI_classification_ACMIL.py:139); fused=True runs it as ONE
-    # multi-tensor kernel instead of ~10 foreach launches (the training step is launch-bound at small bags)
     bucket = GradBucket(list(model.parameters())) if world > 1 else None
     optimizer = make_optimizer(model, conf, device, bucket)
     os.makedirs(conf.out_dir, exist_ok=True)
     best = {"epoch": -1, "val_acc": 0, "val_auc": 0, "val_f1": 0, "test_acc": 0, "test_auc": 0, "test_f1": 0}
     for epoch in range(conf.train_epoch):
-        train_one_epoch(model, train, optimizer, device, epoch, conf, bucket, rank, world)
+        train_one_epoch(model, train, optimizer, device, epoch, conf, bucket, rank, world, fused=hasattr(model, "train_step"))
         val_auc, val_acc, val_f1, _ = evaluate(model, val, device, conf, "Val", rank, world)
         test_auc, test_acc, test_f1, _ = evaluate(model, test, device, conf, "Test", rank, world)
         if val_f1 + val_auc > best["val_f1"] + best["val_auc"]:

@@ -78,3 +78,13 @@ def test_flat_adamw_matches_torch_adamw():
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
     sd = mine.state_dict()
     assert sd["step"] == 25 and sd["exp_avg"].numel() == sum(p.numel() for p in my_p)
+
+
+@pytest.mark.parametrize("arch,extra", [("ga", ["--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"]), ("transmil", [])])
+def test_trainer_main_end_to_end(arch, extra, tmp_path):
+    """python -m acmil_amd.train equivalent: synthetic bags, two epochs, checkpoints written (Step3-style main)."""
+    from acmil_amd import train as T
+    out = str(tmp_path / arch)
+    T.main(["--arch", arch, "--synthetic_slides", "16", "--synthetic_patches", "600", "--train_epoch", "2", "--out_dir", out] + extra)
+    ck = torch.load(os.path.join(out, "checkpoint-last.pth"), weights_only=False)
+    assert set(ck) >= {"model", "optimizer", "epoch", "config"} and ck["epoch"] == 1
