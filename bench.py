@@ -304,6 +304,24 @@ def main():
         torch.cuda.synchronize()
         ms_b1 = (time.perf_counter() - t1) / n_lat * 1e3
 
+    # ---- data-faithful variant: the same bags as they are stored on disk, fp16 (Step2_feature_extract.py:165);
+    # the kernel converts in registers and the x_lo product vanishes.  Reported next to the fp32-bag headline, never as `value`.
+    sps_fp16 = None
+    if not args.no_b1 and world == 1:
+        bags16 = [b.half() for b in bags]
+        step16 = lambda i: ops.ga_forward_batch([bags16[(i * B + j) % N_BAGS] for j in range(B)], packed, dims, args.precision) \
+            if B > 1 else ops.ga_forward(bags16[i % N_BAGS], packed, dims, args.precision)
+        for i in range(5):
+            step16(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n16 = max(20, args.steps // 2)
+        for i in range(n16):
+            step16(i)
+        torch.cuda.synchronize()
+        sps_fp16 = n16 * B / (time.perf_counter() - t2)
+        del bags16
+
     # ---- dominant kernel alone (ga_fwd_kernel, same template instance): scores-only calls launch just it
     n_k = max(50, min(args.steps, 400))
     ws = torch.empty(_lib.load().acmil_ga_workspace_bytes(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, ops.mode_id(args.precision)),
@@ -367,6 +385,7 @@ def main():
                    "precision": args.precision, "slides_per_step": B, "sharding": "independent slides per GPU, no collective"},
         "attention_fwd_ms_per_slide": round(dt / (args.steps * B) * 1e3, 4),
         "attention_fwd_ms_per_slide_b1": None if ms_b1 is None else round(ms_b1, 4),
+        "slides_per_s_fp16_stored_bags": None if sps_fp16 is None else round(sps_fp16, 1),
         "roofline": roofline,
     }
 
