@@ -112,6 +112,7 @@ __device__ __forceinline__ void gm_store_tile(float* S, bool contig_is_k, int ti
 
 // act: 0 none, 1 relu, 2 relu-backward mask (v if aux[row][col] > 0 else 0; aux has C's leading dimension),
 //      3 "c I - P": out = (row == col ? beta : 0) - alpha * P   (beta is the diagonal constant, not an accumulate factor)
+//      4 both: out = alpha * P and aux (written, same layout as C) = beta I - alpha * P
 __device__ __forceinline__ float gm_act(float v, int act, const float* aux, long long idx) {
     if (act == 1) return fmaxf(v, 0.0f);
     if (act == 2) return aux[idx] > 0.0f ? v : 0.0f;
@@ -140,6 +141,11 @@ __device__ __forceinline__ void gm_epilogue(const GemmArgs& g, const f32x16 (&ac
                 float* dst = Cb + (long long)row * ldc + col;
                 if (g.splits > 1) *dst = acc[a][b][r];
                 else if (g.act == 3) *dst = (row == col ? g.beta : 0.0f) - g.alpha * acc[a][b][r];
+                else if (g.act == 4) {   // two outputs: C = alpha P and aux = beta I - alpha P (aux is written, C's layout)
+                    const float pv = g.alpha * acc[a][b][r];
+                    *dst = pv;
+                    const_cast<float*>(g.aux)[(long long)batch * g.sC + (long long)row * ldc + col] = (row == col ? g.beta : 0.0f) - pv;
+                }
                 else {
                     float v = g.alpha * acc[a][b][r] + bias;
                     if (g.beta != 0.0f) v += g.beta * *dst;
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
         const long long idx = (long long)row * g.ldc + col;
         float* dst = g.C + (long long)b * g.sC + idx;
         if (g.act == 3) { *dst = (row == col ? g.beta : 0.0f) - g.alpha * s; continue; }
+        if (g.act == 4) { *dst = g.alpha * s; const_cast<float*>(g.aux)[(long long)b * g.sC + idx] = (row == col ? g.beta : 0.0f) - g.alpha * s; continue; }
         if (g.beta != 0.0f) v += g.beta * *dst;
         *dst = gm_act(v, g.act, g.aux + (long long)b * g.sC, idx);
     }
@@ -430,8 +437,8 @@ static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alp
                   int batch, void* workspace, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
     if (!A || !B || !C) return ACMIL_ERR_NULL;
-    if (act < 0 || act > 3) return ACMIL_ERR_UNSUPPORTED;
-    if (act == 2 && !aux) return ACMIL_ERR_NULL;
+    if (act < 0 || act > 4) return ACMIL_ERR_UNSUPPORTED;
+    if ((act == 2 || act == 4) && !aux) return ACMIL_ERR_NULL;
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.ws = (float*)workspace;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -356,14 +356,6 @@ static bool tm_pinv_x3() { static const bool v = getenv("ACMIL_TM_PINV_X3") != n
 #define TM_PINV_GEMM(...) do { int rc_ = tm_pinv_x3() ? acmil_gemm_f16x3(__VA_ARGS__) : acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 #define TM_LINEAR(...) do { int rc_ = tm_linear_exact() ? acmil_gemm_f32(__VA_ARGS__) : acmil_gemm_f16x3(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
-// out = c I - P for a batch of m x m matrices (first bracket of the Moore-Penrose iteration, nystrom_attention.py:25)
-__global__ __launch_bounds__(256) void tm_ci_minus_kernel(const float* __restrict__ P, float* __restrict__ out, int m, float c, long long total) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int rc = (int)(e % ((long long)m * m));
-    out[e] = ((rc / m == rc % m) ? c : 0.0f) - P[e];
-}
-
 static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (cols <= 64) hipLaunchKernelGGL(tm_softmax_short_kernel<1>, dim3(blocks), dim3(256), 0, st, x, rows, cols);
@@ -418,9 +410,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     for (int it = 0; it < 6; ++it) {
         float* spare = (zc == Z) ? T2 : Z;
         // xz = x z ; t1 = 7I - xz ; t = 15I - xz t1 ; t1 = 13I - xz t ; z' = 0.25 z t1
-        TM_PINV_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 0.0f, XZ, m, mm, nullptr, 0, nullptr, H, gws, st);
-        hipLaunchKernelGGL(tm_ci_minus_kernel, dim3((unsigned)((H * mm + 255) / 256)), dim3(256), 0, st, XZ, T1, m, 7.0f, (long long)H * mm);
-        TM_CHECK_LAUNCH();
+        TM_PINV_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 7.0f, XZ, m, mm, nullptr, 4, T1, H, gws, st);   // + t1 = 7I - xz
         TM_PINV_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 15.0f, spare, m, mm, nullptr, 3, nullptr, H, gws, st);
         TM_PINV_GEMM(0, 0, m, m, m, 1.0f, XZ, m, mm, spare, ACMIL_DTYPE_F32, m, mm, 13.0f, T1, m, mm, nullptr, 3, nullptr, H, gws, st);
         TM_PINV_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);

@@ -131,7 +131,8 @@ int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const fl
  *   C[b] = act( alpha * op(A[b]) * op(B[b]) + bias[col] + beta * C[b] ),  op(A) M x K, op(B) K x N.
  * Stands in for the aten::mm / addmm / bmm calls of the reference's backward (autograd of
  * architecture/transformer.py:305-330) and of TransMIL (architecture/transMIL.py, nystrom_attention.py).
- * B may be fp32/fp16/bf16 (b_dtype).  act: 0 none, 1 relu, 2 relu-backward mask by aux (same layout as C).
+ * B may be fp32/fp16/bf16 (b_dtype).  act: 0 none, 1 relu, 2 relu-backward mask by aux (same layout as C),
+ * 3 C = beta I - alpha P (beta = diagonal constant), 4 C = alpha P and aux (WRITTEN, same layout as C) = beta I - alpha P.
  * Tall-K products are split along K into `workspace` (acmil_gemm_workspace_bytes) and reduced in a fixed order.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
