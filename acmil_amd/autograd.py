@@ -1,4 +1,5 @@
-"""torch.autograd Functions over the HIP ops: the building blocks of the TRAINING path of the TransMIL / Nystrom module.
+"""torch.autograd Functions over the HIP ops: the building blocks of the TRAINING paths of TransMIL, ACMIL_MHA, the DTFD
+attention blocks and IBMIL (ACMIL_GA / ABMIL have their own fused backward: csrc/ga_backward.hip).
 
 Each Function's forward and backward are C-ABI kernels (csrc/gemm_f32.hip, csrc/transmil_train.hip, csrc/attn_generic.hip);
 autograd only sequences them and handles views / concatenation.  No torch math kernel runs over an O(N) tensor except
@@ -11,6 +12,8 @@ copies (cat / pad / slicing / `+`) and the dropout mask.  CUDA fp32 tensors only
   seq_conv(v, w)                 Conv2d(8, 8, (33,1), groups=8)       -> acmil_seqconv/_bwd_w
   dwconv7(x, weff, beff, side)   folded PPEG depth-wise stencil       -> acmil_dwconv7/_bwd_w
   landmark_mean(src, l)          reduce(..., 'sum') / l               -> acmil_landmark_mean/_bwd
+  gated_scores(h, ...)           Attention_Gated / Attn_Net_Gated     -> linear x3 + acmil_gate_fwd/_bwd
+  attn_pool(h, A)                softmax over N, then P @ h           -> softmax_rows + matmul
 """
 from __future__ import annotations
 
