@@ -65,3 +65,30 @@ def test_pinv_iteration_matches_reference_golden():
         t3 = ops.gemm(xz, t2, act=3, beta=13.0, out=torch.empty_like(xz))
         zc = ops.gemm(zc, t3, alpha=0.25)
     np.testing.assert_allclose(zc.cpu().numpy(), z["z"][0], rtol=0, atol=2e-5)
+
+
+def _tm_cases(seed, count):
+    import random
+    rng = random.Random(seed)
+    out = []
+    for _ in range(count):
+        di = rng.choice([128, 256, 384, 512])
+        n = rng.choice([1, 2, 3, 8, 63, 64, 65, di // 2 - 1, di // 2, di // 2 + 1, 1023, 1024]) if rng.random() < 0.5 else rng.randint(1, 4000)
+        out.append((n, rng.choice([384, 512, 768]), di, rng.randint(2, 5)))
+    return out
+
+
+@pytest.mark.parametrize("n,d,di,c", _tm_cases(7, 14))
+def test_random_shapes_vs_oracle(n, d, di, c):
+    """Seeded sweep over bag sizes around every padding edge (n < m, n % m, square-grid wrap) and all fused widths."""
+    from oracle import transmil_oracle as TO
+    sd = TO.default_state_dict(d, di, c, seed=n + di)
+    x = torch.randn(1, n, d, generator=torch.Generator().manual_seed(n + 1))
+    ref = TO.transmil_forward(x, sd)
+    model = _model(sd, d, di, c)
+    with torch.no_grad():
+        logits = model(x.cuda(), debug=True)
+    assert torch.isfinite(logits).all()
+    assert (model._last["h1"].cpu() - ref["h1"][0]).abs().max() < 1e-4
+    assert (model._last["h2"].cpu() - ref["h2"][0]).abs().max() < 1e-4
+    assert (logits.cpu() - ref["logits"]).abs().max() < 1e-4
