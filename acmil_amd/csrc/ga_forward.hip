@@ -115,15 +115,22 @@ __global__ __launch_bounds__(1024) void ga_heads_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-#define GA_FAMILY(ND, KP, MODE) int ga_fwd_family_##ND##_##KP##_##MODE(const GaFwdArgs&, int, bool, hipStream_t);
+#define GA_FAMILY(ND, KP, MODE) int ga_fwd_family_##ND##_##KP##_##MODE(const GaFwdArgs&, int, bool, int, hipStream_t);
 #include "ga_families.inc"
 #undef GA_FAMILY
+
+// kernel generation of the split-f16 families: 2 = software-pipelined loops (default), 1 = the first-generation kernel.
+// ACMIL_GA_KERNEL=1|2 overrides (A/B measurements); read once.
+static int ga_kernel_version() {
+    static const int v = [] { const char* e = getenv("ACMIL_GA_KERNEL"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    return v;
+}
 
 static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
     const int ND = a.L.ND, K = a.L.K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
 #define GA_FAMILY(ND_, KP_, MODE_) \
-    if (ND == ND_ && KP == KP_ && mode == MODE_) return ga_fwd_family_##ND_##_##KP_##_##MODE_(a, x_dtype, pool, st);
+    if (ND == ND_ && KP == KP_ && mode == MODE_) return ga_fwd_family_##ND_##_##KP_##_##MODE_(a, x_dtype, pool, ga_kernel_version(), st);
 #include "ga_families.inc"
 #undef GA_FAMILY
     return ACMIL_ERR_UNSUPPORTED;

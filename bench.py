@@ -35,20 +35,39 @@ N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, D_ATTN = 50000, 512, 256, 5, 2, 128
 N_BAGS = 16
 
 
-def pmc_traffic(precision, batch):
+def kernel_source_id():
+    """Fingerprint of the fused forward kernel's sources; tools/pmc_ga.py stamps it into every PMC summary it writes."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"):
+        with open(os.path.join(ROOT, "acmil_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def pmc_traffic(workload, precision, batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_pmc_bench_<precision>_b<B>.json, produced by tools/pmc_ga.py: FETCH_SIZE / WRITE_SIZE in their own
+    (profiles/r*_pmc_<workload>_<precision>_b<B>.json, produced by tools/pmc_ga.py: FETCH_SIZE / WRITE_SIZE in their own
     passes, corrected by a known-byte calibration run).  PMC cannot be collected from inside the timed process, so the
-    figure is the recorded one; None when no summary exists for this precision / batch."""
+    figure is the recorded one -- and only if the summary was taken on THIS kernel source (fingerprint match); otherwise
+    None plus the reason."""
     import glob
-    root = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_bench_%s_b%d.json" % (precision, batch))), reverse=True):
+    pats = ["r*_pmc_%s_%s_b%d.json" % (workload, precision, batch)]
+    if workload == "ga_eval":
+        pats.append("r*_pmc_bench_%s_b%d.json" % (precision, batch))      # round-1 naming
+    cands = []
+    for pat in pats:
+        cands += glob.glob(os.path.join(ROOT, "profiles", pat))
+    for f in sorted(cands, key=os.path.basename, reverse=True):
         try:
             with open(f) as fh:
-                return int(json.load(fh)["traffic_bytes_per_launch"])
+                js = json.load(fh)
+            if js.get("kernel_source_id") != kernel_source_id():
+                return None, "PMC summary %s was taken on a different kernel source (%s)" % (os.path.basename(f), js.get("kernel_source_id"))
+            return int(js["traffic_bytes_per_launch"]), os.path.basename(f)
         except Exception:
             continue
-    return None
+    return None, "no PMC summary for this workload / precision / batch under profiles/"
 
 
 def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
@@ -59,36 +78,85 @@ def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
     return nbytes, flops
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_cmd(gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` re-executes itself as when it was NOT started by a launcher:
+    one rank per GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def maybe_self_launch(args, argv):
+    """--gpus N > 1 without a launcher environment: spawn the N ranks ourselves and exit with their status."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(self_launch_cmd(args.gpus, argv), env=env))
+
+
 def _dist_setup(args):
+    """One process per GPU.  Returns (world, rank, device).  --dry-run: CPU + gloo (exercises launcher, rendezvous,
+    barrier and the max-over-ranks reduction in a container without GPUs; no compute, no JSON `value`)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("gloo")
+        return world, rank, dev
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     return world, rank, dev
 
 
+def _sync(world, dev):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def dry_run(args):
+    """Launcher / rendezvous check without a GPU: K empty steps bracketed exactly like the real loop."""
+    world, rank, dev = _dist_setup(args)
+    dt = _timed(lambda i: None, args, world, dev)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "launcher check (no compute)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 6),
+                          "workload": args.workload}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def _timed(step, args, world, dev):
     """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
-    barrier()
+    _sync(world, dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    barrier()
+    _sync(world, dev)
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
@@ -214,39 +282,51 @@ def other_workloads(args):
         print(json.dumps(result))
 
 
-def main():
+# GA eval-forward workloads: the BASELINE.json headline and configs[2]
+GA_SHAPES = {
+    "ga_eval": dict(N=50000, D=512, Di=256, K=5, C=2, xdtype="float32",
+                    metric="slides/sec (ACMIL-ga attention-aggregation forward, N=50000 D=512)"),
+    "ga_cfg3": dict(N=50000, D=384, Di=128, K=5, C=2, xdtype="bfloat16",
+                    metric="slides/sec (ACMIL-ga forward, Camelyon16-shape bags N=50000 D=384 D_inner=128, bf16 bags)"),
+}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"],
-                    help="arithmetic of the two projection GEMMs; both are inside the 1e-4 fp32 parity bound")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16"],
+                    help="arithmetic of the two projection GEMMs; f16x3 and fp32 are inside the 1e-4 fp32 parity bound, "
+                         "f16 (single pass, ~2e-4 on the scores) is a throughput mode and is labelled as such")
     ap.add_argument("--batch", type=int, default=16,
                     help="slides per step: bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
                          "reference's strictly per-slide call pattern")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "transmil", "train"],
-                    help="ga_eval = the BASELINE.json headline (default); transmil = configs[3] (N=100000, D=768 TransMIL eval "
-                         "forward); train = configs[4] (ACMIL training step, slide-level DP, gradient all-reduce)")
+    ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "ga_cfg3", "transmil", "train"],
+                    help="ga_eval = the BASELINE.json headline (default); ga_cfg3 = configs[2] (N=50000, D=384, D_inner=128, bf16 "
+                         "bags); transmil = configs[3] (N=100000, D=768 TransMIL eval forward); train = configs[4] (ACMIL "
+                         "training step, slide-level DP, gradient all-reduce)")
     ap.add_argument("--train-n", type=int, default=10000, help="patches per bag of the train workload")
     ap.add_argument("--no-b1", action="store_true",
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
-    args = ap.parse_args()
-    if args.workload != "ga_eval":
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check on CPU with gloo: no GPU, no compute, no metric value")
+    args = ap.parse_args(argv)
+    maybe_self_launch(args, argv)         # --gpus N > 1 and no launcher: re-execute under torch.distributed.run
+    if args.dry_run:
+        return dry_run(args)
+    if args.workload in ("transmil", "train"):
         return other_workloads(args)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    shape = GA_SHAPES[args.workload]
+    N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS = shape["N"], shape["D"], shape["Di"], shape["K"], shape["C"]
+    x_dtype = getattr(torch, shape["xdtype"])
+    s_in = 4 if x_dtype == torch.float32 else 2
+    world, rank, dev = _dist_setup(args)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
     from acmil_amd import _lib, ops
     from acmil_amd import synthetic as S
@@ -262,7 +342,7 @@ def main():
         [sd["classifier.%d.fc.bias" % i] for i in range(N_TOKEN)],
         sd["Slide_classifier.fc.weight"], sd["Slide_classifier.fc.bias"], args.precision)
     # resident synthetic bags: slide index = rank * N_BAGS + i (disjoint across ranks)
-    bags = [S.synthetic_bag(N_PATCH, D_FEAT, slide_idx=rank * N_BAGS + i)[0].to(dev) for i in range(N_BAGS)]
+    bags = [S.synthetic_bag(N_PATCH, D_FEAT, slide_idx=rank * N_BAGS + i)[0].to(x_dtype).to(dev) for i in range(N_BAGS)]
     torch.cuda.synchronize()
 
     B = max(1, min(16, args.batch))
@@ -272,23 +352,7 @@ def main():
             return ops.ga_forward(bags[i % N_BAGS], packed, dims, args.precision)
         return ops.ga_forward_batch([bags[(i * B + j) % N_BAGS] for j in range(B)], packed, dims, args.precision)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        out = step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = _timed(step, args, world, dev)   # W untimed + exactly K timed steps, barrier + synchronize both sides, max over ranks
     slides_per_s = world * args.steps * B / dt
 
     # per-slide latency in the reference's B=1 call pattern (one slide per call, calls back to back)
@@ -307,7 +371,7 @@ def main():
     # ---- data-faithful variant: the same bags as they are stored on disk, fp16 (Step2_feature_extract.py:165);
     # the kernel converts in registers and the x_lo product vanishes.  Reported next to the fp32-bag headline, never as `value`.
     sps_fp16 = None
-    if not args.no_b1 and world == 1:
+    if not args.no_b1 and world == 1 and x_dtype == torch.float32:
         bags16 = [b.half() for b in bags]
         step16 = lambda i: ops.ga_forward_batch([bags16[(i * B + j) % N_BAGS] for j in range(B)], packed, dims, args.precision) \
             if B > 1 else ops.ga_forward(bags16[i % N_BAGS], packed, dims, args.precision)
@@ -339,7 +403,7 @@ def main():
     def main_kernel(i):
         # same launch as the timed steps (same template instance, same grid: B bags), without merge / heads
         xp = (ctypes.c_void_p * B)(*[bags[(i * B + j) % N_BAGS].data_ptr() for j in range(B)])
-        rc = _lib.load().acmil_ga_forward_batch(B, xp, ns_arr, _lib.DTYPE_F32, packed.data_ptr(), *dims.args(),
+        rc = _lib.load().acmil_ga_forward_batch(B, xp, ns_arr, ops._DT[x_dtype], packed.data_ptr(), *dims.args(),
                                                 ops.mode_id(args.precision), a_ptrs, None, None, None, None, 1,
                                                 ws_b.data_ptr(), stream)
         _lib.check(rc, "acmil_ga_forward_batch")
@@ -355,33 +419,50 @@ def main():
     torch.cuda.synchronize()
     t_kernel = e0.elapsed_time(e1) * 1e-3 / n_k  # seconds per launch (back-to-back launches on the launch stream)
 
-    nbytes, flops = algorithmic_work(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS)
+    nbytes, flops = algorithmic_work(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, s_in=s_in)
     nbytes, flops = nbytes * B, flops * B            # one launch processes B slides
-    mfma_peak = 2500.0 if args.precision == "f16x3" else 157.3  # TFLOP/s dense: f16 MFMA / fp32 MFMA
-    executed = flops * (3.0 if args.precision == "f16x3" else 1.0)
+    split = args.precision == "f16x3"
+    mfma_peak = 157.3 if args.precision == "fp32" else 2500.0   # TFLOP/s dense: fp32 MFMA / f16 MFMA
+    # MFMA flops actually executed: split-f16 runs 3 products per fp32 product (2 in GEMM1 when the bag is fp16: x_lo = 0)
+    g1 = 2.0 * N_PATCH * D_FEAT * D_INNER * B
+    g2 = 2.0 * N_PATCH * 2 * D_INNER * D_ATTN * B
+    p1 = (2.0 if x_dtype == torch.float16 else 3.0) if split else 1.0
+    executed = g1 * p1 + g2 * (3.0 if split else 1.0)
+    version = 1 if (os.environ.get("ACMIL_GA_KERNEL") == "1" or not split) else 2
+    waves = 4 if (B * N_PATCH >= 1024 * 128 or N_PATCH < 32768) else 8
+    if os.environ.get("ACMIL_GA_WAVES") in ("4", "8"):
+        waves = int(os.environ["ACMIL_GA_WAVES"])
+    traffic, traffic_src = pmc_traffic(args.workload, args.precision, B)
     roofline = {
-        "kernel": "ga_fwd_kernel<ND=8,KP=5,%s,x=f32,waves=%d>, %d bags per launch" % (
-            args.precision, 4 if (B * N_PATCH >= 1024 * 128 or N_PATCH < 32768) else 8, B),
+        "kernel": "%s<ND=%d,KP=%d,%s,x=%s,waves=%d>, %d bags per launch" % (
+            "ga_fwd2_kernel" if version == 2 else "ga_fwd_kernel", D_INNER // 32, 5 if N_TOKEN > 1 else 1, args.precision,
+            shape["xdtype"], waves, B),
         "bound": "mfma",
         "achieved": round(flops / t_kernel / 1e12, 2), "peak": mfma_peak, "unit": "TFLOP/s",
         "frac": round(flops / t_kernel / 1e12 / mfma_peak, 4),
-        "traffic": pmc_traffic(args.precision, B),
+        "traffic": traffic, "traffic_source": traffic_src,
         "us_per_launch": round(t_kernel * 1e6, 2),
         "executed_tflops": round(executed / t_kernel / 1e12, 1),
         "executed_frac": round(executed / t_kernel / 1e12 / mfma_peak, 4),
-        "note": "flops = algorithmic (SURVEY 8d: 19.85 GFLOP/slide x slides per launch); f16x3 executes 3 f16 MFMA products per fp32 product",
+        "note": "flops = algorithmic (SURVEY 8d: %.2f GFLOP/slide x slides per launch); executed = MFMA flops issued "
+                "(split-f16: 3 f16 products per fp32 product)" % (flops / B / 1e9),
         "hbm": {"achieved": round(nbytes / t_kernel / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(nbytes / t_kernel / 1e9 / 8000.0, 4), "algorithmic_bytes": nbytes},
     }
+    dtype_str = {"f16x3": "f32 (projections as split-f16 x3 MFMA products, fp32 accumulate)", "fp32": "f32",
+                 "f16": "f16 (single-pass f16 MFMA, fp32 accumulate: THROUGHPUT MODE, scores ~2e-4 from the fp32 reference)"}[args.precision]
+    if x_dtype != torch.float32:
+        dtype_str = "%s bags; %s" % (shape["xdtype"], dtype_str)
 
     result = {
-        "metric": "slides/sec (ACMIL-ga attention-aggregation forward, N=50000 D=512)",
+        "metric": shape["metric"],
         "value": round(slides_per_s, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (projections as split-f16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32",
+        "dtype": dtype_str,
         "data": "synthetic",
-        "config": {"workload": "ACMIL-ga eval forward, %d slide(s) per step in one fused launch: N=50000 patches, D=512, "
-                               "D_inner=256, n_token=5, n_class=2, fp32 bags resident in HBM, %d bags rotated" % (B, N_BAGS),
+        "config": {"workload": "ACMIL-ga eval forward, %d slide(s) per step in one fused launch: N=%d patches, D=%d, "
+                               "D_inner=%d, n_token=%d, n_class=%d, %s bags resident in HBM, %d bags rotated" % (
+                                   B, N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, shape["xdtype"], N_BAGS),
                    "precision": args.precision, "slides_per_step": B, "sharding": "independent slides per GPU, no collective"},
         "attention_fwd_ms_per_slide": round(dt / (args.steps * B) * 1e3, 4),
         "attention_fwd_ms_per_slide_b1": None if ms_b1 is None else round(ms_b1, 4),
@@ -393,7 +474,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ga_oracle as O                     # the oracle is only ever the CPU baseline / checker
         all_cores = torch.get_num_threads()
-        xs = [b.cpu().unsqueeze(0) for b in bags[:4]]
+        xs = [b.float().cpu().unsqueeze(0) for b in bags[:4]]
 
         def cpu_run(threads, budget_s, min_iters):
             torch.set_num_threads(threads)
@@ -420,12 +501,12 @@ def main():
         cpu_sps = n_cpu / el
         # cross-check while we are here: GPU result of the last step vs the oracle on the same bag
         last1 = ops.ga_forward(bags[3], packed, dims, args.precision)
-        ref = O.acmil_ga_forward(bags[3].cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
+        ref = O.acmil_ga_forward(bags[3].float().cpu().unsqueeze(0), sd_cpu, n_token=N_TOKEN)
         err = max((last1["A_out"].cpu() - ref["A_out"][0]).abs().max().item(),
                   (last1["sub_preds"].cpu() - ref["sub_preds"]).abs().max().item())
         result["cpu_baseline"] = {"value": round(cpu_sps, 2), "unit": "slides/s", "cores": cores, "kind": "port",
-                                  "sample": "%d forwards of the same N=50000 D=512 bags (%.1f s), torch-CPU oracle, best of thread counts %s "
-                                            "on a %d-thread host" % (n_cpu, el, sorted(probe), all_cores),
+                                  "sample": "%d forwards of the same N=%d D=%d bags (%.1f s), torch-CPU oracle, best of thread counts %s "
+                                            "on a %d-thread host" % (n_cpu, N_PATCH, D_FEAT, el, sorted(probe), all_cores),
                                   "probe_slides_per_s": {str(k): round(v, 2) for k, v in probe.items()},
                                   "ms_per_slide": round(1e3 / cpu_sps, 2)}
         result["speedup_vs_cpu"] = round(slides_per_s / cpu_sps, 1)
