@@ -20,6 +20,19 @@
 #pragma once
 #include "ga_forward_kernel.h"
 
+// Timing-only ablations for tools/build_variants.sh (results are WRONG when any bit is set; never set in the product build):
+// 1 no x DMA, 2 no W DMA, 4 no GEMM1 MFMAs, 8 no GEMM2 MFMAs, 16 no step barrier, 32 stop after the scores, 64 no gate,
+// 128 no W fragment reads, 256 no x read / split.  GA2_LDS_PAD: extra LDS bytes (forces one workgroup per CU).
+// GA2_PROF: s_memtime accounting of the waits; the per-wave cycle totals REPLACE the first 8 scores of each 32-patch group of A_out[0].
+// GA2_NB4 / GA2_NB8: ring slots of the 4- / 8-wave workgroups (defaults 3 / 4).
+// GA2_DEPHASE: the second co-resident workgroup of a CU delays its first tile by that many s_sleep(127) rounds.
+#ifndef GA2_ABL
+#define GA2_ABL 0
+#endif
+#define GA2_MFMA1(A, B, C) ((GA2_ABL & 4) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
+#define GA2_MFMA2(A, B, C) ((GA2_ABL & 8) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
+__device__ __forceinline__ f32x16 ga2_keep(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+
 template <int ND, int KP, int XDT, int WAVES>
 struct Ga2Geom {
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;     // bytes per bag element
@@ -32,7 +45,13 @@ struct Ga2Geom {
     static constexpr int NV = RW + XG;                              // LDS-DMA instructions per wave per step
     static constexpr int REGION = NV * 1024;                        // per-wave region of a slot: RW rows, then the x tile
     static constexpr int SLOT = WAVES * REGION;
-    static constexpr int NB = (WAVES == 8) ? 4 : 3;                 // ring slots (8-wave WG: 1 per CU; 4-wave WG: 2 per CU)
+#ifndef GA2_NB4
+#define GA2_NB4 3
+#endif
+#ifndef GA2_NB8
+#define GA2_NB8 4
+#endif
+    static constexpr int NB = (WAVES == 8) ? GA2_NB8 : GA2_NB4;     // ring slots (8-wave WG: 1 per CU; 4-wave WG: 2 per CU)
     static constexpr int PD = NB - 1;                               // prefetch distance in steps
     static constexpr int ROWS = 32 * WAVES;
     static_assert(ND % 4 == 0, "Di must be a multiple of 128");
@@ -43,7 +62,11 @@ struct Ga2Geom {
     static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4;
     static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;
     static constexpr int PL_BYTES = WAVES * KP * 32 * 4;
+#ifdef GA2_LDS_PAD
+    static constexpr int LDS = PL_OFF + PL_BYTES + GA2_LDS_PAD;
+#else
     static constexpr int LDS = PL_OFF + PL_BYTES;
+#endif
     // byte offset of fragment row r inside a slot
     static constexpr int frow(int r) { return (r / RW) * REGION + (r % RW) * 1024; }
 };
@@ -117,6 +140,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     // piece p (compile time) of step u into ring slot `slot`: p < RW weight rows, then the x pieces
     auto dma_piece = [&](auto pc, int u, int slot) {
         constexpr int p = decltype(pc)::value;
+        if constexpr (((GA2_ABL & 2) && p < G::RW) || ((GA2_ABL & 1) && p >= G::RW)) return;
         const unsigned m0v = m0w + slot * G::SLOT;
         if constexpr (p < G::RW) {
             const int uw = u < SL ? u : SL;
@@ -144,6 +168,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         for (int e = tid; e < (2 + KP) * GA_DA; e += NTHR) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
     }
 
+#ifdef GA2_DEPHASE
+    // HW_REG_LDS_ALLOC[7:0] = LDS base of this workgroup: non-zero for the second workgroup resident on a CU
+    if (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) != 0 && blockIdx.x < 1024)
+        for (int i = 0; i < GA2_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     f32x16 acc1[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d)
@@ -161,6 +190,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     f32x4 xr0, xr1;      // raw fp32
     u32x4 xrw;           // raw 16-bit (8 elements)
     auto read_x = [&](const char* slot) {
+        if constexpr (GA2_ABL & 256) { asm volatile("" : "+v"(xr0), "+v"(xr1), "+v"(xrw)); return; }
         if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
         else xrw = *(const u32x4*)(slot + xrd0);
     };
@@ -168,6 +198,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     constexpr int NSP = XLO ? 4 : 0;
     u32x4 xhw, xlw;
     auto split_piece = [&](int j) {
+        if constexpr (GA2_ABL & 256) { asm volatile("" : "+v"(xhw), "+v"(xlw)); return; }
         float v0, v1;
         if constexpr (XDT == ACMIL_DTYPE_F32) {
             v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
@@ -191,17 +222,34 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     int rslot = 0;   // ring slot of the step being consumed
     const int lane16 = lane * 16;
     auto read_hi = [&](const char* slot) {
+        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(WH[d])); return; }
 #pragma unroll
         for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
     };
     auto read_lo = [&](const char* slot) {
+        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(WL[d])); return; }
 #pragma unroll
         for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
     };
+#ifdef GA2_PROF
+    unsigned long long pf_vm = 0, pf_bar = 0, pf_vm1 = 0, pf_bar1 = 0;
+    const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
+#endif
     auto step_sync = [&]() {
+#ifdef GA2_PROF
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
         ga_wait_vm<(G::PD - 1) * G::NV>();      // this wave's pieces of the step about to be consumed have landed
+#ifdef GA2_PROF
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): every read of the slot about to be recycled has returned
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(GA2_ABL & 16)) __builtin_amdgcn_s_barrier();
+#ifdef GA2_PROF
+        const unsigned long long tc = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        pf_vm += tb - ta; pf_bar += tc - tb;
+#endif
     };
 
     // ---- step 0 (nothing deferred yet)
@@ -217,7 +265,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         read_lo(slot);
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xh, acc1[d], 0, 0, 0);
+            acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
         }
         __builtin_amdgcn_sched_barrier(0);
         issue_all(G::PD, islot);
@@ -225,7 +273,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (XLO) {
 #pragma unroll
-            for (int d = 0; d < ND; ++d) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xl, acc1[d], 0, 0, 0);
+            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
         }
         xhp = xh;
         rslot = (rslot + 1 == G::NB) ? 0 : rslot + 1;
@@ -240,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         // P3(s-1) covers the reads above; the split of x(s) runs in its first MFMA gaps
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[d], xhp, acc1[d], 0, 0, 0);
+            acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
             if (d < NSP) {
                 __builtin_amdgcn_sched_barrier(0);
                 split_piece(d);
@@ -253,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         // P1(s), one LDS-DMA piece of step s+PD per MFMA gap
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
-            acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xh, acc1[d], 0, 0, 0);
+            acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
             __builtin_amdgcn_sched_barrier(0);
             if (d == 0) dma_piece(std::integral_constant<int, 0>{}, s + G::PD, islot);
             if (d == 1 && G::NV > 1) dma_piece(std::integral_constant<int, (G::NV > 1 ? 1 : 0)>{}, s + G::PD, islot);
@@ -266,7 +314,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         islot = (islot + 1 == G::NB) ? 0 : islot + 1;
         if constexpr (XLO) {
 #pragma unroll
-            for (int d = 0; d < ND; ++d) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xl, acc1[d], 0, 0, 0);
+            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
         }
         __builtin_amdgcn_sched_barrier(0);
         xhp = xh;
@@ -274,7 +322,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     }
     // P3 of the last GEMM1 step
 #pragma unroll
-    for (int d = 0; d < ND; ++d) acc1[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[d], xhp, acc1[d], 0, 0, 0);
+    for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+#ifdef GA2_PROF
+    const unsigned long long pf_t1 = __builtin_amdgcn_s_memtime();
+    pf_vm1 = pf_vm; pf_bar1 = pf_bar;
+#endif
 
     // =========================================================== relu + f16 split of h (see v1 for the pinning notes)
 #pragma unroll
@@ -312,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     for (int k = 0; k < KP; ++k) sc[k] = 0.0f;
     static_assert(4 * G::DD == ND, "WH/WL hold the 4*DD fragments of a GEMM2 step part");
     auto read2 = [&](const char* slot, int part, f16x8 (&W)[ND]) {
+        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(W[d])); return; }
 #pragma unroll
         for (int dd = 0; dd < G::DD; ++dd)
 #pragma unroll
@@ -343,7 +396,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 for (int dd = 0; dd < G::DD; ++dd)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[dd * 4 + t], hh[G::DD * (st - 1) + dd][t >> 1], acc2[t & 1], 0, 0, 0);
+                        acc2[t & 1] = GA2_MFMA2(WL[dd * 4 + t], hh[G::DD * (st - 1) + dd][t >> 1], acc2[t & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             read2(slot, 1, WL);
@@ -352,7 +405,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int m = dd * 4 + t;
-                    acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[m], hh[G::DD * st + dd][t >> 1], acc2[t & 1], 0, 0, 0);
+                    acc2[t & 1] = GA2_MFMA2(WH[m], hh[G::DD * st + dd][t >> 1], acc2[t & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (m == 0) dma_piece(std::integral_constant<int, 0>{}, u + G::PD, islot);
                     if (m == 1 && G::NV > 1) dma_piece(std::integral_constant<int, (G::NV > 1 ? 1 : 0)>{}, u + G::PD, islot);
@@ -367,18 +420,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             for (int dd = 0; dd < G::DD; ++dd)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[dd * 4 + t], hl[G::DD * st + dd][t >> 1], acc2[t & 1], 0, 0, 0);
+                    acc2[t & 1] = GA2_MFMA2(WH[dd * 4 + t], hl[G::DD * st + dd][t >> 1], acc2[t & 1]);
             __builtin_amdgcn_sched_barrier(0);
             if (st == 3) {   // the block's last step finishes its own P3: the gate needs the complete accumulators
 #pragma unroll
                 for (int dd = 0; dd < G::DD; ++dd)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc2[t & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[dd * 4 + t], hh[G::DD * 3 + dd][t >> 1], acc2[t & 1], 0, 0, 0);
+                        acc2[t & 1] = GA2_MFMA2(WL[dd * 4 + t], hh[G::DD * 3 + dd][t >> 1], acc2[t & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             rslot = (rslot + 1 == G::NB) ? 0 : rslot + 1;
         }
+        if constexpr (GA2_ABL & 64) { asm volatile("" :: "v"(acc2[0]), "v"(acc2[1])); continue; }
         // gate + partial scores for the 32 units of this block (this lane: 16 of them)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
@@ -396,6 +450,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         }
     }
 
+#ifdef GA2_PROF
+    const unsigned long long pf_t2 = __builtin_amdgcn_s_memtime();
+#endif
     const float* bwp = (const float*)(a.packed + L.bw_off);
     float smax[KP], lsum[KP], pe[KP];
 #pragma unroll
@@ -414,6 +471,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         lsum[k] = l;
     }
 
+    if constexpr (GA2_ABL & 32) return;
     // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
     ga_wait_vm<0>();  // the clamped tail DMAs still target the ring: drain them before it is reused
     __syncthreads();
@@ -497,13 +555,24 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             out[k * PS + e] = v;
         }
     }
+#ifdef GA2_PROF
+    {
+        const unsigned long long pf_t3 = __builtin_amdgcn_s_memtime();
+        const float pv[8] = {(float)(pf_t3 - pf_t0), (float)pf_vm1, (float)pf_bar1, (float)(pf_vm - pf_vm1), (float)(pf_bar - pf_bar1),
+                             (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_t2)};
+        __syncthreads();
+        if (A_out && lane < 8 && m0 + 8 <= N) A_out[m0 + lane] = pv[lane];
+    }
+#endif
 }
 
 template <int ND, int KP, int XDT, int WAVES>
 int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
     using G = Ga2Geom<ND, KP, XDT, WAVES>;
     static_assert(G::LDS <= 160 * 1024, "LDS budget");
+#ifndef GA2_LDS_PAD
     static_assert(WAVES == 8 || 2 * G::LDS <= 160 * 1024, "two 4-wave workgroups must fit one CU");
+#endif
     const dim3 grid(a.tile_start[a.nbags]), block(64 * WAVES);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, WAVES, true, false>
                                    : ga_fwd2_kernel<ND, KP, XDT, WAVES, false, true>;

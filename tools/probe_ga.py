@@ -66,6 +66,12 @@ def child(args):
         res[tag + "_us_med"] = round(ts[len(ts) // 2], 1)
         res[tag + "_us_min"] = round(ts[0], 1)
         res[tag + "_us_per_slide"] = round(ts[len(ts) // 2] / per, 2)
+    if os.environ.get("GA_PROF"):
+        A0 = out["A_out"][0][0]
+        n32 = (A0.numel() // 32) * 32
+        pv = A0[:n32].view(-1, 32)[:, :8].double()
+        res["prof_mean"] = [round(float(v)) for v in pv.mean(0)]
+        res["prof_names"] = ["total", "g1_vm", "g1_bar", "g2_vm", "g2_bar", "g1", "g2", "epi"]
     print("PROBE " + json.dumps(res), flush=True)
 
 
@@ -112,6 +118,8 @@ def main():
             print("VARIANT %s FAILED rc=%d\n%s" % (name, r.returncode, r.stdout[-1500:]), flush=True)
             continue
         res = json.loads(line[0][6:])
+        if "prof_mean" in res:
+            print("PROF %s %s" % (name, dict(zip(res["prof_names"], res["prof_mean"]))), flush=True)
         cur = torch.load(save)
         if ref is None:
             ref = cur
