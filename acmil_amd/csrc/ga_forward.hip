@@ -126,6 +126,17 @@ static int ga_kernel_version() {
     return v;
 }
 
+// the persistent split-f16 kernel covers every built family in F16X3 mode
+static bool ga_use_v2(int mode) { return mode == ACMIL_MODE_F16X3 && ga_kernel_version() == 2; }
+
+// start delay of the second workgroup of each CU (ga_forward_kernel_v2.h), in s_sleep(127) rounds.  Measured on MI355X: offsets up
+// to a full tile change nothing (the two workgroups of a CU drift through every relative phase anyway, the second one
+// being ~25 % slower), so the default is 0; ACMIL_GA_DEPHASE keeps the knob for experiments.
+static int ga_dephase() {
+    static const int env = [] { const char* e = getenv("ACMIL_GA_DEPHASE"); return e ? atoi(e) : 0; }();
+    return env > 0 ? env : 0;
+}
+
 static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
     const int ND = a.L.ND, K = a.L.K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
@@ -142,7 +153,8 @@ extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, i
     size_t b = (size_t)ga_pool_tiles(N) * K * ga_part_stride(Di) * sizeof(float);  // partials (pool tiles >= fused tiles)
     b = (b + 255) & ~(size_t)255;
     b += (size_t)K * Di * sizeof(float);                                          // afeat scratch
-    return (b + 255) & ~(size_t)255;
+    b = (b + 255) & ~(size_t)255;
+    return b + 256;                                                               // tile counter of the persistent kernel
 }
 
 // merge + heads shared by the fused forward (batched) and the masked pooling pass.
@@ -191,7 +203,7 @@ extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D
     for (int b = 0; b < nbags; ++b) { if (Ns[b] <= 0) return 0; tiles += ga_pool_tiles(Ns[b]); }
     size_t bytes = (tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     bytes += ((size_t)nbags * K * Di * sizeof(float) + 255) & ~(size_t)255;
-    return bytes;
+    return bytes + 256;                                                           // tile counter of the persistent kernel
 }
 
 extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
@@ -212,7 +224,8 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     }
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
-    a.waves = ga_pick_waves(maxN, total_patches);
+    a.waves = ga_use_v2(mode) ? 4 : ga_pick_waves(maxN, total_patches);
+    a.dephase = ga_dephase();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
         a.xs[b] = b < nbags ? xs[b] : nullptr;
@@ -221,6 +234,11 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         a.tile_start[b + 1] = a.tile_start[b] + (b < nbags ? (Ns[b] + 32 * a.waves - 1) / (32 * a.waves) : 0);
     }
     a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = nullptr;
+    a.tile_counter = nullptr;
+    if (ga_use_v2(mode)) {   // the last 256 bytes of the workspace: tile counter, zeroed on the stream ahead of the launch
+        a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_batch_workspace_bytes(nbags, Ns, D, Di, K, C, mode) - 256);
+        if (hipMemsetAsync(a.tile_counter, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
     a.L = ga_layout(D, Di, K, C, mode);
 #ifdef GA_TRACE
     static unsigned long long* tr = nullptr;
@@ -285,11 +303,17 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.waves = ga_pick_waves(N);
+    a.waves = ga_use_v2(mode) ? 4 : ga_pick_waves(N);
+    a.dephase = ga_dephase();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);
     a.nbags = 1; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = h_save;
+    a.tile_counter = nullptr;
+    if (ga_use_v2(mode) && workspace) {
+        a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_workspace_bytes(N, D, Di, K, C, mode) - 256);
+        if (hipMemsetAsync(a.tile_counter, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
     a.L = ga_layout(D, Di, K, C, mode);
     return ga_dispatch(a, mode, x_dtype, false, st);
 }

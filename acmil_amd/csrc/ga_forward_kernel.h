@@ -43,7 +43,9 @@ struct GaFwdArgs {
     const char* packed;
     float* part;     // workspace partials [total tiles][K][2+Di]
     float* h_save;   // [N,Di] or null (single-bag score pass only)
-    int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches)
+    int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches); the persistent v2 kernel always uses 4
+    unsigned* tile_counter;   // v2: zeroed word the persistent workgroups draw their next tiles from (null = static striding)
+    int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
 #ifdef GA_TRACE
     unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0
 #endif

@@ -1,74 +1,89 @@
-// ga_forward_kernel_v2.h -- second-generation fused GA forward (split-f16 arithmetic only), gfx950.
+// ga_forward_kernel_v2.h -- second-generation fused GA forward (split-f16 arithmetic), gfx950: PERSISTENT workgroups.
 //
-// Same mathematics, same packed weight stream, same outputs and same per-workgroup partials as ga_fwd_kernel
+// Same mathematics, same packed weight stream, same outputs and same per-tile partials as ga_fwd_kernel
 // (ga_forward_kernel.h; reference: architecture/network.py:49-57, architecture/transformer.py:259-267, :322-324).
-// What changed is the schedule of the two GEMM loops, which ran at ~57 % matrix-pipe efficiency in v1:
+// A cycle account of v1 (s_memtime; tools/probe_ga.py, GA2_PROF) showed where a 128-patch tile's ~156 k cycles per SIMD
+// went with two 4-wave workgroups per CU: 74 k matrix pipe; ~35 k of workgroup turnover (launch, table staging, cold
+// DMA pipeline, drained tail) per tile; 40 k of gate / softmax / pooling phases during which BOTH co-resident
+// workgroups idle the matrix pipe, because equal workgroups started together stay in lock step ("convoy"); the rest in
+// per-step stalls of the GEMM loops.  This kernel attacks all three:
 //
+//   * persistent workgroups: grid = 2 per CU; tiles are DRAWN from a global counter (the second workgroup of a CU runs
+//     ~25 % slower than the first -- age-based issue arbitration -- so equal shares would leave the first idle at the
+//     end); tables are staged once; the LDS-DMA
+//     ring never drains -- the last two steps of a tile already prefetch the first steps of the NEXT tile (its weights
+//     and its bag rows), and the epilogue works in the ring slot that is free at that moment;
+//   * de-phasing: the second workgroup of every CU (HW_REG_LDS_ALLOC.base != 0) delays its start by about half a tile,
+//     so one workgroup's gate / softmax / pooling phases run beside the other's GEMM steps;
 //   * software pipelining ACROSS the step barrier.  A step's 3 MFMA groups are issued in the order
 //         P1 = Whi * xhi,  P2 = Whi * xlo,  P3 = Wlo * xhi
 //     and P3 of step s is deferred until AFTER the barrier of step s+1: the barrier is followed immediately by the
 //     ds_reads of the next "hi" fragments and the next x tile, and the 8 deferred MFMAs (256 matrix-pipe cycles) cover
-//     their LDS latency and the fp32 -> f16 hi/lo conversion of x.  The "lo" fragments are requested under P1.  No
-//     MFMA group ever waits for a read that was issued less than 8 MFMAs earlier, and the pipe stays fed across the barrier.
+//     their LDS latency and the fp32 -> f16 hi/lo split of x.  The "lo" fragments are requested under P1;
 //   * LDS-DMA without vector address arithmetic: global_load_lds_dwordx4 in its SGPR-base + 32-bit lane offset +
-//     immediate form.  Every wave copies RW CONSECUTIVE fragment rows plus its own x tile into one contiguous
-//     per-wave region of the slot, so one M0 value and immediates -4096..+1024 address all of a step's pieces; the
-//     per-step advance is scalar adds.  Pieces are issued one per MFMA gap of P1.
-//   * slot s-1 is recycled right after barrier s (every wave drains lgkmcnt before arriving), which gives the same
-//     prefetch distance as v1 (NB-1 steps) with the same ring.
-// Phases outside the GEMM loops (relu/split, gate, scores, softmax, pooling, combine) are v1's.
+//     immediate form.  Every wave copies RW CONSECUTIVE fragment rows plus its own x tile into one contiguous per-wave
+//     region of the slot, so one M0 value and immediates -4096..+1024 address all of a step's pieces.  Steps that need
+//     no bag rows (GEMM2) issue only the weight rows; the counted vmcnt waits follow the schedule.
+// Ring discipline (NB = 3 slots, prefetch distance 2): barrier b_s makes slot s readable (every wave waited for its own
+// pieces) and slot s-1 writable (every wave drained lgkmcnt before arriving); step s+2 is issued right after b_s.
 #pragma once
 #include "ga_forward_kernel.h"
 
-// Timing-only ablations for tools/build_variants.sh (results are WRONG when any bit is set; never set in the product build):
-// 1 no x DMA, 2 no W DMA, 4 no GEMM1 MFMAs, 8 no GEMM2 MFMAs, 16 no step barrier, 32 stop after the scores, 64 no gate,
-// 128 no W fragment reads, 256 no x read / split.  GA2_LDS_PAD: extra LDS bytes (forces one workgroup per CU).
-// GA2_PROF: s_memtime accounting of the waits; the per-wave cycle totals REPLACE the first 8 scores of each 32-patch group of A_out[0].
-// GA2_NB4 / GA2_NB8: ring slots of the 4- / 8-wave workgroups (defaults 3 / 4).
-// GA2_DEPHASE: the second co-resident workgroup of a CU delays its first tile by that many s_sleep(127) rounds.
+// Timing-only build knobs for tools/build_variants.sh (never set in the product build; results are WRONG with GA2_ABL):
+//   GA2_ABL bits: 1 no x DMA, 2 no W DMA, 4 no GEMM1 MFMAs, 8 no GEMM2 MFMAs.
+//   GA2_PROF: s_memtime accounting; per-wave cycle totals REPLACE the first 8 scores of each 32-patch group of A_out[0].
 #ifndef GA2_ABL
 #define GA2_ABL 0
+#endif
+// wave priority inside the GEMM step loops / outside (gate, softmax, pooling): the wave that feeds the matrix pipe wins the
+// issue arbitration against a co-resident wave that is in a VALU / LDS phase
+#ifndef GA2_PRIO_GEMM
+#define GA2_PRIO_GEMM 2
+#endif
+#ifndef GA2_PRIO_REST
+#define GA2_PRIO_REST 0
 #endif
 #define GA2_MFMA1(A, B, C) ((GA2_ABL & 4) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
 #define GA2_MFMA2(A, B, C) ((GA2_ABL & 8) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
 __device__ __forceinline__ f32x16 ga2_keep(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
 
-template <int ND, int KP, int XDT, int WAVES>
+template <int ND, int KP, int XDT>
 struct Ga2Geom {
+    static constexpr int WAVES = 4;                                 // one wave per SIMD; two workgroups per CU
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;     // bytes per bag element
     static constexpr int WROWS = 2 * ND;                            // fragment rows per step ("hi" rows then "lo" rows)
     static_assert(WROWS % WAVES == 0, "every wave copies the same number of consecutive fragment rows");
     static constexpr int RW = WROWS / WAVES;                        // fragment rows per wave per step
     static_assert(RW >= 1 && RW <= 4, "row immediates must fit -4096..-1024");
     static constexpr int DD = ND / 4;                               // h tiles consumed per GEMM2 step
-    static constexpr int XG = 32 * 16 * XE / 1024;                  // x pieces (1 KiB) per wave per step
-    static constexpr int NV = RW + XG;                              // LDS-DMA instructions per wave per step
-    static constexpr int REGION = NV * 1024;                        // per-wave region of a slot: RW rows, then the x tile
+    static constexpr int XG = 32 * 16 * XE / 1024;                  // x pieces (1 KiB) per wave per GEMM1 step
+    static constexpr int NVX = RW + XG;                             // LDS-DMA instructions per wave, GEMM1 step
+    static constexpr int NVW = RW;                                  //                                 GEMM2 step
+    static constexpr int REGION = NVX * 1024;                       // per-wave region of a slot: RW rows, then the x tile
     static constexpr int SLOT = WAVES * REGION;
-#ifndef GA2_NB4
-#define GA2_NB4 3
-#endif
-#ifndef GA2_NB8
-#define GA2_NB8 4
-#endif
-    static constexpr int NB = (WAVES == 8) ? GA2_NB8 : GA2_NB4;     // ring slots (8-wave WG: 1 per CU; 4-wave WG: 2 per CU)
-    static constexpr int PD = NB - 1;                               // prefetch distance in steps
-    static constexpr int ROWS = 32 * WAVES;
+    static constexpr int NB = 3;                                    // ring slots
+    static constexpr int PD = 2;                                    // prefetch distance in steps
+    static constexpr int ROWS = 32 * WAVES;                         // patches per tile
     static_assert(ND % 4 == 0, "Di must be a multiple of 128");
+    static constexpr int Di = 32 * ND;
     static constexpr int RING = NB * SLOT;
-    static constexpr int POOLW = 64 * 36 * 4;
-    static constexpr int REGION0 = (RING > WAVES * POOLW) ? RING : WAVES * POOLW;
-    static constexpr int TAB_OFF = REGION0;
-    static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4;
+    static constexpr int PTILE = 32 * 36 * 4;                       // wave-private pooling tile [32 features][32 patches + 4 pad] fp32
+    static constexpr int COMB = KP * Di * 4;                        // wave's combine record [KP][Di]
+    static constexpr int PW = (PTILE > COMB) ? PTILE : COMB;        // per-wave epilogue scratch
+    static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4 + 32;     // bv[128], bu[128], Ww[KP][128], bw[8]
+    static constexpr int PL_BYTES = WAVES * KP * 32 * 4;            // softmax numerators [wave][KP][32]
+    static constexpr int ML_BYTES = WAVES * 8 * 2 * 4 + 16;         // (max, sum) [wave][8], then the drawn tile index
+    // the epilogue scratch lives in the ring slot that is free between two tiles when a separate region would cost the
+    // second workgroup of the CU (80 KiB each)
+    static constexpr bool SCRATCH_IN_RING = (RING + WAVES * PW + TAB_BYTES + PL_BYTES + ML_BYTES > 80 * 1024);
+    static_assert(!SCRATCH_IN_RING || REGION >= PW, "free-slot scratch must hold a wave's pooling tile / combine record");
+    static constexpr int SCR_OFF = RING;                            // separate scratch (when not in the ring)
+    static constexpr int TAB_OFF = RING + (SCRATCH_IN_RING ? 0 : WAVES * PW);
     static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;
-    static constexpr int PL_BYTES = WAVES * KP * 32 * 4;
-#ifdef GA2_LDS_PAD
-    static constexpr int LDS = PL_OFF + PL_BYTES + GA2_LDS_PAD;
-#else
-    static constexpr int LDS = PL_OFF + PL_BYTES;
-#endif
-    // byte offset of fragment row r inside a slot
-    static constexpr int frow(int r) { return (r / RW) * REGION + (r % RW) * 1024; }
+    static constexpr int ML_OFF = PL_OFF + PL_BYTES;
+    static constexpr int LDS = ML_OFF + ML_BYTES;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static constexpr int frow(int r) { return (r / RW) * REGION + (r % RW) * 1024; }   // fragment row r inside a slot
 };
 
 // One 1-KiB LDS-DMA piece: lane l's 16 bytes at (sbase + voff + IMM) land at LDS byte (m0v + IMM + 16 l).
@@ -91,500 +106,600 @@ __device__ __forceinline__ void ga2_split_pair(float x0, float x1, unsigned& hi_
         : "=&v"(hi_pk), "=&v"(lo_pk) : "v"(x0), "v"(x1));
 }
 
-template <int ND, int KP, int XDT, int WAVES, bool POOL, bool SAVEH>
-__global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd2_kernel(GaFwdArgs a) {
+template <int ND, int KP, int XDT, bool POOL, bool SAVEH>
+__global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = Ga2Geom<ND, KP, XDT, WAVES>;
-    constexpr int NTHR = 64 * WAVES;
+    using G = Ga2Geom<ND, KP, XDT>;
+    constexpr int WAVES = G::WAVES, NTHR = 64 * WAVES;
     constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
-    constexpr int NCH = ND / 2;
-    constexpr int Di = ND * 32;
+    constexpr int Di = G::Di, PD = G::PD, NB = G::NB;
+    static_assert(PD == 2 && NB == 3, "the wait counts below are written for a prefetch distance of 2 steps");
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    static_assert(G::NVX <= 6, "at most 6 pieces per step");
 
     const GaLayout& L = a.L;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i31 = lane & 31, hi = lane >> 5;
-    int bag = 0;
-    while (bag + 1 < a.nbags && (int)blockIdx.x >= a.tile_start[bag + 1]) ++bag;
-    const int N = a.Ns[bag], D = L.D, K = L.K;
-    const char* xbase = (const char*)a.xs[bag];
-    float* A_out = a.A_outs[bag];
-    const int m0 = ((int)blockIdx.x - a.tile_start[bag]) * G::ROWS + wave * 32;
-    const int row = m0 + i31;
-    const bool valid = row < N;
-
+    // Lane-derived addresses are re-derived per phase from an OPAQUE copy of the lane id: hoisted out of the tile loop they
+    // would stay live through every phase and push the GEMM2 loop (hh/hl 128 + fragments 64 + accumulators 32 registers)
+    // over the 256-register budget (spills, and hipcc drains vmcnt -- i.e. the DMA ring -- at every scratch reload).
+    auto ga2_lane = [&]() { int l = tid & 63; asm volatile("" : "+v"(l)); return l; };
+    const int D = L.D, K = L.K;
+    const int ntiles = a.tile_start[a.nbags];
     const char* wstream = a.packed + L.g1_off;
-    const int S1 = D / 16;
-    constexpr int S2 = 16;
-    const int SL = S1 + S2 - 1;
+    const int S1 = D / 16;                 // GEMM1 steps
+    constexpr int S2 = 16;                 // GEMM2 steps: 4 unit blocks x 4
 
-    // ---- LDS-DMA addressing.  x tile of this wave: rows m0c .. m0c+31 (rows past the bag re-read its last row; their
-    // results are discarded).  Lane offsets are 32-bit and relative to the wave's first row.
-    const int m0c = m0 < N ? m0 : N - 1;
-    unsigned xoff[G::XG];
+    // ---- tile bookkeeping (wave-uniform, SGPRs)
+    struct TileInfo { int N, m0, rmax; const char* xrow0; float* A_out; };
+    auto tile_info = [&](int t) {
+        int bag = 0;
+        while (bag + 1 < a.nbags && t >= a.tile_start[bag + 1]) ++bag;
+        TileInfo ti;
+        ti.N = a.Ns[bag];
+        ti.m0 = (t - a.tile_start[bag]) * G::ROWS + wave * 32;
+        ti.A_out = a.A_outs[bag];
+        // x tile of this wave: rows m0c .. m0c+31 (rows past the bag re-read its last row; their results are discarded)
+        const int m0c = ti.m0 < ti.N ? ti.m0 : ti.N - 1;
+        ti.xrow0 = (const char*)a.xs[bag] + (size_t)m0c * D * G::XE;
+        ti.rmax = ti.N - 1 - m0c;
+        return ti;
+    };
+    // lane offsets of the x copy (relative to xrow0): piece q, lane l -> (row, 16-B piece) with the source-side XOR swizzle
+    auto tile_xoff = [&](const TileInfo& ti, int lane, unsigned (&xo)[G::XG]) {
 #pragma unroll
-    for (int q = 0; q < G::XG; ++q) {
-        int r, piece;
-        if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
-        else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
-        const int rmax = N - 1 - m0c;
-        r = r < rmax ? r : rmax;
-        xoff[q] = (unsigned)r * (unsigned)(D * G::XE) + piece * 16;
-    }
-    const unsigned woff = lane * 16;
-    const char* const xrow0 = xbase + (size_t)m0c * D * G::XE;                          // wave-uniform
+        for (int q = 0; q < G::XG; ++q) {
+            int r, piece;
+            if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
+            else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
+            r = r < ti.rmax ? r : ti.rmax;
+            xo[q] = (unsigned)r * (unsigned)(D * G::XE) + piece * 16;
+        }
+    };
+
     const char* const wreg0 = wstream + (size_t)(wave * G::RW + G::RW) * GA_FRAG_ROW;   // wave-uniform, biased by RW rows
     const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
     const unsigned m0w = lds_base + wave * G::REGION + G::RW * 1024;                    // M0 of slot 0
 
-    // piece p (compile time) of step u into ring slot `slot`: p < RW weight rows, then the x pieces
-    auto dma_piece = [&](auto pc, int u, int slot) {
-        constexpr int p = decltype(pc)::value;
-        if constexpr (((GA2_ABL & 2) && p < G::RW) || ((GA2_ABL & 1) && p >= G::RW)) return;
+    // DMA piece number m (0..NVX-1, compile time) of step u into ring slot `slot`: m < RW = weight rows of step u of the
+    // stream (GEMM1 steps, then GEMM2 steps); m >= RW = bag rows of GEMM1 step u of the tile described by (xrow0, xo)
+    auto dma_piece = [&](auto mc, int u, int slot, unsigned woff, bool with_x, const char* xrow0, const unsigned (&xo)[G::XG]) {
+        constexpr int m = decltype(mc)::value;
         const unsigned m0v = m0w + slot * G::SLOT;
-        if constexpr (p < G::RW) {
-            const int uw = u < SL ? u : SL;
-            ga2_dma<-(G::RW - p) * 1024>(woff, wreg0 + (size_t)uw * G::WROWS * GA_FRAG_ROW, m0v);
-        } else {
-            constexpr int q = p - G::RW;
-            const int ux = u < S1 ? u : S1 - 1;
-            ga2_dma<q * 1024>(xoff[q], xrow0 + (size_t)ux * 16 * G::XE - q * 1024, m0v);
+        if constexpr (m < G::RW) {
+            if constexpr (!(GA2_ABL & 2)) ga2_dma<-(G::RW - m) * 1024>(woff, wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v);
+        } else if constexpr (m < G::NVX) {
+            constexpr int q = m - G::RW;
+            if constexpr (!(GA2_ABL & 1)) { if (with_x) ga2_dma<q * 1024>(xo[q], xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
         }
     };
-    auto issue_all = [&](int u, int slot) {
-        dma_piece(std::integral_constant<int, 0>{}, u, slot);
-        if constexpr (G::NV > 1) dma_piece(std::integral_constant<int, 1>{}, u, slot);
-        if constexpr (G::NV > 2) dma_piece(std::integral_constant<int, 2>{}, u, slot);
-        if constexpr (G::NV > 3) dma_piece(std::integral_constant<int, 3>{}, u, slot);
-        if constexpr (G::NV > 4) dma_piece(std::integral_constant<int, 4>{}, u, slot);
-        if constexpr (G::NV > 5) dma_piece(std::integral_constant<int, 5>{}, u, slot);
-    };
-    static_assert(G::NV <= 6, "issue_all covers at most 6 pieces");
+    // piece d (a loop index the unroller resolves) -> dma_piece<d>
+#define GA2_DMA_AT(d, ...)                                   \
+    do {                                                     \
+        if ((d) == 0) dma_piece(I0{}, __VA_ARGS__);          \
+        if ((d) == 1) dma_piece(I1{}, __VA_ARGS__);          \
+        if ((d) == 2) dma_piece(I2{}, __VA_ARGS__);          \
+        if ((d) == 3) dma_piece(I3{}, __VA_ARGS__);          \
+        if ((d) == 4) dma_piece(I4{}, __VA_ARGS__);          \
+        if ((d) == 5) dma_piece(I5{}, __VA_ARGS__);          \
+    } while (0)
 
-    // epilogue vectors bv, bu, Ww -> LDS (rows K..KP-1 of Ww zero); visible after the first step barrier
+    // epilogue vectors bv, bu, Ww, bw -> LDS once per workgroup (rows K..KP-1 of Ww zero); visible after the first step barrier
     {
         const float* src = (const float*)(a.packed + L.tab_off);
         float* dst = (float*)(smem + G::TAB_OFF);
         for (int e = tid; e < (2 + KP) * GA_DA; e += NTHR) dst[e] = (e < (2 + K) * GA_DA) ? src[e] : 0.0f;
+        if (tid < 8) dst[(2 + KP) * GA_DA + tid] = ((const float*)(a.packed + L.bw_off))[tid];
     }
 
-#ifdef GA2_DEPHASE
-    // HW_REG_LDS_ALLOC[7:0] = LDS base of this workgroup: non-zero for the second workgroup resident on a CU
-    if (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) != 0 && blockIdx.x < 1024)
-        for (int i = 0; i < GA2_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
-    f32x16 acc1[ND];
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[d][r] = 0.0f;
+    // ---- tile drawing.  One lane of wave 0 adds 1 to the global counter (returning atomic, issued early, waited for late);
+    // the result travels to the other waves through one LDS word and a barrier that is there anyway.
+    unsigned* const nn_lds = (unsigned*)(smem + G::ML_OFF + WAVES * 8 * 2 * 4);
+    unsigned draw_raw = 0;
+    auto draw_issue = [&]() {      // wave 0 only
+        unsigned long long keep;
+        const unsigned zero = 0, one = 1;
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                     : "=&v"(draw_raw), "=&s"(keep) : "v"(zero), "v"(one), "s"(a.tile_counter) : "memory");
+    };
+    auto draw_publish = [&]() {    // wave 0 only, at a point where the look-ahead DMAs were issued long ago: vmcnt(0) costs nothing
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(draw_raw) :: "memory");
+        const unsigned v = __builtin_amdgcn_readfirstlane(draw_raw) + gridDim.x;
+        if ((tid & 63) == 0) *nn_lds = v;
+    };
+    const bool dynamic = a.tile_counter != nullptr;
 
+    int tile = blockIdx.x;
+    int ntile = tile + (int)gridDim.x;       // static striding unless a counter is given
+    if (dynamic) {
+        if (wave == 0) { draw_issue(); draw_publish(); }
+        __syncthreads();                      // nothing is in flight yet
+        ntile = (int)__builtin_amdgcn_readfirstlane(*nn_lds);
+    }
+    TileInfo T = tile_info(tile);
+
+    // De-phase the two workgroups of a CU: HW_REG_LDS_ALLOC[7:0] (LDS base) is non-zero for the second one.
+    if (a.dephase > 0 && __builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) != 0)
+        for (int i = 0; i < a.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+
+    // prologue: steps 0 and 1 of the first tile
     int islot = 0;   // ring slot the next issued step goes to
+    {
+        const int ln = ga2_lane();
+        unsigned xo[G::XG];
+        tile_xoff(T, ln, xo);
 #pragma unroll
-    for (int s = 0; s < G::PD; ++s) { issue_all(s, islot); islot = (islot + 1 == G::NB) ? 0 : islot + 1; }
-
-    // ---- x operand of a step: raw read from the wave's own tile, then f16 hi/lo split
-    const int xrd0 = wave * G::REGION + G::RW * 1024 +
-                     ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
-    const int xrd1 = wave * G::REGION + G::RW * 1024 + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
-    f32x4 xr0, xr1;      // raw fp32
-    u32x4 xrw;           // raw 16-bit (8 elements)
-    auto read_x = [&](const char* slot) {
-        if constexpr (GA2_ABL & 256) { asm volatile("" : "+v"(xr0), "+v"(xr1), "+v"(xrw)); return; }
-        if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
-        else xrw = *(const u32x4*)(slot + xrd0);
-    };
-    // split piece j (< NSP) of the raw tile into word j of the hi / lo operands (two K slots per piece)
-    constexpr int NSP = XLO ? 4 : 0;
-    u32x4 xhw, xlw;
-    auto split_piece = [&](int j) {
-        if constexpr (GA2_ABL & 256) { asm volatile("" : "+v"(xhw), "+v"(xlw)); return; }
-        float v0, v1;
-        if constexpr (XDT == ACMIL_DTYPE_F32) {
-            v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
-            v1 = j < 2 ? xr0[2 * (j & 1) + 1] : xr1[2 * (j & 1) + 1];
-        } else {
-            v0 = __builtin_bit_cast(float, xrw[j] << 16);
-            v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
+        for (int s = 0; s < PD; ++s) {
+#pragma unroll
+            for (int m = 0; m < G::NVX; ++m) GA2_DMA_AT(m, s, islot, (unsigned)ln * 16, true, T.xrow0, xo);
+            islot = (islot + 1 == NB) ? 0 : islot + 1;
         }
-        unsigned h, l;
-        ga2_split_pair(v0, v1, h, l);
-        xhw[j] = h; xlw[j] = l;
-    };
-    auto split_done = [&](f16x8& h8, f16x8& l8) {
-        if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
-        else h8 = __builtin_bit_cast(f16x8, xrw);
-    };
-
-    // =========================================================== GEMM1: h^T = W1 * x^T
-    f16x8 WH[ND], WL[ND];
-    f16x8 xh, xl, xhp;
+    }
     int rslot = 0;   // ring slot of the step being consumed
-    const int lane16 = lane * 16;
-    auto read_hi = [&](const char* slot) {
-        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(WH[d])); return; }
-#pragma unroll
-        for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
-    };
-    auto read_lo = [&](const char* slot) {
-        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(WL[d])); return; }
-#pragma unroll
-        for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
-    };
+
 #ifdef GA2_PROF
-    unsigned long long pf_vm = 0, pf_bar = 0, pf_vm1 = 0, pf_bar1 = 0;
-    const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pf_vm = 0, pf_bar = 0;
 #endif
-    auto step_sync = [&]() {
+    // Before reading slot s: this wave's pieces of step s have landed (at most the NEXT step's pieces stay in flight: they
+    // were issued one step ago, step s's two steps ago), every read of the slot about to be recycled has returned, barrier.
+    auto step_sync = [&](bool next_has_x) {
 #ifdef GA2_PROF
         const unsigned long long ta = __builtin_amdgcn_s_memtime();
 #endif
-        ga_wait_vm<(G::PD - 1) * G::NV>();      // this wave's pieces of the step about to be consumed have landed
+        if (next_has_x) ga_wait_vm<G::NVX>(); else ga_wait_vm<G::NVW>();
 #ifdef GA2_PROF
         const unsigned long long tb = __builtin_amdgcn_s_memtime();
 #endif
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): every read of the slot about to be recycled has returned
-        if constexpr (!(GA2_ABL & 16)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
 #ifdef GA2_PROF
         const unsigned long long tc = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xc07f);
         pf_vm += tb - ta; pf_bar += tc - tb;
 #endif
     };
-
-    // ---- step 0 (nothing deferred yet)
-    step_sync();
-    {
-        const char* slot = smem + rslot * G::SLOT;
-        read_x(slot);
-        read_hi(slot);
-#pragma unroll
-        for (int j = 0; j < NSP; ++j) split_piece(j);
-        split_done(xh, xl);
-        __builtin_amdgcn_sched_barrier(0);
-        read_lo(slot);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        issue_all(G::PD, islot);
-        islot = (islot + 1 == G::NB) ? 0 : islot + 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (XLO) {
-#pragma unroll
-            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
-        }
-        xhp = xh;
-        rslot = (rslot + 1 == G::NB) ? 0 : rslot + 1;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    for (int s = 1; s < S1; ++s) {
-        step_sync();
-        const char* slot = smem + rslot * G::SLOT;
-        read_x(slot);      // first: the LDS returns data in order, so the split can start under the hi-fragment reads
-        read_hi(slot);
-        __builtin_amdgcn_sched_barrier(0);
-        // P3(s-1) covers the reads above; the split of x(s) runs in its first MFMA gaps
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
-            if (d < NSP) {
-                __builtin_amdgcn_sched_barrier(0);
-                split_piece(d);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        split_done(xh, xl);
-        __builtin_amdgcn_sched_barrier(0);
-        read_lo(slot);
-        // P1(s), one LDS-DMA piece of step s+PD per MFMA gap
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (d == 0) dma_piece(std::integral_constant<int, 0>{}, s + G::PD, islot);
-            if (d == 1 && G::NV > 1) dma_piece(std::integral_constant<int, (G::NV > 1 ? 1 : 0)>{}, s + G::PD, islot);
-            if (d == 2 && G::NV > 2) dma_piece(std::integral_constant<int, (G::NV > 2 ? 2 : 0)>{}, s + G::PD, islot);
-            if (d == 3 && G::NV > 3) dma_piece(std::integral_constant<int, (G::NV > 3 ? 3 : 0)>{}, s + G::PD, islot);
-            if (d == 4 && G::NV > 4) dma_piece(std::integral_constant<int, (G::NV > 4 ? 4 : 0)>{}, s + G::PD, islot);
-            if (d == 5 && G::NV > 5) dma_piece(std::integral_constant<int, (G::NV > 5 ? 5 : 0)>{}, s + G::PD, islot);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        islot = (islot + 1 == G::NB) ? 0 : islot + 1;
-        if constexpr (XLO) {
-#pragma unroll
-            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        xhp = xh;
-        rslot = (rslot + 1 == G::NB) ? 0 : rslot + 1;
-    }
-    // P3 of the last GEMM1 step
-#pragma unroll
-    for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
-#ifdef GA2_PROF
-    const unsigned long long pf_t1 = __builtin_amdgcn_s_memtime();
-    pf_vm1 = pf_vm; pf_bar1 = pf_bar;
-#endif
-
-    // =========================================================== relu + f16 split of h (see v1 for the pinning notes)
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
-#pragma unroll
-    for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
-
-    f16x8 hh[ND][2], hl[ND][2];
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = acc1[d][8 * e + j];
-                const _Float16 h16 = (_Float16)v;
-                hh[d][e][j] = h16;
-                hl[d][e][j] = (_Float16)(v - (float)h16);
-            }
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            asm volatile("" : "+v"(hh[d][e]));
-            asm volatile("" : "+v"(hl[d][e]));
-        }
-
-    // =========================================================== GEMM2 (four unit blocks) + gate + scores
-    // fragment rows of a step: (dd*2 + part)*4 + t, t = e*2 + al; WH/WL hold the part-0 / part-1 rows of both h tiles
     const float* tabf = (const float*)(smem + G::TAB_OFF);
-    float sc[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) sc[k] = 0.0f;
-    static_assert(4 * G::DD == ND, "WH/WL hold the 4*DD fragments of a GEMM2 step part");
-    auto read2 = [&](const char* slot, int part, f16x8 (&W)[ND]) {
-        if constexpr (GA2_ABL & 128) { for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(W[d])); return; }
-#pragma unroll
-        for (int dd = 0; dd < G::DD; ++dd)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) W[dd * 4 + t] = *(const f16x8*)(slot + G::frow((dd * 2 + part) * 4 + t) + lane16);
-    };
+    const float* bwp = tabf + (2 + KP) * GA_DA;      // bw[8] (LDS copy: no global load inside the tile loop)
 
-#pragma unroll 1
-    for (int g = 0; g < 4; ++g) {
-        f32x16 acc2[2];
+    // =============================================================================================== tile loop
+    for (;;) {
+#ifdef GA2_PROF
+        const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long pf_vm0 = pf_vm, pf_bar0 = pf_bar;
+#endif
+        // the tile after this one (its first steps are prefetched by this tile's last steps); none -> refetch this tile's rows
+        const bool has_next = ntile < ntiles;
+        const TileInfo TN = tile_info(has_next ? ntile : tile);
+        if (dynamic && has_next && wave == 0) draw_issue();      // the tile after the next one
+        // Drain the scalar-load counter with the BUILTIN (which hipcc's wait-count pass models): otherwise pending s_loads
+        // make lgkmcnt "out of order" in the compiler's model and every first MFMA of a group waits lgkmcnt(0).
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+
+        f32x16 acc1[ND];
 #pragma unroll
-        for (int al = 0; al < 2; ++al)
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                int boff = 32 * g + 8 * rq + 4 * hi;
-                asm volatile("" : "+v"(boff) : "v"(sc[0]));
-                const f32x4 b = *(const f32x4*)(tabf + al * GA_DA + boff);
-                acc2[al][4 * rq + 0] = b[0]; acc2[al][4 * rq + 1] = b[1];
-                acc2[al][4 * rq + 2] = b[2]; acc2[al][4 * rq + 3] = b[3];
-            }
+            for (int r = 0; r < 16; ++r) acc1[d][r] = 0.0f;
+
+        // ======================================================= GEMM1: h^T = W1 * x^T
+        {
+            const int ln = ga2_lane();
+            const int i31 = ln & 31, hi = ln >> 5;
+            const int lane16 = ln * 16;
+            unsigned xoff[G::XG];
+            tile_xoff(T, ln, xoff);
+            // x operand of a step: raw read from the wave's own tile, then f16 hi/lo split
+            const int xrd0 = wave * G::REGION + G::RW * 1024 +
+                             ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
+            const int xrd1 = wave * G::REGION + G::RW * 1024 + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
+            f32x4 xr0, xr1;      // raw fp32
+            u32x4 xrw;           // raw 16-bit (8 elements)
+            auto read_x = [&](const char* slot) {
+                if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
+                else xrw = *(const u32x4*)(slot + xrd0);
+            };
+            // split piece j (< NSP) of the raw tile into word j of the hi / lo operands (two K slots per piece)
+            constexpr int NSP = XLO ? 4 : 0;
+            u32x4 xhw, xlw;
+            auto split_piece = [&](int j) {
+                float v0, v1;
+                if constexpr (XDT == ACMIL_DTYPE_F32) {
+                    v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
+                    v1 = j < 2 ? xr0[2 * (j & 1) + 1] : xr1[2 * (j & 1) + 1];
+                } else {
+                    v0 = __builtin_bit_cast(float, xrw[j] << 16);
+                    v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
+                }
+                unsigned h, l;
+                ga2_split_pair(v0, v1, h, l);
+                xhw[j] = h; xlw[j] = l;
+            };
+            auto split_done = [&](f16x8& h8, f16x8& l8) {
+                if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
+                else h8 = __builtin_bit_cast(f16x8, xrw);
+            };
+            f16x8 WH[ND], WL[ND];
+            auto read_hi = [&](const char* slot) {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int u = S1 + g * 4 + st;
-            step_sync();
-            const char* slot = smem + rslot * G::SLOT;
-            read2(slot, 0, WH);
-            __builtin_amdgcn_sched_barrier(0);
-            if (st > 0) {   // P3 of the previous step of this block
+                for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
+            };
+            auto read_lo = [&](const char* slot) {
 #pragma unroll
-                for (int dd = 0; dd < G::DD; ++dd)
+                for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
+            };
+            __builtin_amdgcn_s_setprio(GA2_PRIO_GEMM);
+            f16x8 xh, xl, xhp;
+            // defined values at loop entry: otherwise LLVM treats the fragments of the PREVIOUS tile's last step as the
+            // incoming values of the step loop and keeps 36 registers alive (spilled) through GEMM2 and the epilogue
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc2[t & 1] = GA2_MFMA2(WL[dd * 4 + t], hh[G::DD * (st - 1) + dd][t >> 1], acc2[t & 1]);
+            for (int d = 0; d < ND; ++d) WL[d] = (f16x8)(_Float16)0.0f;
+            xhp = (f16x8)(_Float16)0.0f;
+            for (int s = 0; s < S1; ++s) {
+                step_sync(s + 1 < S1);
+                const char* slot = smem + rslot * G::SLOT;
+                read_x(slot);      // first: the LDS returns data in order, so the split can start under the hi-fragment reads
+                read_hi(slot);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            read2(slot, 1, WL);
+                if (s > 0) {
+                    // P3(s-1) covers the reads above; the split of x(s) runs in its first MFMA gaps
 #pragma unroll
-            for (int dd = 0; dd < G::DD; ++dd)
+                    for (int d = 0; d < ND; ++d) {
+                        acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+                        if (d < NSP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            split_piece(d);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {   // first step of the tile: nothing deferred yet
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int m = dd * 4 + t;
-                    acc2[t & 1] = GA2_MFMA2(WH[m], hh[G::DD * st + dd][t >> 1], acc2[t & 1]);
+                    for (int j = 0; j < NSP; ++j) split_piece(j);
+                }
+                split_done(xh, xl);
+                __builtin_amdgcn_sched_barrier(0);
+                read_lo(slot);
+                // P1(s), one LDS-DMA piece of step s+PD per MFMA gap (bag rows only while that step is still a GEMM1 step)
+                const bool wx = s + PD < S1;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (m == 0) dma_piece(std::integral_constant<int, 0>{}, u + G::PD, islot);
-                    if (m == 1 && G::NV > 1) dma_piece(std::integral_constant<int, (G::NV > 1 ? 1 : 0)>{}, u + G::PD, islot);
-                    if (m == 2 && G::NV > 2) dma_piece(std::integral_constant<int, (G::NV > 2 ? 2 : 0)>{}, u + G::PD, islot);
-                    if (m == 3 && G::NV > 3) dma_piece(std::integral_constant<int, (G::NV > 3 ? 3 : 0)>{}, u + G::PD, islot);
-                    if (m == 4 && G::NV > 4) dma_piece(std::integral_constant<int, (G::NV > 4 ? 4 : 0)>{}, u + G::PD, islot);
-                    if (m == 5 && G::NV > 5) dma_piece(std::integral_constant<int, (G::NV > 5 ? 5 : 0)>{}, u + G::PD, islot);
+                    GA2_DMA_AT(d, s + PD, islot, (unsigned)lane16, wx, T.xrow0, xoff);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            islot = (islot + 1 == G::NB) ? 0 : islot + 1;
+                islot = (islot + 1 == NB) ? 0 : islot + 1;
+                if constexpr (XLO) {
 #pragma unroll
-            for (int dd = 0; dd < G::DD; ++dd)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc2[t & 1] = GA2_MFMA2(WH[dd * 4 + t], hl[G::DD * st + dd][t >> 1], acc2[t & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (st == 3) {   // the block's last step finishes its own P3: the gate needs the complete accumulators
-#pragma unroll
-                for (int dd = 0; dd < G::DD; ++dd)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc2[t & 1] = GA2_MFMA2(WL[dd * 4 + t], hh[G::DD * 3 + dd][t >> 1], acc2[t & 1]);
+                    for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                xhp = xh;
+                rslot = (rslot + 1 == NB) ? 0 : rslot + 1;
             }
-            rslot = (rslot + 1 == G::NB) ? 0 : rslot + 1;
+            // P3 of the last GEMM1 step
+#pragma unroll
+            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+            __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
         }
-        if constexpr (GA2_ABL & 64) { asm volatile("" :: "v"(acc2[0]), "v"(acc2[1])); continue; }
-        // gate + partial scores for the 32 units of this block (this lane: 16 of them)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            int ubase = 32 * g + 8 * rq + 4 * hi;
-            float gate[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gate[q] = ga_tanh(acc2[0][4 * rq + q]) * ga_sigmoid(acc2[1][4 * rq + q]);
-            asm volatile("" : "+v"(ubase) : "v"(gate[3]));
-#pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                const f32x4 w = *(const f32x4*)(tabf + (2 + k) * GA_DA + ubase);
-                sc[k] = fmaf(gate[0], w[0], sc[k]); sc[k] = fmaf(gate[1], w[1], sc[k]);
-                sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
-            }
-        }
-    }
-
 #ifdef GA2_PROF
-    const unsigned long long pf_t2 = __builtin_amdgcn_s_memtime();
+        const unsigned long long pf_t1 = __builtin_amdgcn_s_memtime();
+        const unsigned long long pf_vm1 = pf_vm, pf_bar1 = pf_bar;
 #endif
-    const float* bwp = (const float*)(a.packed + L.bw_off);
-    float smax[KP], lsum[KP], pe[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        sc[k] += __shfl_xor(sc[k], 32);
-        sc[k] += bwp[k];
-        if (A_out && valid && hi == 0 && k < K) A_out[(size_t)k * N + row] = sc[k];
-        float m = valid ? sc[k] : -INFINITY;
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        smax[k] = m;
-        pe[k] = valid ? __expf(sc[k] - m) : 0.0f;
-        float l = pe[k];
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o);
-        lsum[k] = l;
-    }
 
-    if constexpr (GA2_ABL & 32) return;
-    // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
-    ga_wait_vm<0>();  // the clamped tail DMAs still target the ring: drain them before it is reused
-    __syncthreads();
-    float* pool = (float*)(smem + wave * G::POOLW);
-    float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;
-    if (POOL && hi == 0) {
+        // ======================================================= relu + f16 split of h
+        // acc1[d][r] holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)].  The empty asm statements keep LLVM from
+        // sinking the relu / split into the GEMM2 steps (old and new values live together -> hundreds of spills).
 #pragma unroll
-        for (int k = 0; k < KP; ++k) pl[k * 32 + i31] = pe[k];
-    }
-    float pacc[NCH][KP];
+        for (int d = 0; d < ND; ++d)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
+            for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
 #pragma unroll
-        for (int k = 0; k < KP; ++k) pacc[c][k] = 0.0f;
+        for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
+        f16x8 hh[ND][2], hl[ND][2];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                u32x4 hw, lw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned h, l;
+                    ga2_split_pair(acc1[d][8 * e + 2 * j], acc1[d][8 * e + 2 * j + 1], h, l);
+                    hw[j] = h; lw[j] = l;
+                }
+                hh[d][e] = __builtin_bit_cast(f16x8, hw);
+                hl[d][e] = __builtin_bit_cast(f16x8, lw);
+            }
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                asm volatile("" : "+v"(hh[d][e]));
+                asm volatile("" : "+v"(hl[d][e]));
+            }
 
+        // ======================================================= GEMM2 (four unit blocks) + gate + scores
+        float sc[KP];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < KP; ++k) sc[k] = 0.0f;
+        {
+            // Fragment rows of a step: (dd*2 + part)*4 + t, t = e*2 + al: four groups of 4 rows, consumed in the order
+            // G0 = hi(dd 0), G1 = lo(dd 0), G2 = hi(dd 1), G3 = lo(dd 1).  Two 4-fragment buffers ping-pong (hh/hl already hold
+            // 128 registers here): group i+1 is requested while group i computes, and G3 of a step is deferred across the next
+            // step's barrier, where it covers the request of that step's G0.
+            // (Di = 128: one h tile per step, groups G0 / G1 only)
+            static_assert(G::DD == 2 || G::DD == 1, "GEMM2 step = one or two h tiles");
+            f16x8 FA[4], FB[4];
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {
+                const int ln = ga2_lane();
+                const int hi = ln >> 5, lane16 = ln * 16;
+                auto readgrp = [&](const char* slot, int grp, f16x8 (&F)[4]) {
 #pragma unroll
-        for (int dl = 0; dl < 2; ++dl)
+                    for (int t = 0; t < 4; ++t) F[t] = *(const f16x8*)(slot + G::frow(grp * 4 + t) + lane16);
+                };
+                // unit block g = units 32g..32g+31: accumulator tile al = 0 tanh branch, 1 sigmoid branch; init = bias
+                f32x16 acc2[2];
+#pragma unroll
+                for (int al = 0; al < 2; ++al)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        int boff = 32 * g + 8 * rq + 4 * hi;
+                        asm volatile("" : "+v"(boff) : "v"(sc[0]));   // order after the previous block's epilogue
+                        const f32x4 b = *(const f32x4*)(tabf + al * GA_DA + boff);
+                        acc2[al][4 * rq + 0] = b[0]; acc2[al][4 * rq + 1] = b[1];
+                        acc2[al][4 * rq + 2] = b[2]; acc2[al][4 * rq + 3] = b[3];
+                    }
+                __builtin_amdgcn_s_setprio(GA2_PRIO_GEMM);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int j = g * 4 + st;                       // GEMM2 step; tile step u = S1 + j
+                    const int d0 = G::DD * st, d1 = G::DD * st + G::DD - 1;   // h tiles of this step (d1 == d0 when DD == 1)
+                    // the step after this one needs bag rows only when it is step 0 of the next tile
+                    step_sync(j + 1 == S2);
+                    const char* slot = smem + rslot * G::SLOT;
+                    readgrp(slot, 0, FA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st > 0) {   // last group (lo x hh) of the previous step of this block
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = GA2_MFMA2(FB[t], hh[d0 - 1][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    readgrp(slot, 1, FB);
+                    // step j+PD of this tile, or step j+PD-S2 of the NEXT tile (weights restart at the stream head, bag rows of TN)
+                    const bool nx = j + PD >= S2;
+                    const int un = nx ? j + PD - S2 : S1 + j + PD;
+                    unsigned xoffn[G::XG];
+                    tile_xoff(TN, ln, xoffn);     // used by 2 steps per tile: recomputed there instead of carried through GEMM2
+                    // G0: hi(dd 0) x (hh, hl), one LDS-DMA piece per MFMA gap
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc2[t & 1] = GA2_MFMA2(FA[t], hh[d0][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        GA2_DMA_AT(t, un, islot, (unsigned)lane16, nx, TN.xrow0, xoffn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        acc2[t & 1] = GA2_MFMA2(FA[t], hl[d0][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        GA2_DMA_AT(4 + t, un, islot, (unsigned)lane16, nx, TN.xrow0, xoffn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    islot = (islot + 1 == NB) ? 0 : islot + 1;
+                    if constexpr (G::DD == 2) {
+                        readgrp(slot, 2, FA);
+                        // G1: lo(dd 0) x hh
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = GA2_MFMA2(FB[t], hh[d0][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        readgrp(slot, 3, FB);
+                        // G2: hi(dd 1) x (hh, hl)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = GA2_MFMA2(FA[t], hh[d1][t >> 1], acc2[t & 1]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = GA2_MFMA2(FA[t], hl[d1][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (st == 3) {   // the block's last step finishes its own G3: the gate needs the complete accumulators
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[t & 1] = GA2_MFMA2(FB[t], hh[d1][t >> 1], acc2[t & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    rslot = (rslot + 1 == NB) ? 0 : rslot + 1;
+                }
+                __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
+                // gate + partial scores for the 32 units of this block (this lane: 16 of them)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    int ubase = 32 * g + 8 * rq + 4 * hi;
+                    float gate[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gate[q] = ga_tanh(acc2[0][4 * rq + q]) * ga_sigmoid(acc2[1][4 * rq + q]);
+                    // tie the table address to the gate value: keeps each read next to its use (no mass hoisting + spill)
+                    asm volatile("" : "+v"(ubase) : "v"(gate[3]));
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const f32x4 w = *(const f32x4*)(tabf + (2 + k) * GA_DA + ubase);
+                        sc[k] = fmaf(gate[0], w[0], sc[k]); sc[k] = fmaf(gate[1], w[1], sc[k]);
+                        sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
+                    }
+                }
+            }
+        }
+#ifdef GA2_PROF
+        const unsigned long long pf_t2 = __builtin_amdgcn_s_memtime();
+#endif
+
+        // ======================================================= scores, wave-level softmax statistics
+        const int lane = ga2_lane();
+        const int i31 = lane & 31, hi = lane >> 5;
+        const int N = T.N, m0 = T.m0;
+        float* A_out = T.A_out;
+        const int row = m0 + i31;
+        const bool valid = row < N;
+        float smax[KP], lsum[KP], pe[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            sc[k] += __shfl_xor(sc[k], 32);      // the other lane-half holds the other 64 attention units
+            sc[k] += bwp[k];
+            if (A_out && valid && hi == 0 && k < K) A_out[(size_t)k * N + row] = sc[k];
+            float m = valid ? sc[k] : -INFINITY;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            smax[k] = m;
+            pe[k] = valid ? __expf(sc[k] - m) : 0.0f;
+            float l = pe[k];
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+            lsum[k] = l;
+        }
+
+        // ======================================================= attention-weighted sum  sum_n p[k][n] h[n][:]
+        // Scratch: the ring slot consumed last (the two others hold the next tile's first steps, in flight) or the separate
+        // region.  h is transposed through a wave-private padded tile, 32 features at a time: lane (f = lane&31, ph = lane>>5)
+        // accumulates feature f over patches 16ph .. 16ph+15.  No vmcnt / __syncthreads here: the DMA ring stays in flight.
+        const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
+        char* const scr = G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW;
+        float* pool = (float*)scr;
+        float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // [KP][32 m]
+        if (POOL && hi == 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) pl[k * 32 + i31] = pe[k];
+        }
+        float pacc[ND][KP];
+#pragma unroll
+        for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) pacc[c][k] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+            __builtin_amdgcn_sched_barrier(0);   // one chunk at a time
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float hv = (float)hh[2 * c + dl][r >> 3][r & 7] + (float)hl[2 * c + dl][r >> 3][r & 7];
-                pool[(dl * 32 + mfma32_row(r, hi)) * 36 + i31] = hv;
+                const float hv = (float)hh[c][r >> 3][r & 7] + (float)hl[c][r >> 3][r & 7];
+                pool[mfma32_row(r, hi) * 36 + i31] = hv;
             }
-        __builtin_amdgcn_wave_barrier();
-        const f32x4* prow = (const f32x4*)(pool + lane * 36);
-#pragma unroll 2
-        for (int mq = 0; mq < 8; ++mq) {
-            const f32x4 hv = prow[mq];
-            if constexpr (SAVEH) {
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);    // feature 32c + (lane&31), patches 16hi..
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (m0 + 4 * mq + e < N) a.h_save[(size_t)(m0 + 4 * mq + e) * Di + 64 * c + lane] = hv[e];
+            for (int mq = 0; mq < 4; ++mq) {
+                const f32x4 hv = prow[mq];
+                if constexpr (SAVEH) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * c + i31] = hv[e];
+                }
+                if constexpr (POOL) {
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const f32x4 p = *(const f32x4*)(pl + k * 32 + 16 * hi + 4 * mq);
+                        pacc[c][k] = fmaf(p[0], hv[0], pacc[c][k]); pacc[c][k] = fmaf(p[1], hv[1], pacc[c][k]);
+                        pacc[c][k] = fmaf(p[2], hv[2], pacc[c][k]); pacc[c][k] = fmaf(p[3], hv[3], pacc[c][k]);
+                    }
+                }
             }
+            // pin the sums here: LLVM otherwise sinks every FMA into the (k < K) branches of the combine and spills its operands
             if constexpr (POOL) {
 #pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    const f32x4 p = *(const f32x4*)(pl + k * 32 + 4 * mq);
-                    pacc[c][k] = fmaf(p[0], hv[0], pacc[c][k]); pacc[c][k] = fmaf(p[1], hv[1], pacc[c][k]);
-                    pacc[c][k] = fmaf(p[2], hv[2], pacc[c][k]); pacc[c][k] = fmaf(p[3], hv[3], pacc[c][k]);
+                for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(pacc[c][k]));
+            }
+        }
+
+        if constexpr (POOL) {
+            // =================================================== combine the 4 waves, publish the tile's partial
+            __builtin_amdgcn_wave_barrier();
+            float* comb = (float*)scr;   // [KP][Di], overlays this wave's (now dead) pooling tile
+            float* ml = (float*)(smem + G::ML_OFF);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                if (k < K) {
+                    if (lane == 0) { ml[(wave * 8 + k) * 2 + 0] = smax[k]; ml[(wave * 8 + k) * 2 + 1] = lsum[k]; }
+#pragma unroll
+                    for (int c = 0; c < ND; ++c) {
+                        const float v = pacc[c][k] + __shfl_xor(pacc[c][k], 32);
+                        if (hi == 0) comb[k * Di + 32 * c + i31] = v;
+                    }
+                }
+            }
+            if (dynamic && has_next && wave == 0) draw_publish();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+            constexpr int PS = 2 + Di;
+            float* out = a.part + (size_t)tile * K * PS;
+            const int scr_stride = G::SCRATCH_IN_RING ? G::REGION : G::PW;
+            const char* scr0 = G::SCRATCH_IN_RING ? smem + fslot * G::SLOT : smem + G::SCR_OFF;
+            for (int k = 0; k < K; ++k) {
+                float mw[WAVES], M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) { mw[w] = ml[(w * 8 + k) * 2]; M = fmaxf(M, mw[w]); }
+                float fw[WAVES];
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) fw[w] = (mw[w] == -INFINITY) ? 0.0f : __expf(mw[w] - M);
+                for (int e = tid; e < Di; e += NTHR) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) v = fmaf(fw[w], ((const float*)(scr0 + w * scr_stride))[k * Di + e], v);
+                    out[k * PS + 2 + e] = v;
+                }
+                if (tid == 0) {
+                    float lt = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) lt = fmaf(fw[w], ml[(w * 8 + k) * 2 + 1], lt);
+                    out[k * PS + 0] = M; out[k * PS + 1] = lt;
                 }
             }
         }
-    }
-    if constexpr (!POOL) return;
-
-    // =========================================================== combine the waves, publish the partial
-    __builtin_amdgcn_wave_barrier();
-    constexpr int PS = 2 + Di;
-    static_assert(KP * PS * 4 <= G::POOLW, "combine record must fit the wave's pooling tile");
-    float* comb = pool;
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-        if (k < K) {
-            if (lane == 0) { comb[k * PS + 0] = smax[k]; comb[k * PS + 1] = lsum[k]; }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) comb[k * PS + 2 + 64 * c + lane] = pacc[c][k];
-        }
-    }
-    __syncthreads();
-    float* out = a.part + (size_t)blockIdx.x * K * PS;
-    for (int k = 0; k < K; ++k) {
-        float mw[WAVES], M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            mw[w] = ((const float*)(smem + w * G::POOLW))[k * PS + 0];
-            M = fmaxf(M, mw[w]);
-        }
-        float fw[WAVES];
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) fw[w] = (mw[w] == -INFINITY) ? 0.0f : __expf(mw[w] - M);
-        for (int e = tid; e < PS; e += NTHR) {
-            float v;
-            if (e == 0) v = M;
-            else {
-                v = 0.0f;
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) v = fmaf(fw[w], ((const float*)(smem + w * G::POOLW))[k * PS + e], v);
-            }
-            out[k * PS + e] = v;
-        }
-    }
 #ifdef GA2_PROF
-    {
-        const unsigned long long pf_t3 = __builtin_amdgcn_s_memtime();
-        const float pv[8] = {(float)(pf_t3 - pf_t0), (float)pf_vm1, (float)pf_bar1, (float)(pf_vm - pf_vm1), (float)(pf_bar - pf_bar1),
-                             (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_t2)};
-        __syncthreads();
-        if (A_out && lane < 8 && m0 + 8 <= N) A_out[m0 + lane] = pv[lane];
+        {
+            const unsigned long long pf_t3 = __builtin_amdgcn_s_memtime();
+            const float pv[8] = {(float)(pf_t3 - pf_t0), (float)(pf_vm1 - pf_vm0), (float)(pf_bar1 - pf_bar0), (float)(pf_vm - pf_vm1),
+                                 (float)(pf_bar - pf_bar1), (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_t2)};
+            if (A_out && lane < 8 && m0 + 8 <= N) A_out[m0 + lane] = pv[lane];
+            // start time (two 24-bit halves), CU identity (HW_ID, XCC_ID), second-workgroup flag, workgroup id
+            const float pw[8] = {(float)(unsigned)(pf_t0 & 0xffffff), (float)(unsigned)((pf_t0 >> 24) & 0xffffff),
+                                 (float)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)), (float)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)),
+                                 (float)__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)), (float)blockIdx.x, (float)tile, 0.0f};
+            if (A_out && lane >= 8 && lane < 16 && m0 + 16 <= N) A_out[m0 + lane] = pw[lane - 8];
+        }
+#endif
+        if (!has_next) break;
+        if constexpr (!POOL) {
+            if (dynamic) {
+                if (wave == 0) draw_publish();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        tile = ntile;
+        ntile = dynamic ? (int)__builtin_amdgcn_readfirstlane(*nn_lds) : tile + (int)gridDim.x;
+        T = TN;
+        // the scratch (possibly a ring slot) is released by the next step's barrier: every wave reaches it after its epilogue
     }
-#endif
+#undef GA2_DMA_AT
+    ga_wait_vm<0>();   // the last tile's look-ahead pieces (re-fetched rows nobody reads) must land before the LDS is released
 }
 
-template <int ND, int KP, int XDT, int WAVES>
-int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    using G = Ga2Geom<ND, KP, XDT, WAVES>;
-    static_assert(G::LDS <= 160 * 1024, "LDS budget");
-#ifndef GA2_LDS_PAD
-    static_assert(WAVES == 8 || 2 * G::LDS <= 160 * 1024, "two 4-wave workgroups must fit one CU");
-#endif
-    const dim3 grid(a.tile_start[a.nbags]), block(64 * WAVES);
-    void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, WAVES, true, false>
-                                   : ga_fwd2_kernel<ND, KP, XDT, WAVES, false, true>;
-    static const hipError_t attr[2] = {
-        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, WAVES, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS),
-        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, WAVES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)};
-    if (attr[0] != hipSuccess || attr[1] != hipSuccess) return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
-    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
-}
-
+// persistent launch: two workgroups per CU (or one per tile when there are fewer tiles)
 template <int ND, int KP, int XDT>
 int ga_launch_fwd2(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    return a.waves == 4 ? ga_launch_fwd2_w<ND, KP, XDT, 4>(a, pool, st) : ga_launch_fwd2_w<ND, KP, XDT, 8>(a, pool, st);
+    using G = Ga2Geom<ND, KP, XDT>;
+    static const int slots = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
+        return 2 * prop.multiProcessorCount;
+    }();
+    static const hipError_t attr[2] = {
+        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS),
+        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)};
+    if (attr[0] != hipSuccess || attr[1] != hipSuccess) return ACMIL_ERR_LAUNCH;
+    const int tiles = a.tile_start[a.nbags];
+    const dim3 grid(tiles < slots ? tiles : slots), block(256);
+    void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, true, false> : ga_fwd2_kernel<ND, KP, XDT, false, true>;
+    hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

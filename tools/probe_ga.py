@@ -72,6 +72,13 @@ def child(args):
         pv = A0[:n32].view(-1, 32)[:, :8].double()
         res["prof_mean"] = [round(float(v)) for v in pv.mean(0)]
         res["prof_names"] = ["total", "g1_vm", "g1_bar", "g2_vm", "g2_bar", "g1", "g2", "epi"]
+        import numpy as np
+        rows = []
+        for b in range(len(out["A_out"])):
+            Ab = out["A_out"][b][0]
+            nb = (Ab.numel() // 32) * 32
+            rows.append(Ab[:nb].view(-1, 32)[:, :16].cpu().numpy())
+        np.save(args.save.replace(".pt", "_prof.npy"), np.concatenate(rows, 0))
     print("PROBE " + json.dumps(res), flush=True)
 
 
