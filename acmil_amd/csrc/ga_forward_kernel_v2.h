@@ -67,7 +67,7 @@ struct Ga2Geom {
     static_assert(ND % 4 == 0, "Di must be a multiple of 128");
     static constexpr int Di = 32 * ND;
     static constexpr int RING = NB * SLOT;
-    static constexpr int PTILE = 32 * 36 * 4;                       // wave-private pooling tile [32 features][32 patches + 4 pad] fp32
+    static constexpr int PTILE = 4608;                              // wave-private transposition image: 2 x 4 planes x 576 B (f16) or [32][36] fp32
     static constexpr int COMB = KP * Di * 4;                        // wave's combine record [KP][Di]
     static constexpr int PW = (PTILE > COMB) ? PTILE : COMB;        // per-wave epilogue scratch
     static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4 + 32;     // bv[128], bu[128], Ww[KP][128], bw[8]
@@ -105,6 +105,13 @@ __device__ __forceinline__ void ga2_split_pair(float x0, float x1, unsigned& hi_
         "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
         : "=&v"(hi_pk), "=&v"(lo_pk) : "v"(x0), "v"(x1));
 }
+
+// DPP move (no LDS): lanes the control / row mask leaves without a source keep `idv`, the identity of the reduction
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ga2_dpp(float v, float idv) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, idv), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 template <int ND, int KP, int XDT, bool POOL, bool SAVEH>
 __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
@@ -531,99 +538,147 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         }
 #ifdef GA2_PROF
         const unsigned long long pf_t2 = __builtin_amdgcn_s_memtime();
+        unsigned long long pf_tb = pf_t2;
 #endif
 
         // ======================================================= scores, wave-level softmax statistics
+        // Everything cross-lane here is DPP / permlane (VALU): no ds_bpermute round trips, no LDS traffic beside the GEMM
+        // of the co-resident workgroup.  The two lane halves (64 attention units each) are folded pairwise with
+        // v_permlane32_swap: afterwards "slot" s holds branch 2s in lanes 0-31 and branch 2s+1 in lanes 32-63.
         const int lane = ga2_lane();
         const int i31 = lane & 31, hi = lane >> 5;
         const int N = T.N, m0 = T.m0;
         float* A_out = T.A_out;
         const int row = m0 + i31;
         const bool valid = row < N;
-        float smax[KP], lsum[KP], pe[KP];
+        constexpr int NS = (KP + 1) / 2;
+        float smax[KP], lsum[KP], pe[NS];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            sc[k] += __shfl_xor(sc[k], 32);      // the other lane-half holds the other 64 attention units
-            sc[k] += bwp[k];
-            if (A_out && valid && hi == 0 && k < K) A_out[(size_t)k * N + row] = sc[k];
-            float m = valid ? sc[k] : -INFINITY;
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            smax[k] = m;
-            pe[k] = valid ? __expf(sc[k] - m) : 0.0f;
-            float l = pe[k];
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) l += __shfl_xor(l, o);
-            lsum[k] = l;
+        for (int sl = 0; sl < NS; ++sl) {
+            // (inline asm: hipcc 7.2 folds sw[0] + sw[1] of __builtin_amdgcn_permlane32_swap into 2 * sw[0]; the s_nops are the
+            //  VALU-write -> permlane-read wait states the compiler would have inserted)
+            float fa = sc[2 * sl], fb = (2 * sl + 1 < KP) ? sc[2 * sl + 1] : 0.0f;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fa), "+v"(fb));   // [a.lo | b.lo], [a.hi | b.hi]
+            const int kk = 2 * sl + hi;                                                  // this lane's branch in slot sl
+            float v = fa + fb;
+            v += bwp[kk < KP ? kk : 0];
+            if (A_out && valid && kk < K) A_out[(size_t)kk * N + row] = v;
+            // inclusive max-scan inside the 16-lane rows, then row 15 -> next row: lane 31 / 63 hold the maximum of their half
+            float m = valid ? v : -INFINITY;
+            m = fmaxf(m, ga2_dpp<0x111, 0xf>(m, -INFINITY)); m = fmaxf(m, ga2_dpp<0x112, 0xf>(m, -INFINITY));
+            m = fmaxf(m, ga2_dpp<0x114, 0xf>(m, -INFINITY)); m = fmaxf(m, ga2_dpp<0x118, 0xf>(m, -INFINITY));
+            m = fmaxf(m, ga2_dpp<0x142, 0xa>(m, -INFINITY));
+            const float mlo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 31));
+            const float mhi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), 63));
+            const float p = valid ? __expf(v - (hi ? mhi : mlo)) : 0.0f;
+            float l = p;
+            l += ga2_dpp<0x111, 0xf>(l, 0.0f); l += ga2_dpp<0x112, 0xf>(l, 0.0f);
+            l += ga2_dpp<0x114, 0xf>(l, 0.0f); l += ga2_dpp<0x118, 0xf>(l, 0.0f);
+            l += ga2_dpp<0x142, 0xa>(l, 0.0f);
+            smax[2 * sl] = mlo;
+            lsum[2 * sl] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), 31));
+            if (2 * sl + 1 < KP) {
+                smax[2 * sl + 1] = mhi;
+                lsum[2 * sl + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, l), 63));
+            }
+            pe[sl] = p;
         }
+#ifdef GA2_PROF
+        const unsigned long long pf_t2a = __builtin_amdgcn_s_memtime();
+#endif
 
         // ======================================================= attention-weighted sum  sum_n p[k][n] h[n][:]
         // Scratch: the ring slot consumed last (the two others hold the next tile's first steps, in flight) or the separate
-        // region.  h is transposed through a wave-private padded tile, 32 features at a time: lane (f = lane&31, ph = lane>>5)
-        // accumulates feature f over patches 16ph .. 16ph+15.  No vmcnt / __syncthreads here: the DMA ring stays in flight.
+        // region.  No vmcnt / __syncthreads here: the DMA ring stays in flight.
         const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
         char* const scr = G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW;
-        float* pool = (float*)scr;
-        float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // [KP][32 m]
-        if (POOL && hi == 0) {
-#pragma unroll
-            for (int k = 0; k < KP; ++k) pl[k * 32 + i31] = pe[k];
-        }
-        float pacc[ND][KP];
-#pragma unroll
-        for (int c = 0; c < ND; ++c)
-#pragma unroll
-            for (int k = 0; k < KP; ++k) pacc[c][k] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < ND; ++c) {
-            __builtin_amdgcn_sched_barrier(0);   // one chunk at a time
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float hv = (float)hh[c][r >> 3][r & 7] + (float)hl[c][r >> 3][r & 7];
-                pool[mfma32_row(r, hi) * 36 + i31] = hv;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);    // feature 32c + (lane&31), patches 16hi..
-#pragma unroll
-            for (int mq = 0; mq < 4; ++mq) {
-                const f32x4 hv = prow[mq];
-                if constexpr (SAVEH) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * c + i31] = hv[e];
-                }
-                if constexpr (POOL) {
-#pragma unroll
-                    for (int k = 0; k < KP; ++k) {
-                        const f32x4 p = *(const f32x4*)(pl + k * 32 + 16 * hi + 4 * mq);
-                        pacc[c][k] = fmaf(p[0], hv[0], pacc[c][k]); pacc[c][k] = fmaf(p[1], hv[1], pacc[c][k]);
-                        pacc[c][k] = fmaf(p[2], hv[2], pacc[c][k]); pacc[c][k] = fmaf(p[3], hv[3], pacc[c][k]);
-                    }
-                }
-            }
-            // pin the sums here: LLVM otherwise sinks every FMA into the (k < K) branches of the combine and spills its operands
-            if constexpr (POOL) {
-#pragma unroll
-                for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(pacc[c][k]));
-            }
-        }
-
+        float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // softmax numerators [KP][32 patches]
         if constexpr (POOL) {
-            // =================================================== combine the 4 waves, publish the tile's partial
+            // On the matrix pipe: D[k][f] = sum_n P[k][n] h[n][f] per 32-feature tile d, A = P (rows = branches, K = the wave's
+            // 32 patches), B = h^T.  h sits in registers with lane = patch; the B operand wants lane = feature.  The f16
+            // fragments hh / hl are written as they are (ds_write_b128, 4 per tile) and read back through the hardware
+            // transpose ds_read_b64_tr_b16 (8 per tile): no fp32 transposition, no conversions, no VALU FMAs.  Split
+            // arithmetic as in the GEMMs: Ph*Hh + Pl*Hh + Ph*Hl, fp32 accumulate.
+            // LDS image of one tile: plane (e, hi) = the 32 lanes' 16-byte words, planes 576 B apart (64 B pad: conflict-free
+            // tr reads); hh planes at 0, hl planes at 2304.
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const int kk = 2 * sl + hi;
+                if (kk < KP) pl[kk * 32 + i31] = pe[sl];
+            }
             __builtin_amdgcn_wave_barrier();
-            float* comb = (float*)scr;   // [KP][Di], overlays this wave's (now dead) pooling tile
+            // A fragments: lane (row k = lane&31, kg = lane>>5) holds P[k][16s + 8kg + j], j < 8, split into f16 hi / lo
+            f16x8 PH[2], PL[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                f32x4 p0 = {0.0f, 0.0f, 0.0f, 0.0f}, p1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (i31 < KP) {
+                    p0 = *(const f32x4*)(pl + i31 * 32 + 16 * st + 8 * hi);
+                    p1 = *(const f32x4*)(pl + i31 * 32 + 16 * st + 8 * hi + 4);
+                }
+                u32x4 hw, lw;
+                unsigned h, l;
+                ga2_split_pair(p0[0], p0[1], h, l); hw[0] = h; lw[0] = l;
+                ga2_split_pair(p0[2], p0[3], h, l); hw[1] = h; lw[1] = l;
+                ga2_split_pair(p1[0], p1[1], h, l); hw[2] = h; lw[2] = l;
+                ga2_split_pair(p1[2], p1[3], h, l); hw[3] = h; lw[3] = l;
+                PH[st] = __builtin_bit_cast(f16x8, hw);
+                PL[st] = __builtin_bit_cast(f16x8, lw);
+            }
+            // write side: lane (patch i31, hi) word e -> plane (e*2 + hi); read side: supplier lane (j = (lane&15)>>2, q = lane&3)
+            // of 16-lane group (G = (lane>>4)&1, kg = lane>>5) addresses patch 8kg + j, features 16G + 4q .. 4q+3
+            const int wr_off = hi * 576 + i31 * 16;
+            const int q = lane & 3;
+            const int rd_off = ((((lane >> 4) & 1) * 2 + (q & 1)) * 576) + 8 * (q >> 1) + 16 * (8 * hi + ((lane & 15) >> 2));
+            typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+            typedef __attribute__((address_space(3))) h16x4* ltr_t;
+            float pk[ND][4];
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                __builtin_amdgcn_sched_barrier(0);
+                *(f16x8*)(scr + wr_off) = hh[d][0];
+                *(f16x8*)(scr + wr_off + 2 * 576) = hh[d][1];
+                *(f16x8*)(scr + 2304 + wr_off) = hl[d][0];
+                *(f16x8*)(scr + 2304 + wr_off + 2 * 576) = hl[d][1];
+                __builtin_amdgcn_wave_barrier();
+                f32x16 accp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    // K step st = patches 16st .. 16st+15; two transposed reads (4 patches each) per fragment
+                    const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st));
+                    const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st + 64));
+                    const h16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st));
+                    const h16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st + 64));
+                    const f16x8 Bh = __builtin_shufflevector(__builtin_bit_cast(f16x4, a0), __builtin_bit_cast(f16x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f16x8 Bl = __builtin_shufflevector(__builtin_bit_cast(f16x4, b0), __builtin_bit_cast(f16x4, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bh, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PL[st], Bh, accp, 0, 0, 0);
+                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bl, accp, 0, 0, 0);
+                }
+                // D rows: register r of lane half hi is branch (r&3) + 8(r>>2) + 4hi -> registers 0..3 = branches 4hi .. 4hi+3
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[d][r] = accp[r];
+                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef GA2_PROF
+            const unsigned long long pf_t2b = __builtin_amdgcn_s_memtime();
+#endif
+            // =================================================== combine the 4 waves, publish the tile's partial
+            float* comb = (float*)scr;   // [KP][Di], overlays this wave's (now dead) transposition image
             float* ml = (float*)(smem + G::ML_OFF);
+            if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < KP; ++k) {
-                if (k < K) {
-                    if (lane == 0) { ml[(wave * 8 + k) * 2 + 0] = smax[k]; ml[(wave * 8 + k) * 2 + 1] = lsum[k]; }
+                for (int k = 0; k < KP; ++k) { ml[(wave * 8 + k) * 2 + 0] = smax[k]; ml[(wave * 8 + k) * 2 + 1] = lsum[k]; }
+            }
 #pragma unroll
-                    for (int c = 0; c < ND; ++c) {
-                        const float v = pacc[c][k] + __shfl_xor(pacc[c][k], 32);
-                        if (hi == 0) comb[k * Di + 32 * c + i31] = v;
-                    }
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 4 * hi + r;
+                if (kk < KP) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) comb[kk * Di + 32 * d + i31] = pk[d][r];
                 }
             }
             if (dynamic && has_next && wave == 0) draw_publish();
@@ -653,12 +708,41 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                     out[k * PS + 0] = M; out[k * PS + 1] = lt;
                 }
             }
+#ifdef GA2_PROF
+            pf_tb = pf_t2b;
+#endif
+        } else {
+            // score pass of the training step (SAVEH): h goes to HBM as fp32 rows.  Transposed through a wave-private padded tile,
+            // 32 features at a time, so that a half-wave stores 128 contiguous bytes of a row.
+            float* pool = (float*)scr;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = (float)hh[c][r >> 3][r & 7] + (float)hl[c][r >> 3][r & 7];
+                    pool[mfma32_row(r, hi) * 36 + i31] = hv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);    // feature 32c + (lane&31), patches 16hi..
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {
+                    const f32x4 hv = prow[mq];
+                    if constexpr (SAVEH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * c + i31] = hv[e];
+                    }
+                }
+            }
         }
 #ifdef GA2_PROF
         {
             const unsigned long long pf_t3 = __builtin_amdgcn_s_memtime();
-            const float pv[8] = {(float)(pf_t3 - pf_t0), (float)(pf_vm1 - pf_vm0), (float)(pf_bar1 - pf_bar0), (float)(pf_vm - pf_vm1),
-                                 (float)(pf_bar - pf_bar1), (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_t2)};
+            const float pv[8] = {(float)(pf_t3 - pf_t0), (float)(pf_vm1 - pf_vm0), (float)(pf_bar1 - pf_bar0), (float)(pf_t2a - pf_t2),
+                                 (float)(pf_tb - pf_t2a), (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_tb)};
             if (A_out && lane < 8 && m0 + 8 <= N) A_out[m0 + lane] = pv[lane];
             // start time (two 24-bit halves), CU identity (HW_ID, XCC_ID), second-workgroup flag, workgroup id
             const float pw[8] = {(float)(unsigned)(pf_t0 & 0xffffff), (float)(unsigned)((pf_t0 >> 24) & 0xffffff),

@@ -71,7 +71,7 @@ def child(args):
         n32 = (A0.numel() // 32) * 32
         pv = A0[:n32].view(-1, 32)[:, :8].double()
         res["prof_mean"] = [round(float(v)) for v in pv.mean(0)]
-        res["prof_names"] = ["total", "g1_vm", "g1_bar", "g2_vm", "g2_bar", "g1", "g2", "epi"]
+        res["prof_names"] = ["total", "g1_vm", "g1_bar", "softmax", "pool", "g1", "g2", "combine"]
         import numpy as np
         rows = []
         for b in range(len(out["A_out"])):
