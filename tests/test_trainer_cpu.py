@@ -119,3 +119,72 @@ def test_data_parallel_gradient_bucket_gloo_world2():
         mean = sum(torch.from_numpy(loc[i]) for loc in r["locals"]) / world
         assert torch.allclose(red, mean, atol=1e-7)
         assert not torch.allclose(torch.from_numpy(r["locals"][0][i]), torch.from_numpy(r["locals"][1][i]))
+
+
+# ---------------------------------------------------------------------------------- bench.py launcher (no GPU needed)
+def test_bench_self_launch_command_and_dry_run_world2():
+    """`python bench.py --gpus 2` without a launcher environment re-executes itself under torch.distributed.run (one rank per
+    GPU, rendezvous on 127.0.0.1); --dry-run drives launcher, rendezvous, barrier and the max-over-ranks reduction on CPU/gloo."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.self_launch_cmd(4, ["--gpus", "4", "--steps", "3"], port=29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for workload in ("ga_eval", "train"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1",
+                            "--workload", workload], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        js = json.loads(line)
+        assert js["dry_run"] is True and js["n_gpus"] == 2 and js["steps"] == 3 and js["value"] is None
+
+
+def _dp_step_worker(rank, world, port, out):
+    """One data-parallel optimizer step wired exactly as bench.py --workload train / train.main: GradBucket first, the optimizer
+    from make_optimizer(..., bucket), gradients written INTO the bucket views, sync_from_grads, allreduce_mean, step."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5, bias=False), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    T.broadcast_parameters(model, world)
+    conf = T.Struct(wd=1e-2)
+    bucket = T.GradBucket(list(model.parameters()))
+    opt = T.make_optimizer(model, conf, torch.device("cpu"), bucket, lr=1e-2)
+    views = [p.grad for p in model.parameters()]
+    assert all(v.data_ptr() >= bucket.flat.data_ptr() for v in views)
+    for step in range(3):
+        grads = []
+        for r in range(2):        # the gradients two ranks would produce (every process can compute both)
+            g = torch.Generator().manual_seed(1000 * step + r)
+            x, y = torch.randn(7, 6, generator=g), torch.randint(0, 3, (7,), generator=g)
+            grads.append(torch.autograd.grad(torch.nn.functional.cross_entropy(model(x), y), list(model.parameters())))
+        mine = grads[rank] if world > 1 else [(a + b) / 2 for a, b in zip(*grads)]
+        for v, gnew in zip(views, mine):      # a fused train_step writes straight into the bucket views
+            v.copy_(gnew)
+        bucket.sync_from_grads()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(model.parameters(), views))
+        bucket.allreduce_mean(world)
+        opt.step()
+    if rank == 0:
+        torch.save([p.detach().clone() for p in model.parameters()], out)
+    if world > 1:
+        chk = [None] * world
+        dist.all_gather_object(chk, [p.detach().numpy() for p in model.parameters()])
+        assert all(np.array_equal(a, b) for a, b in zip(chk[0], chk[-1]))
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_through_bucket_and_make_optimizer_matches_single_process():
+    """2 gloo ranks, each with its own slide, end with identical parameters equal to ONE process stepping on the averaged gradients."""
+    with tempfile.TemporaryDirectory() as d:
+        o2, o1 = os.path.join(d, "w2.pt"), os.path.join(d, "w1.pt")
+        mp.spawn(_dp_step_worker, args=(2, _free_port(), o2), nprocs=2, join=True)
+        _dp_step_worker(0, 1, _free_port(), o1)
+        a, b = torch.load(o2, weights_only=False), torch.load(o1, weights_only=False)
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, atol=1e-6, rtol=1e-6)

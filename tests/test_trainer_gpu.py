@@ -88,3 +88,38 @@ def test_trainer_main_end_to_end(arch, extra, tmp_path):
     T.main(["--arch", arch, "--synthetic_slides", "16", "--synthetic_patches", "600", "--train_epoch", "2", "--out_dir", out] + extra)
     ck = torch.load(os.path.join(out, "checkpoint-last.pth"), weights_only=False)
     assert set(ck) >= {"model", "optimizer", "epoch", "config"} and ck["epoch"] == 1
+
+
+def test_fused_step_shares_bucket_with_flat_adamw():
+    """The wiring of bench.py --workload train / train.main on one GPU: GradBucket first, FlatAdamW on the SAME flat buffer
+    (make_optimizer(..., bucket)), ACMIL_GA.train_step writing its gradients straight into the bucket views, one optimizer
+    launch.  Checked against torch.optim.AdamW stepping a twin model on the same gradients."""
+    from acmil_amd import train as T
+    from acmil_amd.optim import FlatAdamW
+    conf = T.Struct(train_epoch=3, warmup_epoch=0, wd=1e-2, lr=1e-3, min_lr=0, n_class=3, n_token=5, n_masked_patch=10,
+                    mask_drop=0.6, arch="ga", precision="f16x3", seed=1, D_feat=384, D_inner=128)
+    dev = torch.device("cuda", 0)
+    T.set_seed(3)
+    model = T.build_model(conf).to(dev).train()
+    twin = T.build_model(conf).to(dev).train()
+    twin.load_state_dict(model.state_dict())
+    bucket = T.GradBucket(list(model.parameters()))
+    opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)
+    assert isinstance(opt, FlatAdamW) and opt.grad.data_ptr() == bucket.flat.data_ptr()
+    ref = torch.optim.AdamW(twin.parameters(), lr=conf.lr, weight_decay=conf.wd)
+    bags = T.SyntheticBags(4, 700, 384, 3, seed=5)
+    for i in range(4):
+        x = bags[i]["input"].to(dev).unsqueeze(0)
+        y = torch.tensor([bags[i]["label"]], device=dev)
+        model.train_step(x, y)
+        bucket.sync_from_grads()
+        assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() and
+                   p.grad.data_ptr() < bucket.flat.data_ptr() + 4 * bucket.numel for p in model.parameters() if p.requires_grad)
+        bucket.allreduce_mean(1)
+        for pt, pm in zip(twin.parameters(), model.parameters()):      # the twin steps on the very same gradients
+            pt.grad = pm.grad.detach().clone()
+        assert float(bucket.flat.abs().sum()) > 0.0
+        opt.step()
+        ref.step()
+    for (n, pm), pt in zip(model.named_parameters(), twin.parameters()):
+        assert (pm - pt).abs().max().item() <= 3e-6 * max(1.0, pt.abs().max().item()), n
