@@ -106,10 +106,39 @@ class _GatedBase(nn.Module):
         """Drop the packed-weight cache (for optimizers that update the parameters outside torch's version counters)."""
         self._pack_cache = None
 
+    # D_inner with a fully fused forward kernel (csrc/ga_families.inc); the reference's other feature extractors
+    # (Step3_WSI_classification_ACMIL.py:78-87: CLIP-L 768/384, UNI 1024/512, GigaPath 1536/768) take the composed path
+    FUSED_D_INNER = (128, 256)
+
+    def _is_fused(self) -> bool:
+        return self.dimreduction.fc1.weight.shape[0] in self.FUSED_D_INNER
+
+    def _score_pass(self, xb, packed, dims):
+        """Raw scores A [K,N] and h [N,Di].  Fused widths: one kernel (GEMM chain in registers).  Other widths: the projection
+        as a split-f16 MFMA GEMM with the ReLU epilogue (acmil_gemm_f16x3; network.py:49-57), then acmil_gated_scores
+        (transformer.py:259-267) on h in HBM -- same arithmetic class, h makes one round trip."""
+        if self._is_fused():
+            return ops.ga_scores(xb, packed, dims, self.precision)
+        base = self._raw_params()[0]
+        prec = "fp32" if self.precision == "fp32" else "f16x3"
+        x32 = xb if xb.dtype == torch.float32 else xb.float()      # storage-format conversion of a 16-bit bag
+        h = ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
+        A = ops.gated_scores(h, *[p.detach() for p in base[1:7]], precision=prec)
+        return A, h
+
+    def _eval_forward(self, xb, packed, dims, want_scores=True, want_preds=True, want_bag_feat=False):
+        """Unmasked forward: the fully fused kernel where a family exists, else score pass + pooling pass."""
+        if self._is_fused():
+            return ops.ga_forward(xb, packed, dims, self.precision, want_scores=want_scores, want_preds=want_preds,
+                                  want_bag_feat=want_bag_feat)
+        out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False)
+        out.pop("h", None)
+        return out
+
     def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
         """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
         n = xb.shape[0]
-        A, h = ops.ga_scores(xb, packed, dims, self.precision)
+        A, h = self._score_pass(xb, packed, dims)
         k = min(self.n_masked_patch, n) if masking else 0
         m = int(k * self.mask_drop)
         topk = midx = None
@@ -154,7 +183,7 @@ class ABMIL(_GatedBase):
             self._masking_now = False
             return _GaTrainFn.apply(self, xb, None, len(params), *params)[0]
         packed, dims = self._packed()
-        out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=False)
+        out = self._eval_forward(xb, packed, dims, want_scores=False)
         return out["sub_preds"]
 
 
@@ -190,7 +219,7 @@ class ACMIL_GA(_GatedBase):
         if masking:
             out = self._masked_forward(xb, packed, dims, uniforms)
         else:
-            out = ops.ga_forward(xb, packed, dims, self.precision)
+            out = self._eval_forward(xb, packed, dims)
         self._last = out
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
 
@@ -221,7 +250,11 @@ class ACMIL_GA(_GatedBase):
         (acmil_ga_forward_batch).  Returns a list of the reference's per-slide triples
         (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N_b]).  Not in the reference (it is strictly B=1); same maths per bag."""
         packed, dims = self._packed()
-        out = ops.ga_forward_batch([b if b.is_contiguous() else b.contiguous() for b in bags], packed, dims, self.precision)
+        bags = [b if b.is_contiguous() else b.contiguous() for b in bags]
+        if not self._is_fused():
+            outs = [self._eval_forward(b, packed, dims) for b in bags]
+            return [(o["sub_preds"], o["slide_pred"].unsqueeze(0), o["A_out"].unsqueeze(0)) for o in outs]
+        out = ops.ga_forward_batch(bags, packed, dims, self.precision)
         return [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
 
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
@@ -231,8 +264,7 @@ class ACMIL_GA(_GatedBase):
         if self.n_masked_patch > 0 and use_attention_mask:
             out = self._masked_forward(xb, packed, dims, uniforms, want_bag_feat=True)
         else:
-            out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=False, want_preds=False,
-                                 want_bag_feat=True)
+            out = self._eval_forward(xb, packed, dims, want_scores=False, want_preds=False, want_bag_feat=True)
         return out["bag_feat"].unsqueeze(0)
 
 

@@ -268,7 +268,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
                            float*, int, long long, const float*, int, const float*, int, void*, void*);
     const gemm_fn gemm_fwd = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_f16x3;
     const gemm_fn gemm_grad = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_bf16x3;
-    if (Di != 128 && Di != 256 && Di != 384 && Di != 512) return ACMIL_ERR_UNSUPPORTED;
+    if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;   // gate pass instances (FPL = Di/64)
     if (!x || !h || !A_out || !afeat || !Wv || !bv || !Wu || !bu || !Ww || !Wc || !d_sub || !workspace) return ACMIL_ERR_NULL;
     if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc) return ACMIL_ERR_NULL;
     if ((Ws != nullptr) != (d_slide != nullptr) || (Ws && (!dWs || !dbs))) return ACMIL_ERR_NULL;
@@ -309,8 +309,8 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     const int FPL = Di / 64;
     const int blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
 #define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
-    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else GB_LAUNCH_GATE(1, 8); }
-    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else GB_LAUNCH_GATE(5, 8); }
+    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
+    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
     else return ACMIL_ERR_UNSUPPORTED;
 #undef GB_LAUNCH_GATE
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
