@@ -8,6 +8,10 @@ Mirrors `architecture/transformer.py` of dazhangyu123/ACMIL: `Attention_Gated` (
 
 Extra, non-reference knobs (keyword-only, defaults keep reference behaviour):
   precision   'f16x3' (default: fp32-parity split-f16 MFMA), 'fp32' (exact fp32 MFMA) or 'f16' (throughput)
+  range_guard True (default): the split-f16 kernels flag bag values / projected features outside the f16 range (|v| >= 65504,
+              inf, NaN) in a device status word; the module reads it back after the forward (one 4-byte copy) and redoes
+              that bag with exact fp32 MFMA arithmetic, so a result is never silently inf / garbage where the reference's
+              fp32 result is finite.  False skips the read-back (no synchronisation; the status is still in `_last`).
   and `forward(x, uniforms=...)` to inject the STKIM `torch.rand(K,k)` draw for reproducible tests.
 """
 from __future__ import annotations
@@ -51,7 +55,7 @@ class _GaTrainFn(torch.autograd.Function):
         packed, dims = module._packed()
         out = module._masked_forward(xb, packed, dims, uniforms, want_afeat=True,
                                      masking=getattr(module, "_masking_now", True))
-        ctx.dims = dims
+        ctx.dims = out.get("dims_bwd", dims)
         ctx.has_slide = "slide_pred" in out
         ctx.save_for_backward(xb, out["h"], out["A_out"], out["afeat"], *[p.detach() for p in params])
         module._last = out
@@ -74,8 +78,18 @@ class _GatedBase(nn.Module):
     """Shared plumbing: parameter gathering, the packed-weight cache, the two-pass training forward."""
 
     precision: str
+    range_guard = True
     n_masked_patch = 0
     mask_drop = 0.0
+
+    def _out_of_range(self, status) -> bool:
+        """Read the device status word of a split-f16 launch (synchronises); True = redo the bag in fp32 mode."""
+        if not self.range_guard or status is None:
+            return False
+        bad = int(status) != 0
+        if bad:
+            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+        return bad
 
     def _heads(self):
         raise NotImplementedError
@@ -87,10 +101,14 @@ class _GatedBase(nn.Module):
                 a.attention_U[0].weight, a.attention_U[0].bias, a.attention_weights.weight,
                 a.attention_weights.bias], wc, bc, ws, bs
 
-    def _packed(self):
+    def _packed(self, precision: Optional[str] = None):
         """Packed fragment stream of the current parameter values; re-packed only when a parameter changed
-        (tracked through tensor version counters / storage pointers)."""
+        (tracked through tensor version counters / storage pointers).  precision: pack for another arithmetic mode than the
+        module's (the fp32 re-run of the range guard); not cached."""
         base, wc, bc, ws, bs = self._raw_params()
+        if precision is not None and precision != self.precision:
+            return ops.ga_pack_weights(*[p.detach() for p in base], [p.detach() for p in wc], [p.detach() for p in bc],
+                                       None if ws is None else ws.detach(), None if bs is None else bs.detach(), precision)
         allp = base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
         key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in allp)
         cache = getattr(self, "_pack_cache", None)
@@ -118,9 +136,19 @@ class _GatedBase(nn.Module):
         as a split-f16 MFMA GEMM with the ReLU epilogue (acmil_gemm_f16x3; network.py:49-57), then acmil_gated_scores
         (transformer.py:259-267) on h in HBM -- same arithmetic class, h makes one round trip."""
         if self._is_fused():
-            return ops.ga_scores(xb, packed, dims, self.precision)
+            if self.precision != "f16x3":
+                return ops.ga_scores(xb, packed, dims, self.precision)
+            A, h, status = ops.ga_scores(xb, packed, dims, self.precision, with_status=True)
+            if self._out_of_range(status):
+                p32, d32 = self._packed("fp32")
+                self._bwd_dims = d32               # the backward of this step follows in exact fp32 as well
+                return ops.ga_scores(xb, p32, d32, "fp32")
+            return A, h
         base = self._raw_params()[0]
         prec = "fp32" if self.precision == "fp32" else "f16x3"
+        if prec == "f16x3" and self.range_guard and not bool(torch.isfinite(xb).all() and (xb.abs().max() < 65504.0)):
+            prec = "fp32"      # composed path: the GEMM has no status word; same rule, checked up front
+            self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
         x32 = xb if xb.dtype == torch.float32 else xb.float()      # storage-format conversion of a 16-bit bag
         h = ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
         A = ops.gated_scores(h, *[p.detach() for p in base[1:7]], precision=prec)
@@ -129,8 +157,14 @@ class _GatedBase(nn.Module):
     def _eval_forward(self, xb, packed, dims, want_scores=True, want_preds=True, want_bag_feat=False):
         """Unmasked forward: the fully fused kernel where a family exists, else score pass + pooling pass."""
         if self._is_fused():
-            return ops.ga_forward(xb, packed, dims, self.precision, want_scores=want_scores, want_preds=want_preds,
-                                  want_bag_feat=want_bag_feat)
+            out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=want_scores, want_preds=want_preds,
+                                 want_bag_feat=want_bag_feat)
+            if self.precision == "f16x3" and self._out_of_range(out["range_status"]):
+                p32, d32 = self._packed("fp32")
+                out = ops.ga_forward(xb, p32, d32, "fp32", want_scores=want_scores, want_preds=want_preds,
+                                     want_bag_feat=want_bag_feat)
+                out["range_fallback"] = True
+            return out
         out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False)
         out.pop("h", None)
         return out
@@ -138,6 +172,7 @@ class _GatedBase(nn.Module):
     def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
         """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
         n = xb.shape[0]
+        self._bwd_dims = dims
         A, h = self._score_pass(xb, packed, dims)
         k = min(self.n_masked_patch, n) if masking else 0
         m = int(k * self.mask_drop)
@@ -149,6 +184,7 @@ class _GatedBase(nn.Module):
         out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat,
                           want_afeat=want_afeat)
         out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
+        out["dims_bwd"] = self._bwd_dims
         return out
 
     def _all_params(self):
@@ -164,7 +200,7 @@ class _GatedBase(nn.Module):
 
 
 class ABMIL(_GatedBase):
-    def __init__(self, conf, D=128, droprate=0, *, precision="f16x3"):
+    def __init__(self, conf, D=128, droprate=0, *, precision="f16x3", range_guard=True):
         super().__init__()
         if droprate != 0:
             raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
@@ -172,6 +208,7 @@ class ABMIL(_GatedBase):
         self.attention = Attention_Gated(conf.D_inner, D, 1)
         self.classifier = Classifier_1fc(conf.D_inner, conf.n_class, droprate)
         self.precision = precision
+        self.range_guard = range_guard
 
     def _heads(self):
         return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
@@ -188,8 +225,9 @@ class ABMIL(_GatedBase):
 
 
 class ACMIL_GA(_GatedBase):
-    def __init__(self, conf, D=128, droprate=0, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3"):
+    def __init__(self, conf, D=128, droprate=0, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3", range_guard=True):
         super().__init__()
+        self.range_guard = range_guard
         if droprate != 0:
             raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
         self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
@@ -239,8 +277,8 @@ class ACMIL_GA(_GatedBase):
         for p in params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-        ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], dims, d_sub, d_slide, d_A,
-                        grads_out=[p.grad for p in params])
+        ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], out.get("dims_bwd", dims), d_sub, d_slide,
+                        d_A, grads_out=[p.grad for p in params])
         self._last = out
         return losses, out
 
@@ -255,6 +293,9 @@ class ACMIL_GA(_GatedBase):
             outs = [self._eval_forward(b, packed, dims) for b in bags]
             return [(o["sub_preds"], o["slide_pred"].unsqueeze(0), o["A_out"].unsqueeze(0)) for o in outs]
         out = ops.ga_forward_batch(bags, packed, dims, self.precision)
+        if self.precision == "f16x3" and self._out_of_range(out["range_status"]):      # some bag left the f16 range: redo in fp32
+            p32, d32 = self._packed("fp32")
+            out = ops.ga_forward_batch(bags, p32, d32, "fp32")
         return [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
 
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):

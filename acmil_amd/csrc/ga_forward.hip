@@ -234,10 +234,11 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         a.tile_start[b + 1] = a.tile_start[b] + (b < nbags ? (Ns[b] + 32 * a.waves - 1) / (32 * a.waves) : 0);
     }
     a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = nullptr;
-    a.tile_counter = nullptr;
-    if (ga_use_v2(mode)) {   // the last 256 bytes of the workspace: tile counter, zeroed on the stream ahead of the launch
+    a.tile_counter = nullptr; a.status = nullptr;
+    if (ga_use_v2(mode)) {   // the last 256 bytes of the workspace: {tile counter, range status}, zeroed on the stream ahead of the launch
         a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_batch_workspace_bytes(nbags, Ns, D, Di, K, C, mode) - 256);
-        if (hipMemsetAsync(a.tile_counter, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        a.status = a.tile_counter + 1;
+        if (hipMemsetAsync(a.tile_counter, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     a.L = ga_layout(D, Di, K, C, mode);
 #ifdef GA_TRACE
@@ -309,10 +310,11 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);
     a.nbags = 1; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = h_save;
-    a.tile_counter = nullptr;
+    a.tile_counter = nullptr; a.status = nullptr;
     if (ga_use_v2(mode) && workspace) {
         a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_workspace_bytes(N, D, Di, K, C, mode) - 256);
-        if (hipMemsetAsync(a.tile_counter, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        a.status = a.tile_counter + 1;
+        if (hipMemsetAsync(a.tile_counter, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     a.L = ga_layout(D, Di, K, C, mode);
     return ga_dispatch(a, mode, x_dtype, false, st);

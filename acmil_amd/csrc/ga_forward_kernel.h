@@ -45,6 +45,8 @@ struct GaFwdArgs {
     float* h_save;   // [N,Di] or null (single-bag score pass only)
     int waves;       // 8 or 4 waves per workgroup (tile = 32 * waves patches); the persistent v2 kernel always uses 4
     unsigned* tile_counter;   // v2: zeroed word the persistent workgroups draw their next tiles from (null = static striding)
+    unsigned* status;         // v2: zeroed word; bit 0 = a bag value, bit 1 = a projected feature h outside the f16 range (or NaN):
+                              //     the split-f16 result is then NOT the fp32 result and the caller must redo the bag in fp32 mode
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
 #ifdef GA_TRACE
     unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0

@@ -290,6 +290,10 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[d][r] = 0.0f;
 
+        // range guard of the split-f16 arithmetic: largest |bag value| this lane converted (as a bit pattern, so that inf and
+        // NaN rank above every finite value), largest feature it produced
+        unsigned xmax = 0u;
+        float hmax = 0.0f;
         // ======================================================= GEMM1: h^T = W1 * x^T
         {
             const int ln = ga2_lane();
@@ -322,6 +326,9 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 unsigned h, l;
                 ga2_split_pair(v0, v1, h, l);
                 xhw[j] = h; xlw[j] = l;
+                // range guard on the bit patterns of |x| (orders finite < inf < NaN)
+                const unsigned b0 = __builtin_bit_cast(unsigned, v0) & 0x7fffffffu, b1 = __builtin_bit_cast(unsigned, v1) & 0x7fffffffu;
+                xmax = xmax > b0 ? xmax : b0; xmax = xmax > b1 ? xmax : b1;
             };
             auto split_done = [&](f16x8& h8, f16x8& l8) {
                 if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
@@ -402,6 +409,10 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) hmax = fmaxf(hmax, fmaxf(acc1[d][r], acc1[d][r + 1]));
 #pragma unroll
         for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
         f16x8 hh[ND][2], hl[ND][2];
@@ -551,6 +562,12 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         float* A_out = T.A_out;
         const int row = m0 + i31;
         const bool valid = row < N;
+        if (a.status) {
+            // 65504 = largest finite f16; !(x < limit) also catches NaN
+            const bool xbad = valid && xmax >= 0x477fe000u /* 65504.0f */, hbad = valid && !(hmax < 65504.0f);
+            const unsigned bits = (__builtin_amdgcn_ballot_w64(xbad) != 0 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(hbad) != 0 ? 2u : 0u);
+            if (bits != 0 && lane == 0) atomicOr(a.status, bits);      // (ballots outside the one-lane branch: all lanes vote)
+        }
         constexpr int NS = (KP + 1) / 2;
         float smax[KP], lsum[KP], pe[NS];
 #pragma unroll

@@ -83,6 +83,13 @@ def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
+def _range_status(ws: torch.Tensor) -> torch.Tensor:
+    """Device view of the split-f16 range status the fused kernel leaves in its workspace (last 256 bytes: {tile counter,
+    status}).  Non-zero = a bag value (bit 0) or a projected feature (bit 1) left the f16 range / was not finite: the
+    f16x3 result is then not the fp32 result.  Reading it (`int(...)`) synchronises; the modules do that, the raw ops do not."""
+    return ws[-252:-248].view(torch.int32)
+
+
 def _check_x(x: torch.Tensor, dims: GaDims) -> None:
     _need_cuda(x)
     if x.dim() != 2 or x.shape[1] != dims.D or x.shape[0] < 1:
@@ -112,6 +119,7 @@ def ga_forward(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, want_s
     for k, v in (("A_out", A), ("sub_preds", sub), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
         if v is not None:
             out[k] = v
+    out["range_status"] = _range_status(ws)
     return out
 
 
@@ -140,25 +148,27 @@ def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaD
     rc = lib.acmil_ga_forward_batch(B, xp, Ns, _DT[xs[0].dtype], packed.data_ptr(), *dims.args(), mode, Ap, sub.data_ptr(),
                                     _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_forward_batch")
-    out: Dict[str, object] = {"sub_preds": sub}
+    out: Dict[str, object] = {"sub_preds": sub, "range_status": _range_status(ws)}
     for k, v in (("A_out", A), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
         if v is not None:
             out[k] = v
     return out
 
 
-def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward)."""
+def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, with_status: bool = False):
+    """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward);
+    with_status: also the device view of the split-f16 range status (see _range_status)."""
     lib = _lib.load()
     mode = mode_id(mode)
     _check_x(x, dims)
     N, dev = x.shape[0], x.device
     A = torch.empty(dims.K, N, dtype=torch.float32, device=dev)
     h = torch.empty(N, dims.Di, dtype=torch.float32, device=dev)
+    ws = _workspace(N, dims, mode, dev)        # tile counter + range status of the persistent kernel
     rc = lib.acmil_ga_forward(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), *dims.args(), mode, A.data_ptr(), None,
-                              None, None, None, h.data_ptr(), int(dims.has_bag_head), None, _stream())
+                              None, None, None, h.data_ptr(), int(dims.has_bag_head), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_forward(score pass)")
-    return A, h
+    return (A, h, _range_status(ws)) if with_status else (A, h)
 
 
 def stkim_select(scores: torch.Tensor, k: int, m: int, uniforms: Optional[torch.Tensor]):

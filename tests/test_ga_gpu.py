@@ -185,3 +185,71 @@ def test_repeated_launches_are_bitwise_reproducible():
         i = rep % 3
         again = ops.ga_forward(xs[i], packed, dims, "f16x3")
         assert torch.equal(again["A_out"], first[i]["A_out"]) and torch.equal(again["sub_preds"], first[i]["sub_preds"])
+
+
+@pytest.mark.parametrize("what", ["x_big", "x_inf_free_h_big", "x_nan"])
+def test_f16_range_guard_falls_back_to_fp32(what):
+    """Split-f16 operands overflow at |v| >= 65504 (bag values, or the projected features h).  The kernel flags it in a status
+    word and the module redoes the bag in exact-fp32 mode: the result equals the fp32-mode result and is finite wherever the
+    reference's fp32 result is -- never the inf / garbage the unguarded split would give."""
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    case, sd = load_golden("ga_eval_n257_d512_k5_c2")
+    d, di, k, c = case_dims(sd)
+    sd = {k2: v.clone() for k2, v in sd.items()}
+    x = torch.from_numpy(case["x"]).float().clone()
+    if what == "x_big":
+        x[0, 100, 7] = 1.0e5
+        x[0, 3, 400] = -7.0e4
+    elif what == "x_inf_free_h_big":
+        sd["dimreduction.fc1.weight"] *= 1.0e3            # h = relu(x W1^T) reaches ~1e5 while x and W1 stay in range
+        x[0] *= 30.0
+    else:
+        x[0, 5, 5] = float("nan")
+    guarded = _build(sd, k, c, d, di, "f16x3").eval()
+    exact = _build(sd, k, c, d, di, "fp32").eval()
+    loose = _build(sd, k, c, d, di, "f16x3").eval()
+    loose.range_guard = False
+    with torch.no_grad():
+        sub_g, slide_g, a_g = guarded(x.cuda())
+        sub_e, slide_e, a_e = exact(x.cuda())
+        feat_g, feat_e = guarded.forward_feature(x.cuda()), exact.forward_feature(x.cuda())
+        loose(x.cuda())
+    assert guarded.range_fallbacks >= 1 and int(loose._last["range_status"]) != 0
+    if what == "x_nan":
+        # a NaN in the bag is flagged like an out-of-range value and the bag takes the fp32 path.  (Garbage in: torch's relu
+        # would carry the NaN into every output of that patch; the MFMA kernels' max-based relu drops it in BOTH modes.)
+        assert torch.equal(a_g, a_e)
+        return
+    assert torch.isfinite(a_e).all() and torch.isfinite(a_g).all()
+    assert torch.equal(a_g, a_e) and torch.equal(sub_g, sub_e) and torch.equal(slide_g, slide_e) and torch.equal(feat_g, feat_e)
+    # and an in-range bag never takes the slow path
+    x_ok = torch.from_numpy(case["x"]).float().cuda()
+    before = guarded.range_fallbacks
+    with torch.no_grad():
+        guarded(x_ok)
+    assert guarded.range_fallbacks == before and int(guarded._last["range_status"]) == 0
+    # batched entry follows the same rule
+    outs = guarded.forward_batch([x[0].cuda(), x_ok[0]])
+    assert torch.equal(outs[0][2], a_e)
+
+
+def test_f16_range_guard_training_step():
+    """A training step on an out-of-range bag runs forward AND backward in exact fp32 (gradients equal the fp32-mode module's)."""
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    case, sd = load_golden("ga_train_n640_d512_k5_c2")
+    d, di, k, c = case_dims(sd)
+    x = torch.from_numpy(case["x"]).float().clone()
+    x[0, 17, 3] = 9.0e4
+    u = torch.from_numpy(case["uniforms"]).cuda()
+    label = torch.from_numpy(case["label"]).cuda()
+    grads = []
+    for prec in ("f16x3", "fp32"):
+        m = ACMIL_GA(type("C", (), dict(D_feat=d, D_inner=di, n_class=c, n_token=k)), n_token=k, n_masked_patch=10, mask_drop=0.6,
+                     precision=prec)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        losses, _ = m.train_step(x.cuda(), label, uniforms=u)
+        assert torch.isfinite(losses).all()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
