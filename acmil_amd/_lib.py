@@ -49,6 +49,8 @@ SIGNATURES = {
     "acmil_attn_pool_workspace_bytes": (_sz, [_i] * 3),
     "acmil_attn_pool": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "acmil_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "acmil_attn_row_stats": (_i, [_vp, _i, _i, _vp, _vp]),
+    "acmil_attn_heatmap": (_i, [_vp, _i, _i, C.c_float, _vp, _vp, _vp]),
     "acmil_layernorm_fwd": (_i, [_vp, C.c_longlong, _i, _vp, _vp, C.c_float, _vp, _vp, _vp]),
     "acmil_layernorm_bwd_workspace_bytes": (_sz, [C.c_longlong, _i]),
     "acmil_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -388,12 +388,13 @@ class ACMIL_MHA(nn.Module):
         k_mask = min(self.sub_attention[0].n_masked_patch, n) if self.training else 0
         if k_mask > 0:                                                                            # transformer.py:162-171, per (head, branch) row
             drop = int(k_mask * self.sub_attention[0].mask_drop)
-            _, idx = torch.topk(S, k_mask, dim=-1)
-            sel = torch.argsort(torch.rand(idx.shape, device=S.device), dim=-1)[:, :drop]
-            midx = idx[torch.arange(idx.shape[0], device=S.device).unsqueeze(-1), sel]
-            mask = torch.ones_like(S).scatter_(-1, midx, 0)
-            masked = S.masked_fill(mask == 0, -1e9)
-            attns = masked.view(H, K, n)
+            if drop > 0:
+                # top-k + random subset with the STKIM kernels of the GA path (one row per (head, branch)), then the mask as a
+                # differentiable index fill: no [8K, N] topk / ones / scatter / masked_fill tensors
+                u = torch.rand(S.shape[0], k_mask, device=S.device)
+                _, midx = ops.stkim_select(S.detach().contiguous(), k_mask, drop, u)
+                masked = AG.mask_fill(S, midx)
+                attns = masked.view(H, K, n)
         P = AG.softmax_rows(masked.contiguous())
         pooled = AG.matmul(P, h).view(H, K, di)                                                    # sum_n P h
         outs = []

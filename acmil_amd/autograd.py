@@ -296,3 +296,28 @@ def gated_scores(h, Wv, bv, Wu, bu, Ww, bw, precision="f16x3"):
 def attn_pool(h, A):
     """softmax over N of A [K, N], then P @ h -> [K, Di] (differentiable)"""
     return matmul(softmax_rows(A.contiguous()), h)
+
+
+class _MaskFill(torch.autograd.Function):
+    """STKIM mask as a differentiable op: out = S with -1e9 at (row, midx[row, j]); masked entries get zero gradient
+    (`attn.masked_fill(random_mask == 0, -1e9)`, architecture/transformer.py:168-171 / :318-320).  The index set is tiny
+    ([rows, m]); the only O(N) work is one copy of S."""
+
+    @staticmethod
+    def forward(ctx, S, midx):
+        ctx.save_for_backward(midx)
+        out = S.clone()
+        out.scatter_(1, midx, -1e9)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (midx,) = ctx.saved_tensors
+        g = g.clone()
+        g.scatter_(1, midx, 0.0)
+        return g, None
+
+
+def mask_fill(S: torch.Tensor, midx: torch.Tensor) -> torch.Tensor:
+    return _MaskFill.apply(S, midx)
+

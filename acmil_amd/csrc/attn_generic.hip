@@ -105,3 +105,66 @@ extern "C" int acmil_softmax_rows(const float* S, float* P, int rows, int cols, 
     hipLaunchKernelGGL(ag_softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, S, P, cols);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Consumers of the raw score map A [K, N] outside the model:
+//   evaluate():  div_loss = sum(softmax(A) * log_softmax(A)) / K      Step3_WSI_classification_ACMIL.py:259
+//   heat maps:   probs = softmax(A, -1).mean(0) * N * zoom_factor     Step4_visualize_heatmap_camelyon.py:117-118
+// Both need the per-row softmax statistics; one workgroup per row gathers (max, sum e^{s-m}, sum e^{s-m}(s-m)) with a fixed
+// reduction tree (deterministic), since  sum_n p log p = T / L - log L  with T = sum e^{s-m}(s-m), L = sum e^{s-m}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ag_row_stats_kernel(const float* __restrict__ A, int N, float* __restrict__ stats) {
+    __shared__ float red[3][16];
+    const float* row = A + (size_t)blockIdx.x * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int n = tid; n < N; n += 1024) m = fmaxf(m, row[n]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[0][wave] = m;
+    __syncthreads();
+    float M = red[0][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, red[0][w]);
+    float l = 0.0f, t = 0.0f;
+    for (int n = tid; n < N; n += 1024) {
+        const float d = row[n] - M, e = __expf(d);
+        l += e; t = fmaf(e, d, t);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { l += __shfl_xor(l, o); t += __shfl_xor(t, o); }
+    if (lane == 0) { red[1][wave] = l; red[2][wave] = t; }
+    __syncthreads();
+    if (tid == 0) {
+        float L = 0.0f, T = 0.0f;
+        for (int w = 0; w < 16; ++w) { L += red[1][w]; T += red[2][w]; }
+        stats[4 * blockIdx.x + 0] = M; stats[4 * blockIdx.x + 1] = L; stats[4 * blockIdx.x + 2] = T;
+        stats[4 * blockIdx.x + 3] = T / L - __logf(L);       // sum_n p log p of this row
+    }
+}
+
+__global__ __launch_bounds__(256) void ag_heatmap_kernel(const float* __restrict__ A, int K, int N, const float* __restrict__ stats,
+                                                         float scale, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s += __expf(A[(size_t)k * N + n] - stats[4 * k]) / stats[4 * k + 1];
+    out[n] = s * scale / (float)K;
+}
+
+extern "C" int acmil_attn_row_stats(const float* A, int K, int N, float* stats, void* stream) {
+    if (K <= 0 || N <= 0) return ACMIL_ERR_SHAPE;
+    if (!A || !stats) return ACMIL_ERR_NULL;
+    hipLaunchKernelGGL(ag_row_stats_kernel, dim3(K), dim3(1024), 0, (hipStream_t)stream, A, N, stats);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+extern "C" int acmil_attn_heatmap(const float* A, int K, int N, float scale, float* probs, float* stats, void* stream) {
+    if (K <= 0 || N <= 0) return ACMIL_ERR_SHAPE;
+    if (!A || !probs || !stats) return ACMIL_ERR_NULL;
+    int rc = acmil_attn_row_stats(A, K, N, stats, stream);
+    if (rc != ACMIL_OK) return rc;
+    hipLaunchKernelGGL(ag_heatmap_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, A, K, N, stats, scale, probs);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+

@@ -431,3 +431,34 @@ def softmax_rows(S: torch.Tensor) -> torch.Tensor:
     P = torch.empty_like(S)
     _lib.check(lib.acmil_softmax_rows(S.data_ptr(), P.data_ptr(), S.shape[0], S.shape[1], _stream()), "acmil_softmax_rows")
     return P
+
+
+def attn_row_stats(A: torch.Tensor) -> torch.Tensor:
+    """acmil_attn_row_stats: [rows, 4] = (max, sum e^{s-m}, sum e^{s-m}(s-m), sum_n p log p) per row of the raw scores A [rows, N]."""
+    lib = _lib.load()
+    _need_cuda(A)
+    A2 = A.detach().reshape(-1, A.shape[-1]).to(torch.float32).contiguous()
+    stats = torch.empty(A2.shape[0], 4, dtype=torch.float32, device=A.device)
+    _lib.check(lib.acmil_attn_row_stats(A2.data_ptr(), A2.shape[0], A2.shape[1], stats.data_ptr(), _stream()), "acmil_attn_row_stats")
+    return stats
+
+
+def attn_entropy_loss(attn: torch.Tensor) -> torch.Tensor:
+    """evaluate()'s div_loss = sum(softmax(attn) * log_softmax(attn)) / attn.shape[1] (Step3_WSI_classification_ACMIL.py:259)
+    for attn [B, K, N] (GA: B = 1; MHA: B = 8 heads), as a device scalar; one HIP launch, no [K,N] temporaries."""
+    return attn_row_stats(attn)[:, 3].sum() / attn.shape[1]
+
+
+def attn_heatmap(attn: torch.Tensor, zoom_factor: float = 1.0) -> torch.Tensor:
+    """acmil_attn_heatmap: probs [N] = softmax(attn, -1)[0].mean(0) * N * zoom_factor (Step4_visualize_heatmap_camelyon.py:117-118)."""
+    lib = _lib.load()
+    _need_cuda(attn)
+    A = attn.detach()
+    A = (A[0] if A.dim() == 3 else A).to(torch.float32).contiguous()
+    K, N = A.shape
+    probs = torch.empty(N, dtype=torch.float32, device=A.device)
+    stats = torch.empty(K, 4, dtype=torch.float32, device=A.device)
+    _lib.check(lib.acmil_attn_heatmap(A.data_ptr(), K, N, float(N * zoom_factor), probs.data_ptr(), stats.data_ptr(), _stream()),
+               "acmil_attn_heatmap")
+    return probs
+

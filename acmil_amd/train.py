@@ -27,6 +27,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .staging import staged
 
 PRETRAIN_DIMS = {  # Step3_WSI_classification_ACMIL.py:69-87
@@ -265,7 +266,7 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
         if isinstance(out, tuple):
             sub_preds, slide_preds, attn = out
             # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
-            divs.append(torch.sum(F.softmax(attn, dim=-1) * F.log_softmax(attn, dim=-1)) / attn.shape[1])
+            divs.append(ops.attn_entropy_loss(attn))          # div_loss (:259) from one HIP pass over the raw scores
         else:
             slide_preds = out
         losses.append(F.cross_entropy(slide_preds, y))
@@ -310,7 +311,11 @@ def build_model(conf):
     if conf.arch == "transmil":
         from .architecture.transMIL import TransMIL
         return TransMIL(conf)
-    raise SystemExit("--arch %s is not on the MI355X path yet (ga, abmil, transmil)" % conf.arch)
+    if conf.arch == "mha":      # Step3_WSI_classification_ACMIL.py:127-128
+        from .architecture.transformer import ACMIL_MHA
+        return ACMIL_MHA(conf, n_token=conf.n_token, n_masked_patch=conf.n_masked_patch, mask_drop=conf.mask_drop,
+                         precision="fp32" if conf.precision == "fp32" else "f16x3")
+    raise SystemExit("--arch %s is not on the MI355X path yet (ga, abmil, mha, transmil)" % conf.arch)
 
 
 def get_arguments(argv=None):
@@ -320,7 +325,7 @@ def get_arguments(argv=None):
     p.add_argument("--n_token", type=int, default=1)
     p.add_argument("--n_masked_patch", type=int, default=0)
     p.add_argument("--mask_drop", type=float, default=0.6)
-    p.add_argument("--arch", default="ga", choices=["ga", "abmil", "transmil"])
+    p.add_argument("--arch", default="ga", choices=["ga", "abmil", "mha", "transmil"])
     p.add_argument("--pretrain", default="medical_ssl", choices=sorted(PRETRAIN_DIMS))
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32", "f16"])

@@ -249,6 +249,18 @@ int acmil_attn_pool(const float* h, const float* A, int N, int Di, int K, float*
 int acmil_softmax_rows(const float* S, float* P, int rows, int cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Consumers of the raw score map A [K,N] outside the model:
+ *   acmil_attn_row_stats: stats [K][4] = per row (max m, L = sum e^{s-m}, T = sum e^{s-m}(s-m), sum_n p log p = T/L - log L).
+ *     evaluate()'s div_loss = sum(softmax(A) * log_softmax(A)) / K  (Step3_WSI_classification_ACMIL.py:259) is
+ *     sum_k stats[k][3] / K; works for any row count (MHA: rows = 8 K).
+ *   acmil_attn_heatmap: probs [N] = scale * mean_k softmax_N(A)[k][n] -- the heat-map scores of
+ *     Step4_visualize_heatmap_camelyon.py:117-118 (scale = N * zoom_factor); stats [K][4] is scratch / by-product.
+ * ------------------------------------------------------------------------------------------- */
+int acmil_attn_row_stats(const float* A, int K, int N, float* stats, void* stream);
+
+int acmil_attn_heatmap(const float* A, int K, int N, float scale, float* probs, float* stats, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Op-level forward / backward kernels for TRAINING the TransMIL / Nystrom path (csrc/transmil_train.hip).  The eval forward
  * is acmil_transmil_forward; training runs op by op as torch.autograd Functions (acmil_amd/autograd.py) over these entry
  * points and the GEMMs above.  All tensors fp32, row-major, caller-owned.

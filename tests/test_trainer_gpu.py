@@ -80,7 +80,8 @@ def test_flat_adamw_matches_torch_adamw():
     assert sd["step"] == 25 and sd["exp_avg"].numel() == sum(p.numel() for p in my_p)
 
 
-@pytest.mark.parametrize("arch,extra", [("ga", ["--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"]), ("transmil", [])])
+@pytest.mark.parametrize("arch,extra", [("ga", ["--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"]), ("transmil", []),
+                                        ("mha", ["--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"])])
 def test_trainer_main_end_to_end(arch, extra, tmp_path):
     """python -m acmil_amd.train equivalent: synthetic bags, two epochs, checkpoints written (Step3-style main)."""
     from acmil_amd import train as T

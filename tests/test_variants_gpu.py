@@ -78,3 +78,38 @@ def test_generic_blocks_large_bag_vs_oracle():
     af = ops.attn_pool(c(h), A)
     assert (af.cpu() - torch.softmax(ref, 1) @ h).abs().max() < 1e-5
     assert (ops.softmax_rows(A).cpu() - torch.softmax(ref, 1)).abs().max() < 1e-7
+
+
+def test_attention_map_consumers_entropy_and_heatmap():
+    """div_loss of evaluate() (Step3_WSI_classification_ACMIL.py:259) and the heat-map scores of
+    Step4_visualize_heatmap_camelyon.py:117-119 from the HIP row-statistics pass vs the reference's torch expressions."""
+    import torch.nn.functional as F
+    from acmil_amd import heatmap, ops
+    g = torch.Generator().manual_seed(3)
+    for shape in [(1, 5, 50000), (1, 1, 777), (8, 5, 4096)]:
+        attn = (torch.randn(shape, generator=g) * 3.0).cuda()
+        attn[..., 7] = -1e9                                    # masked entries of a training-mode map
+        ref = torch.sum(F.softmax(attn.double(), dim=-1) * F.log_softmax(attn.double(), dim=-1)) / attn.shape[1]
+        got = ops.attn_entropy_loss(attn)
+        assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref)) + 1e-6
+        if shape[0] == 1:
+            probs = torch.softmax(attn.double(), dim=-1)[0].mean(0)
+            want = probs * probs.numel() * 2.5 * 100
+            got_map = ops.attn_heatmap(attn, zoom_factor=2.5) * 100.0
+            assert got_map.shape == (shape[2],)
+            assert (got_map.double().cpu() - want.cpu()).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-6
+    # through a model
+    from oracle import ga_oracle as O
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    sd = O.default_state_dict(512, 256, 2, 5)
+    m = ACMIL_GA(type("C", (), dict(D_feat=512, D_inner=256, n_class=2, n_token=5)), n_token=5)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    x = O.synthetic_bag(3000, 512, 4)[0].cuda().unsqueeze(0)
+    scores = heatmap.heatmap_scores(m, x, zoom_factor=1.0)
+    with torch.no_grad():
+        a = m(x)[2]
+    want = torch.softmax(a, dim=-1)[0].mean(0) * 3000 * 100
+    assert (scores - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    b0 = heatmap.branch_heatmap_scores(a, 2)
+    assert (b0 - torch.softmax(a, dim=-1)[0, 2] * 3000 * 100).abs().max().item() <= 1e-4 * float(b0.abs().max())
