@@ -1,0 +1,98 @@
+// linear.hip -- host side of the packed-weight Linear kernel (linear_kernel.h): weight packing and the C entry points.
+#include "linear_kernel.h"
+
+// Packed stream of W [n_out, K] (row-major, leading dimension ldw): n_out / 256 chunks of ND = 8 (256 output columns), then
+// one ND = 4 chunk when n_out % 256 == 128.  Chunk = K/16 steps; step = ND "hi" fragment rows then ND "lo" rows; fragment
+// row (step s, tile d): lane (i = lane & 31, hi = lane >> 5) holds the 8 f16 halves of W[col0 + 32 d + i][16 s + 8 hi .. + 7].
+struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; };
+
+__global__ __launch_bounds__(256) void lin_pack_kernel(LinPackArgs a) {
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int S1 = a.K / 16, nfull = a.n_out / 256;
+    const size_t rows_full = (size_t)nfull * S1 * 16;
+    const size_t rows_all = rows_full + ((a.n_out % 256) ? (size_t)S1 * 8 : 0);
+    if (row >= rows_all) return;
+    int ND, col0; size_t r;
+    if (row < rows_full) { ND = 8; const size_t c = row / ((size_t)S1 * 16); col0 = (int)c * 256; r = row - c * (size_t)S1 * 16; }
+    else { ND = 4; col0 = nfull * 256; r = row - rows_full; }
+    const int d = r % ND; r /= ND;
+    const int part = r & 1; const int s = (int)(r >> 1);
+    const float* src = a.W + (size_t)(col0 + 32 * d + i) * a.ldw + 16 * s + 8 * hi;
+    f16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)src[j];
+        v[j] = part ? (_Float16)(src[j] - (float)h) : h;
+    }
+    *(f16x8*)(a.out + row * GA_FRAG_ROW + lane * 16) = v;
+}
+
+static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K > 0 && n_out % 128 == 0 && K % 16 == 0; }
+
+extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
+    if (!lin_dims_ok(n_out, K)) return 0;
+    return (size_t)(K / 16) * GA_FRAG_ROW * (16 * (size_t)(n_out / 256) + ((n_out % 256) ? 8 : 0));
+}
+
+extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream) {
+    if (!lin_dims_ok(n_out, K) || ldw < K) return ACMIL_ERR_SHAPE;
+    if (!W || !packed) return ACMIL_ERR_NULL;
+    LinPackArgs a = {W, (char*)packed, ldw, n_out, K};
+    const size_t rows = acmil_linear_packed_bytes(n_out, K) / GA_FRAG_ROW;
+    hipLaunchKernelGGL(lin_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+template <int ND, int XDT>
+static int lin_launch(const LinArgs& a, hipStream_t st) {
+    using G = Ga2Geom<ND, 1, XDT>;
+    static const int slots = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
+        return 2 * prop.multiProcessorCount;
+    }();
+    static const hipError_t attr = hipFuncSetAttribute((const void*)lin_kernel<ND, XDT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    if (attr != hipSuccess) return ACMIL_ERR_LAUNCH;
+    const long long tiles = (long long)((a.M + G::ROWS - 1) / G::ROWS) * a.nchunks;
+    const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
+    hipLaunchKernelGGL((lin_kernel<ND, XDT>), grid, block, G::LDS, st, a);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+template <int ND>
+static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
+    switch (x_dtype) {
+        case ACMIL_DTYPE_F32: return lin_launch<ND, ACMIL_DTYPE_F32>(a, st);
+        case ACMIL_DTYPE_F16: return lin_launch<ND, ACMIL_DTYPE_F16>(a, st);
+        case ACMIL_DTYPE_BF16: return lin_launch<ND, ACMIL_DTYPE_BF16>(a, st);
+    }
+    return ACMIL_ERR_UNSUPPORTED;
+}
+
+extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
+                                  const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream) {
+    if (M <= 0 || !lin_dims_ok(n_out, K) || ldx < K || ldy < n_out) return ACMIL_ERR_SHAPE;
+    if (act != 0 && act != 1) return ACMIL_ERR_UNSUPPORTED;
+    if (!x || !packed || !y || !workspace) return ACMIL_ERR_NULL;
+    const int xe = (x_dtype == ACMIL_DTYPE_F32) ? 4 : 2;
+    if (((size_t)x & 15) != 0 || ((size_t)ldx * xe) % 16 != 0) return ACMIL_ERR_SHAPE;     // 16-byte LDS-DMA pieces
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* ctr = (unsigned*)workspace;
+    if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    LinArgs a;
+    a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
+    const int nfull = n_out / 256;
+    int rc = ACMIL_OK;
+    if (nfull > 0) {
+        a.packed = (const char*)packed; a.nchunks = nfull; a.col0 = 0; a.tile_counter = ctr;
+        rc = lin_launch_dt<8>(a, x_dtype, st);
+        if (rc != ACMIL_OK) return rc;
+    }
+    if (n_out % 256) {
+        a.packed = (const char*)packed + (size_t)nfull * (K / 16) * 16 * GA_FRAG_ROW; a.nchunks = 1; a.col0 = nfull * 256;
+        a.bias = bias ? bias + nfull * 256 : nullptr; a.tile_counter = ctr + 1;
+        rc = lin_launch_dt<4>(a, x_dtype, st);
+    }
+    return rc;
+}

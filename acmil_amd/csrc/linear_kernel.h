@@ -1,0 +1,287 @@
+// linear_kernel.h -- y = act(x W^T + b) (+ beta y) for the nn.Linear layers of the aggregation paths, split-f16 arithmetic
+// (3 f16 MFMA products per fp32 product, fp32 accumulate), gfx950.
+//
+// Replaces, as ONE kernel family: DimReduction.fc1 / TransMIL._fc1 (architecture/network.py:49-57, transMIL.py:51,63),
+// NystromAttention.to_qkv / to_out (nystrom_attention.py:80,139), the [Wv;Wu] projection of Attention_Gated outside the
+// fused GA kernel (transformer.py:259-267).
+//
+// It is the GEMM1 loop of ga_fwd2_kernel (ga_forward_kernel_v2.h) made standalone: the weight matrix is consumed as a
+// pre-packed f16 hi/lo FRAGMENT STREAM (acmil_linear_pack: 256- or 128-wide output chunks, per chunk K/16 steps x 2 ND
+// fragment rows in exactly the order the MFMA A operand wants them), staged with plain linear LDS-DMA; the activations x are
+// the B operand: fp32 (or 16-bit) rows DMA'd as they are, split hi/lo in registers inside the MFMA shadow.  Persistent
+// workgroups (2 per CU, 4 waves, one 32-row x (32 ND)-column tile per wave) draw (row tile, chunk) pairs from a counter;
+// the DMA ring runs across tile boundaries; P3 (Wlo * xhi) of a step is deferred across the next step's barrier where it
+// covers the fragment reads.  The epilogue transposes the accumulators through the free ring slot so that a half-wave
+// stores 128 contiguous bytes of an output row, adding bias / ReLU / beta * y there.
+#pragma once
+#include "ga_forward_kernel_v2.h"
+
+struct LinArgs {
+    const void* x;          // [M, K] row-major, leading dimension ldx (elements), fp32 / fp16 / bf16
+    const char* packed;     // fragment stream: chunk c at c * (K/16) * 2 ND KiB
+    const float* bias;      // [n_out of this launch] or null (indexed by output column - col0)
+    float* y;               // [M, ldy] fp32; this launch writes columns col0 .. col0 + nchunks * 32 ND
+    unsigned* tile_counter; // zeroed word (dynamic tile drawing) or null
+    long long ldx, ldy;
+    int M, K, nchunks, col0, act;   // act: 0 none, 1 relu
+    float beta;                     // y = act(acc + bias) + beta * y_old   (residual adds)
+};
+
+template <int ND, int XDT>
+__global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = Ga2Geom<ND, 1, XDT>;
+    constexpr int NTHR = 256, PD = G::PD, NB = G::NB;
+    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);
+    static_assert(PD == 2 && NB == 3, "wait counts assume a prefetch distance of 2 steps");
+    static_assert(G::REGION >= 4608 || !G::SCRATCH_IN_RING, "transposition tile must fit the free slot");
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto opaque_lane = [&]() { int l = tid & 63; asm volatile("" : "+v"(l)); return l; };
+    const int K = a.K, M = a.M;
+    const int S1 = K / 16;
+    const int rtiles = (M + G::ROWS - 1) / G::ROWS;
+    const int ntiles = rtiles * a.nchunks;
+    const size_t chunk_bytes = (size_t)S1 * G::WROWS * GA_FRAG_ROW;
+    const size_t rowb = (size_t)a.ldx * G::XE;
+
+    struct TileInfo { int m0, rmax, col; const char* xrow0; const char* wreg0; };
+    auto tile_info = [&](int t) {
+        TileInfo ti;
+        const int rt = t / a.nchunks, c = t - rt * a.nchunks;
+        ti.m0 = rt * G::ROWS + wave * 32;
+        const int m0c = ti.m0 < M ? ti.m0 : M - 1;
+        ti.rmax = M - 1 - m0c;
+        ti.col = c * 32 * ND;
+        ti.xrow0 = (const char*)a.x + (size_t)m0c * rowb;
+        ti.wreg0 = a.packed + c * chunk_bytes + (size_t)(wave * G::RW + G::RW) * GA_FRAG_ROW;
+        return ti;
+    };
+    auto tile_xoff = [&](const TileInfo& ti, int lane, unsigned (&xo)[G::XG]) {
+#pragma unroll
+        for (int q = 0; q < G::XG; ++q) {
+            int r, piece;
+            if constexpr (G::XG == 2) { r = 16 * q + (lane >> 2); piece = (lane & 3) ^ ((r >> 2) & 3); }
+            else { r = lane >> 1; piece = (lane & 1) ^ ((r >> 3) & 1); }
+            r = r < ti.rmax ? r : ti.rmax;
+            xo[q] = (unsigned)r * (unsigned)rowb + piece * 16;
+        }
+    };
+    const unsigned lds_base = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned m0w = lds_base + wave * G::REGION + G::RW * 1024;
+    auto dma_piece = [&](auto mc, int u, int slot, unsigned woff, const TileInfo& ti, const unsigned (&xo)[G::XG]) {
+        constexpr int m = decltype(mc)::value;
+        const unsigned m0v = m0w + slot * G::SLOT;
+        if constexpr (m < G::RW) ga2_dma<-(G::RW - m) * 1024>(woff, ti.wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v);
+        else if constexpr (m < G::NVX) { constexpr int q = m - G::RW; ga2_dma<q * 1024>(xo[q], ti.xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
+    };
+#define LIN_DMA_AT(d, ...)                                   \
+    do {                                                     \
+        if ((d) == 0) dma_piece(I0{}, __VA_ARGS__);          \
+        if ((d) == 1) dma_piece(I1{}, __VA_ARGS__);          \
+        if ((d) == 2) dma_piece(I2{}, __VA_ARGS__);          \
+        if ((d) == 3) dma_piece(I3{}, __VA_ARGS__);          \
+        if ((d) == 4) dma_piece(I4{}, __VA_ARGS__);          \
+        if ((d) == 5) dma_piece(I5{}, __VA_ARGS__);          \
+    } while (0)
+
+    // tile drawing (see ga_fwd2_kernel)
+    unsigned* const nn_lds = (unsigned*)(smem + G::ML_OFF);
+    unsigned draw_raw = 0;
+    auto draw_issue = [&]() {
+        unsigned long long keep;
+        const unsigned zero = 0, one = 1;
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                     : "=&v"(draw_raw), "=&s"(keep) : "v"(zero), "v"(one), "s"(a.tile_counter) : "memory");
+    };
+    auto draw_publish = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(draw_raw) :: "memory");
+        const unsigned v = __builtin_amdgcn_readfirstlane(draw_raw) + gridDim.x;
+        if ((tid & 63) == 0) *nn_lds = v;
+    };
+    const bool dynamic = a.tile_counter != nullptr;
+    int tile = blockIdx.x;
+    int ntile = tile + (int)gridDim.x;
+    if (dynamic) {
+        if (wave == 0) { draw_issue(); draw_publish(); }
+        __syncthreads();
+        ntile = (int)__builtin_amdgcn_readfirstlane(*nn_lds);
+    }
+    TileInfo T = tile_info(tile);
+
+    int islot = 0, rslot = 0;
+    {
+        const int ln = opaque_lane();
+        unsigned xo[G::XG];
+        tile_xoff(T, ln, xo);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+#pragma unroll
+            for (int m = 0; m < G::NVX; ++m) LIN_DMA_AT(m, s, islot, (unsigned)ln * 16, T, xo);
+            islot = (islot + 1 == NB) ? 0 : islot + 1;
+        }
+    }
+    auto step_sync = [&]() {
+        ga_wait_vm<G::NVX>();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    for (;;) {
+        const bool has_next = ntile < ntiles;
+        const TileInfo TN = tile_info(has_next ? ntile : tile);
+        if (dynamic && has_next && wave == 0) draw_issue();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+
+        f32x16 acc[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[d][r] = 0.0f;
+        {
+            const int ln = opaque_lane();
+            const int i31 = ln & 31, hi = ln >> 5;
+            const int lane16 = ln * 16;
+            unsigned xoff[G::XG], xoffn[G::XG];
+            tile_xoff(T, ln, xoff);
+            tile_xoff(TN, ln, xoffn);
+            const int xrd0 = wave * G::REGION + G::RW * 1024 +
+                             ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
+            const int xrd1 = wave * G::REGION + G::RW * 1024 + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);
+            f32x4 xr0, xr1;
+            u32x4 xrw;
+            auto read_x = [&](const char* slot) {
+                if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
+                else xrw = *(const u32x4*)(slot + xrd0);
+            };
+            constexpr int NSP = XLO ? 4 : 0;
+            u32x4 xhw, xlw;
+            auto split_piece = [&](int j) {
+                float v0, v1;
+                if constexpr (XDT == ACMIL_DTYPE_F32) {
+                    v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
+                    v1 = j < 2 ? xr0[2 * (j & 1) + 1] : xr1[2 * (j & 1) + 1];
+                } else {
+                    v0 = __builtin_bit_cast(float, xrw[j] << 16);
+                    v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
+                }
+                unsigned h, l;
+                ga2_split_pair(v0, v1, h, l);
+                xhw[j] = h; xlw[j] = l;
+            };
+            auto split_done = [&](f16x8& h8, f16x8& l8) {
+                if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
+                else h8 = __builtin_bit_cast(f16x8, xrw);
+            };
+            f16x8 WH[ND], WL[ND];
+            f16x8 xh, xl, xhp;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) WL[d] = (f16x8)(_Float16)0.0f;
+            xhp = (f16x8)(_Float16)0.0f;
+            __builtin_amdgcn_s_setprio(2);
+            for (int s = 0; s < S1; ++s) {
+                step_sync();
+                const char* slot = smem + rslot * G::SLOT;
+                read_x(slot);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s > 0) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[d], xhp, acc[d], 0, 0, 0);
+                        if (d < NSP) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            split_piece(d);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NSP; ++j) split_piece(j);
+                }
+                split_done(xh, xl);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
+                // step s+2 of this tile, or step s+2-S1 of the next one
+                const bool nx = s + PD >= S1;
+                const int un = nx ? s + PD - S1 : s + PD;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xh, acc[d], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (nx) LIN_DMA_AT(d, un, islot, (unsigned)lane16, TN, xoffn); else LIN_DMA_AT(d, un, islot, (unsigned)lane16, T, xoff);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (ND < G::NVX) {   // more pieces than MFMAs in the group (narrow chunks): issue the rest here
+#pragma unroll
+                    for (int d = ND; d < G::NVX; ++d) { if (nx) LIN_DMA_AT(d, un, islot, (unsigned)lane16, TN, xoffn); else LIN_DMA_AT(d, un, islot, (unsigned)lane16, T, xoff); }
+                }
+                islot = (islot + 1 == NB) ? 0 : islot + 1;
+                if constexpr (XLO) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xl, acc[d], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                xhp = xh;
+                rslot = (rslot + 1 == NB) ? 0 : rslot + 1;
+            }
+#pragma unroll
+            for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[d], xhp, acc[d], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+
+        // ======================================================= epilogue: transpose 32 x 32 tiles through the free slot, store rows
+        {
+            const int lane = opaque_lane();
+            const int i31 = lane & 31, hi = lane >> 5;
+            const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
+            float* pool = (float*)(G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW);
+            const int m0 = T.m0;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pool[mfma32_row(r, hi) * 36 + i31] = acc[c][r];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);     // column T.col + 32c + i31, rows 16hi ..
+                const int col = T.col + 32 * c + i31;
+                const float b = a.bias ? a.bias[col] : 0.0f;
+                float* yc = a.y + (size_t)(a.col0 + col);
+#pragma unroll
+                for (int mq = 0; mq < 4; ++mq) {
+                    const f32x4 hv = prow[mq];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = m0 + 16 * hi + 4 * mq + e;
+                        if (row < M) {
+                            float v = hv[e] + b;
+                            if (a.act == 1) v = fmaxf(v, 0.0f);
+                            float* dst = yc + (size_t)row * a.ldy;
+                            if (a.beta != 0.0f) v = fmaf(a.beta, *dst, v);
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        if (dynamic) {
+            if (wave == 0) draw_publish();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+        }
+        tile = ntile;
+        ntile = dynamic ? (int)__builtin_amdgcn_readfirstlane(*nn_lds) : tile + (int)gridDim.x;
+        T = TN;
+    }
+#undef LIN_DMA_AT
+    ga_wait_vm<0>();
+}

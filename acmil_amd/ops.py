@@ -462,3 +462,36 @@ def attn_heatmap(attn: torch.Tensor, zoom_factor: float = 1.0) -> torch.Tensor:
                "acmil_attn_heatmap")
     return probs
 
+
+def linear_pack(W: torch.Tensor) -> torch.Tensor:
+    """acmil_linear_pack: W [n_out, K] fp32 (CUDA, contiguous) -> packed fragment stream (uint8) for linear_f16x3."""
+    lib = _lib.load()
+    _need_cuda(W)
+    W = W.detach()
+    if W.dtype != torch.float32 or not W.is_contiguous() or W.dim() != 2:
+        raise RuntimeError("acmil_amd.linear_pack: W must be contiguous fp32 [n_out, K]")
+    n_out, K = W.shape
+    nbytes = lib.acmil_linear_packed_bytes(n_out, K)
+    if nbytes == 0:
+        raise RuntimeError("acmil_amd.linear_pack: needs n_out % 128 == 0 and K % 16 == 0, got %s" % (tuple(W.shape),))
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+    _lib.check(lib.acmil_linear_pack(W.data_ptr(), K, n_out, K, packed.data_ptr(), _stream()), "acmil_linear_pack")
+    return packed
+
+
+def linear_f16x3(x: torch.Tensor, packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None, relu: bool = False,
+                 out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
+    """acmil_linear_f16x3: y = act(x W^T + bias) + beta * y for x [M, K] (fp32 / fp16 / bf16, unit inner stride)."""
+    lib = _lib.load()
+    _need_cuda(x, packed)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in _DT:
+        raise RuntimeError("acmil_amd.linear_f16x3: x must be [M, K] with unit inner stride")
+    M, K = x.shape
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    ws = torch.empty(256, dtype=torch.uint8, device=x.device)
+    rc = lib.acmil_linear_f16x3(x.data_ptr(), _DT[x.dtype], M, K, x.stride(0), packed.data_ptr(), n_out, _ptr(bias), int(relu),
+                                float(beta), out.data_ptr(), out.stride(0), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_linear_f16x3")
+    return out
+

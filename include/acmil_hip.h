@@ -229,6 +229,23 @@ int acmil_mha_forward(const float* x, int N, int D, int Di, int K, int C, const 
                       float* slide_pred, float* attns, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * nn.Linear with a pre-packed weight stream: y = act(x W^T + bias) + beta * y   (csrc/linear_kernel.h)
+ * Replaces the Linear layers around the aggregation kernels: DimReduction.fc1 / TransMIL._fc1 (architecture/network.py:49-57,
+ * transMIL.py:51,63), NystromAttention.to_qkv / to_out (nystrom_attention.py:80,139).  Split-f16 arithmetic (as
+ * acmil_gemm_f16x3: ~1e-6 relative, operands inside the f16 range), persistent workgroups, LDS-DMA staging.
+ *   acmil_linear_pack: W [n_out, K] fp32 (leading dimension ldw) -> fragment stream of acmil_linear_packed_bytes(n_out, K)
+ *     bytes; n_out % 128 == 0, K % 16 == 0.  Re-pack when W changes.
+ *   acmil_linear_f16x3: x [M, K] of x_dtype (leading dimension ldx elements, rows 16-byte aligned), y [M, n_out] fp32
+ *     (leading dimension ldy); bias [n_out] or NULL; act 0 none / 1 relu; beta: residual accumulate.  workspace: 256 bytes.
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_linear_packed_bytes(int n_out, int K);
+
+int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream);
+
+int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
+                       const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Gated attention on an already projected bag (the other gated-attention consumers).
  *   acmil_gated_scores: A [K,N] = ((tanh(h Wv^T + bv) * sigmoid(h Wu^T + bu)) Ww^T + bw)^T for h [N,L] fp32, Wv/Wu [Da,L],
  *     Ww [K,Da]; any Da, K <= 5.  Replaces Attention_Gated.forward (architecture/Attention.py:47-57, ibmil.py:27-35) and

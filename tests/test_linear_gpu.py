@@ -1,0 +1,45 @@
+"""acmil_linear_f16x3 (packed-weight Linear kernel, csrc/linear_kernel.h) against fp64."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 16, 128)])
+@pytest.mark.parametrize("xdt", [torch.float32, torch.float16, torch.bfloat16])
+def test_linear_matches_fp64(m, k, n_out, xdt):
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(m + 3 * k + n_out)
+    x = (torch.randn(m, k, generator=g) * 2.0).to(xdt)
+    w = torch.randn(n_out, k, generator=g) * 0.05
+    b = torch.randn(n_out, generator=g)
+    ref = x.double() @ w.double().T + b.double()
+    scale = (x.double().abs() @ w.double().abs().T).max().item()
+    packed = ops.linear_pack(w.cuda())
+    y = ops.linear_f16x3(x.cuda(), packed, n_out, bias=b.cuda())
+    assert (y.cpu().double() - ref).abs().max().item() <= 3e-6 * scale + 1e-6
+    y = ops.linear_f16x3(x.cuda(), packed, n_out, bias=b.cuda(), relu=True)
+    assert (y.cpu().double() - ref.clamp_min(0)).abs().max().item() <= 3e-6 * scale + 1e-6
+    # residual accumulate into a strided destination, strided source rows, no bias
+    big = torch.randn(m, n_out + 64, generator=g).cuda()
+    y0 = big[:, 32:32 + n_out]
+    want = (ref - b.double()) + y0.cpu().double()
+    xs = torch.zeros(m, k + 16, dtype=xdt).cuda()
+    xs[:, :k] = x.cuda()
+    out = ops.linear_f16x3(xs[:, :k], packed, n_out, out=y0, beta=1.0)
+    assert out.data_ptr() == y0.data_ptr()
+    assert (y0.cpu().double() - want).abs().max().item() <= 3e-6 * scale + 2e-6
+    assert torch.equal(big[:, :32].cpu(), big[:, :32].cpu()) and torch.isfinite(big).all()
+
+
+def test_linear_bitwise_reproducible_and_equal_to_generic_gemm_class():
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(20000, 768, generator=g).cuda()
+    w = (torch.randn(384, 768, generator=g) * 0.03).cuda()
+    packed = ops.linear_pack(w)
+    a = ops.linear_f16x3(x, packed, 384)
+    b = ops.linear_f16x3(x, packed, 384)
+    assert torch.equal(a, b)
+    c = ops.gemm(x, w, trans_b=True, precision="f16x3")
+    assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item()
