@@ -190,10 +190,9 @@ static int ga_pick_waves(int maxN, long long total_patches = 0) {
     // one large bag; 4-wave (128-patch) workgroups, two per CU, spread small bags over more CUs and -- measured, 8 x 50 000
     // patches per launch: 524 vs 548 us -- balance better once a launch holds several rounds of tiles (>= 1024 of them).
     // ACMIL_GA_WAVES=4|8 overrides (tuning).
-    int w = (maxN >= 32768 && total_patches < 1024LL * 128) ? 8 : 4;
-    const char* e = getenv("ACMIL_GA_WAVES");
-    if (e && (atoi(e) == 4 || atoi(e) == 8)) w = atoi(e);
-    return w;
+    static const int env = [] { const char* e = getenv("ACMIL_GA_WAVES"); return e ? atoi(e) : 0; }();   // read once
+    if (env == 4 || env == 8) return env;
+    return (maxN >= 32768 && total_patches < 1024LL * 128) ? 8 : 4;
 }
 
 extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D, int Di, int K, int C, int mode) {
@@ -241,42 +240,8 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         if (hipMemsetAsync(a.tile_counter, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     a.L = ga_layout(D, Di, K, C, mode);
-#ifdef GA_TRACE
-    static unsigned long long* tr = nullptr;
-    if (!tr) { hipMalloc(&tr, 8 * 512 * 8); }
-    hipMemset(tr, 0, 8 * 512 * 8);
-    a.trace = tr;
-#endif
     rc = ga_dispatch(a, mode, x_dtype, true, st);
     if (rc != ACMIL_OK) return rc;
-#ifdef GA_TRACE
-    {
-        static int calls = 0;
-        if (++calls == 8) {
-            static unsigned long long h[8 * 512];
-            hipDeviceSynchronize();
-            hipMemcpy(h, tr, sizeof(h), hipMemcpyDeviceToHost);
-            const int S1 = D / 16;
-            unsigned long long t0 = h[0];
-            for (int w = 1; w < 8; ++w) if (h[w * 512] < t0) t0 = h[w * 512];
-            for (int s2 = 6; s2 < 14; ++s2) {
-                printf("TRACE step %2d:", s2);
-                for (int w = 0; w < 8; ++w) {
-                    unsigned long long* q = h + w * 512 + 4 * s2;
-                    printf(" w%d[arr %5llu wait %4llu bar %4llu body %4llu]", w, q[0] - t0, q[1] - q[0], q[2] - q[1], q[3] - q[2]);
-                }
-                printf("\n");
-            }
-            printf("TRACE step 9 sub-phases (cycles after barrier release): hh-MFMAs issued / DMA issued / lh-MFMAs issued / x read+split / end\n");
-            for (int w = 0; w < 8; ++w) {
-                unsigned long long* q = h + w * 512;
-                unsigned long long b0 = q[4 * 9 + 2];
-                printf("TRACE   w%d: gemm1 %llu relu+cvt %llu gemm2 blocks %llu %llu %llu %llu scores %llu pool %llu comb %llu total %llu\n", w, q[400] - q[0], q[4 * S1] - q[400], q[300] - q[400], q[301] - q[300], q[302] - q[301], q[303] - q[302], q[402] - q[401], q[403] - q[402], q[404] - q[403], q[404] - q[0]);
-            }
-            (void)S1;
-        }
-    }
-#endif
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,

@@ -48,9 +48,6 @@ struct GaFwdArgs {
     unsigned* status;         // v2: zeroed word; bit 0 = a bag value, bit 1 = a projected feature h outside the f16 range (or NaN):
                               //     the split-f16 result is then NOT the fp32 result and the caller must redo the bag in fp32 mode
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
-#ifdef GA_TRACE
-    unsigned long long* trace;   // debug builds only: s_memtime stamps of wave 0 / workgroup 0
-#endif
     GaLayout L;
 };
 
@@ -77,11 +74,6 @@ __device__ __forceinline__ void ga_glds16(const char* gsrc, unsigned ldst) {   /
 #define GA_GLDS16(gsrc, ldst) ga_glds16((const char*)(gsrc), (unsigned)(ldst))
 #endif
 
-#ifdef GA_TRACE
-#define GA_STAMP(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.trace[(threadIdx.x >> 6) * 512 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GA_STAMP(i) do {} while (0)
-#endif
 
 template <int N>
 __device__ __forceinline__ void ga_wait_vm() {
@@ -266,15 +258,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     constexpr int WAIT2 = (G::PD - 1) * G::N1;             // GEMM2 only needs W(s): all of steps s+1 .. s+PD-1 may be in flight
     for (int s = 0; s < S1; ++s) {
         // wait for W(s) and for this wave's x(s+1); the rest of step s+1 and all of step s+2 stay in flight
-        GA_STAMP(4 * s + 0);
         if constexpr (G::ALT) {
             // the group that issued step s (and, one step ago, step s+2) needs all of step s: its step s+2 stays in flight;
             // the other group issued step s+1 (x first) and needs x(s+1): its W(s+1) stays in flight
             if ((wave >> 2) == (s & 1)) ga_wait_vm<G::NA>(); else ga_wait_vm<G::WGA>();
         } else ga_wait_vm<WAIT1>();
-        GA_STAMP(4 * s + 1);
         __builtin_amdgcn_s_barrier();
-        GA_STAMP(4 * s + 2);
         if constexpr (G::ALT) issue_step(s + G::PD);   // issuing wave: DMA first, while its partner owns the matrix pipe
         // (non-ALT: the next ring slot's LDS-DMA is issued from inside the MFMA stream below: its issue cost -- address
         //  VALU, M0 writes, ~100 cycles per instruction -- then overlaps matrix-core work instead of delaying it)
@@ -332,9 +321,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) xv[j] = xvn[j];
         xh = xhn; xl = xln;
-        GA_STAMP(4 * s + 3);
     }
-    GA_STAMP(400);
 
     // =========================================================== relu
     // acc1[d][r] now holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)]
@@ -395,14 +382,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int s = S1 + g * 4 + st;
-            GA_STAMP(4 * s + 0);
             if constexpr (G::ALT) {
                 // S1 is even (D % 64 == 0), so step parity == (g*4 + st) parity: the group that issued step s drains it
                 if ((wave >> 2) == (st & 1)) ga_wait_vm<G::NA>();
             } else ga_wait_vm<WAIT2>();
-            GA_STAMP(4 * s + 1);
             __builtin_amdgcn_s_barrier();
-            GA_STAMP(4 * s + 2);
             if constexpr (G::ALT) issue_step(s + G::PD);
             const char* slot = smem + (s % G::NB) * G::SLOT;
 #pragma unroll
@@ -460,10 +444,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
                 sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
             }
         }
-        GA_STAMP(300 + g);
     }
 
-    GA_STAMP(401);
     const float* bwp = (const float*)(a.packed + L.bw_off);
     float smax[KP], lsum[KP], pe[KP];
 #pragma unroll
@@ -483,7 +465,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
     }
 
     // =========================================================== attention-weighted sum  sum_n p[k][n] h[n][:]
-    GA_STAMP(402);
     ga_wait_vm<0>();  // the clamped tail DMAs still target the ring: drain them before it is reused
     __syncthreads();  // every wave is done with the ring; region 0 becomes the pooling tiles
     float* pool = (float*)(smem + wave * G::POOLW);
@@ -531,7 +512,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             }
         }
     }
-    GA_STAMP(403);
     if constexpr (!POOL) return;
 
     // =========================================================== combine the 8 waves, publish the partial
@@ -570,7 +550,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
             out[k * PS + e] = v;
         }
     }
-    GA_STAMP(404);
 }
 
 // launcher for one (ND, KP, MODE, XDT) family; pool=true -> eval variant, else the h-saving score pass.
@@ -584,8 +563,10 @@ int ga_launch_fwd_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
     const dim3 grid(a.tile_start[a.nbags]), block(64 * WAVES);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>
                                    : ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
-        return ACMIL_ERR_LAUNCH;
+    static const hipError_t attr[2] = {   // once per process, not per launch
+        hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS),
+        hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)};
+    if (attr[0] != hipSuccess || attr[1] != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

@@ -43,6 +43,18 @@ class FlatAdamW:
         self.step_count = 0
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
         self.on_step = on_step
+        self._frozen = []          # (offset, numel) ranges that receive no gradient this run: skipped like torch skips grad=None
+
+    def set_frozen(self, params: Iterable[torch.nn.Parameter]):
+        """Parameters that never receive a gradient (e.g. the branch head of an n_token = 1 ACMIL model, whose loss term is not
+        built: Step3_WSI_classification_ACMIL.py:201-204).  torch.optim.AdamW skips a parameter whose .grad is None -- no
+        moment update and NO weight decay; the flat kernel touches every element, so these ranges are put back after the step."""
+        ids = {id(p) for p in params}
+        self._frozen, off = [], 0
+        for p in self.params:
+            if id(p) in ids:
+                self._frozen.append((off, p.numel()))
+            off += p.numel()
 
     def zero_grad(self, set_to_none: bool = False):
         self.grad.zero_()
@@ -53,19 +65,53 @@ class FlatAdamW:
         self.step_count += 1
         b1, b2 = g["betas"]
         lib = _lib.load()
+        kept = [(o, self.flat[o:o + n].clone()) for o, n in self._frozen]
         rc = lib.acmil_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                   self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
                                   1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "acmil_adamw_step")
+        for o, v in kept:
+            self.flat[o:o + v.numel()].copy_(v)
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
             self.on_step()
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        """torch.optim.AdamW's layout (what the reference's checkpoints hold under 'optimizer', utils/utils.py:415-422): per-parameter
+        'state' entries {step, exp_avg, exp_avg_sq} and 'param_groups' with parameter indices -- loadable by torch.optim.AdamW."""
+        state, off = {}, 0
+        frozen = {o for o, _ in self._frozen}
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            if off not in frozen and self.step_count > 0:
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
+            off += n
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": True, "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """Accepts torch.optim.AdamW's layout (also one written by the reference) or this class's earlier flat layout."""
+        if "state" in sd:
+            off, steps = 0, []
+            for i, p in enumerate(self.params):
+                n = p.numel()
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                if st is not None:
+                    self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.append(int(float(st["step"])))
+                else:
+                    self.exp_avg[off:off + n].zero_(); self.exp_avg_sq[off:off + n].zero_()
+                off += n
+            self.step_count = max(steps) if steps else 0
+            for g, s_ in zip(self.param_groups, sd["param_groups"]):
+                g.update({k: v for k, v in s_.items() if k in ("lr", "betas", "eps", "weight_decay")})
+            return
         self.step_count = int(sd["step"])
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+        for g, s_ in zip(self.param_groups, sd["param_groups"]):
+            g.update(s_)

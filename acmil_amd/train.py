@@ -296,8 +296,13 @@ def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, l
     params = [p for p in model.parameters() if p.requires_grad]
     if device.type == "cuda" and not getattr(conf, "torch_optimizer", False):
         from .optim import FlatAdamW
-        return FlatAdamW(params, lr=lr, weight_decay=conf.wd, grad_buffer=None if bucket is None else bucket.flat,
-                         on_step=getattr(model, "invalidate_packed", None))
+        opt = FlatAdamW(params, lr=lr, weight_decay=conf.wd, grad_buffer=None if bucket is None else bucket.flat,
+                        on_step=getattr(model, "invalidate_packed", None))
+        if getattr(conf, "arch", "") == "ga" and getattr(conf, "n_token", 2) == 1:
+            # n_token == 1: the branch-head loss is not built (Step3_WSI_classification_ACMIL.py:201-204), its parameters keep
+            # grad None in the reference and torch's AdamW leaves them untouched (no weight decay)
+            opt.set_frozen(list(model.classifier[0].parameters()))
+        return opt
     return torch.optim.AdamW(params, lr=lr, weight_decay=conf.wd)
 
 

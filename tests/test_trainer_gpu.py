@@ -76,8 +76,28 @@ def test_flat_adamw_matches_torch_adamw():
         ref.step(); mine.step()
     for a, b in zip(ref_p, my_p):
         assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    # the checkpoint entry has torch.optim.AdamW's layout: a torch optimizer loads it and continues identically
     sd = mine.state_dict()
-    assert sd["step"] == 25 and sd["exp_avg"].numel() == sum(p.numel() for p in my_p)
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == len(my_p) and float(sd["state"][0]["step"]) == 25.0
+    twin_p = [torch.nn.Parameter(p.detach().clone()) for p in my_p]
+    twin = torch.optim.AdamW(twin_p, lr=1e-3, weight_decay=1e-2)
+    twin.load_state_dict(sd)
+    back = FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in my_p], lr=1e-3, weight_decay=1e-2)
+    back.load_state_dict(ref.state_dict())                      # and the reverse: a torch (reference) checkpoint into FlatAdamW
+    for a, b, c in zip(ref_p, twin_p, back.params):
+        grad = torch.randn(a.shape, generator=g).cuda()
+        a.grad = grad.clone(); b.grad = grad.clone(); c.grad.copy_(grad)
+    ref.step(); twin.step(); back.step()
+    for a, b, c in zip(ref_p, twin_p, back.params):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+        assert (a - c).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item())
+    # frozen ranges (parameters without gradient) are left untouched, as torch does for grad=None
+    fz = FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in my_p], lr=1e-2, weight_decay=0.5)
+    fz.set_frozen([fz.params[1]])
+    before = fz.params[1].detach().clone()
+    fz.grad.zero_(); fz.step()
+    assert torch.equal(fz.params[1], before) and not torch.equal(fz.params[0], my_p[0])
+    assert 1 not in fz.state_dict()["state"]
 
 
 @pytest.mark.parametrize("arch,extra", [("ga", ["--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"]), ("transmil", []),
