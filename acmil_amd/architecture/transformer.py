@@ -140,6 +140,9 @@ class _GatedBase(nn.Module):
             if self.precision != "f16x3":
                 return ops.ga_scores(xb, packed, dims, self.precision)
             A, h, status = ops.ga_scores(xb, packed, dims, self.precision, with_status=True)
+            if getattr(self, "_defer_guard", False):
+                self._pending_status = status         # the fused training step checks it once, after its last launch
+                return A, h
             if self._out_of_range(status):
                 p32, d32 = self._packed("fp32")
                 self._bwd_dims = d32               # the backward of this step follows in exact fp32 as well
@@ -287,14 +290,38 @@ class ACMIL_GA(_GatedBase):
         packed, dims = self._packed()
         xb = self._bag(x)
         params = self._all_params()
-        out = self._masked_forward(xb, packed, dims, uniforms, want_afeat=True,
-                                   masking=self.n_masked_patch > 0 and self.training)
-        losses, d_sub, d_slide, d_A = ops.ga_loss(out["sub_preds"], out.get("slide_pred"), out["A_out"], label)
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-        ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], out.get("dims_bwd", dims), d_sub, d_slide,
-                        d_A, grads_out=[p.grad for p in params])
+        masking = self.n_masked_patch > 0 and self.training
+        if masking and uniforms is None:      # drawn here so that an fp32 re-run of the step masks the same patches
+            uniforms = torch.rand(dims.K, min(self.n_masked_patch, xb.shape[0]), device=xb.device)
+
+        def run():
+            out = self._masked_forward(xb, packed, dims, uniforms, want_afeat=True, masking=masking)
+            losses, d_sub, d_slide, d_A = ops.ga_loss(out["sub_preds"], out.get("slide_pred"), out["A_out"], label)
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+            ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], out.get("dims_bwd", dims), d_sub,
+                            d_slide, d_A, grads_out=[p.grad for p in params])
+            return losses, out
+
+        # Range guard of the split-f16 score pass: the status word is read ONCE, after the step's last launch (a read in the
+        # middle would idle the GPU while the host enqueues the ~20 launches that follow); a flagged step is redone in fp32.
+        self._pending_status = None
+        self._defer_guard = (self.range_guard and getattr(self, "guard_deferred", True) and self.precision == "f16x3"
+                             and self._is_fused())
+        try:
+            losses, out = run()
+        finally:
+            self._defer_guard = False
+        if self._pending_status is not None and self._out_of_range(self._pending_status):
+            keep, self.precision = self.precision, "fp32"
+            self._pack_cache = None
+            try:
+                packed, dims = self._packed()
+                losses, out = run()
+            finally:
+                self.precision = keep
+                self._pack_cache = None
         self._last = out
         return losses, out
 

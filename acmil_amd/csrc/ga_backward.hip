@@ -16,10 +16,8 @@
 // Everything heavy is exact-fp32 MFMA (gemm_f32.hip); the row pass is HBM-streaming with one wave per row.
 #include "ga_common.h"
 
-extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
-                              long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
-                              float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
-                              int batch, void* workspace, void* stream);
+#include "ga_train_internal.h"
+
 extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
 
 #define GB_MAXK ACMIL_MAX_TOKENS
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(1024) void ga_bwd_stats_kernel(const float* __restr
 }
 
 struct GaBwdGateArgs {
-    const float *h, *A, *dA_ext, *d_afeat, *ck, *stats, *Ww;
+    const float *h, *A, *dA_ext, *coef, *d_afeat, *ck, *stats, *Ww;   // coef [KP][KP] (or null): the diversity-loss term of dA formed here
     float* G;     // [N][256] in: pre-activations (v | u), out: dG
     float* dh0;   // [N][Di] out
     float* part;  // [blocks][KP*128 + KP + 256] partial sums
@@ -118,10 +116,12 @@ __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
     __shared__ float sred[4][PREC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, K = a.K;
-    float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP];
+    float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KP][KP];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const bool on = k < K;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) cf[k][j] = (a.coef && on && j < K) ? a.coef[k * KP + j] : 0.0f;
 #pragma unroll
         for (int f = 0; f < FPL; ++f) daf[k][f] = on ? a.d_afeat[(size_t)k * Di + FPL * lane + f] : 0.0f;
         ww[k][0] = on ? a.Ww[k * GA_DA + 2 * lane] : 0.0f;
@@ -152,6 +152,15 @@ __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
             P[k] = masked ? 0.0f : __expf(s - Mk[k]) * iL[k];
             const float ext = (a.dA_ext && k < K) ? a.dA_ext[(size_t)k * N + n] : 0.0f;
             dA[k] = masked ? 0.0f : fmaf(P[k], dp - ck[k], ext);
+        }
+        if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (ga_loss.hip; zero where masked: p = 0)
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                float sdiv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) sdiv = fmaf(cf[k][j], P[j], sdiv);
+                dA[k] = fmaf(P[k], sdiv, dA[k]);
+            }
         }
         const float* grow = a.G + (size_t)n * (2 * GA_DA);
         const float gv0 = grow[2 * lane], gv1 = grow[2 * lane + 1];
@@ -193,25 +202,6 @@ __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
     for (int e = tid; e < PREC; e += 256) out[e] = (sred[0][e] + sred[1][e]) + (sred[2][e] + sred[3][e]);
 }
 
-// fixed-order sum of the gate pass partial records -> dWw [K][128], dbw [K], dbv [128], dbu [128]
-// one wave per output element: lanes stride over the workgroup records, then a shuffle tree (deterministic)
-template <int KP>
-__global__ __launch_bounds__(256) void ga_bwd_reduce_kernel(const float* __restrict__ part, int blocks, int K,
-                                                            float* dWw, float* dbw, float* dbv, float* dbu) {
-    constexpr int PREC = KP * GA_DA + KP + 2 * GA_DA;
-    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= PREC) return;
-    float s = 0.0f;
-    for (int b = lane; b < blocks; b += 64) s += part[(size_t)b * PREC + e];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    if (lane != 0) return;
-    if (e < KP * GA_DA) { const int k = e / GA_DA; if (k < K) dWw[k * GA_DA + e % GA_DA] = s; }
-    else if (e < KP * GA_DA + KP) { const int k = e - KP * GA_DA; if (k < K) dbw[k] = s; }
-    else if (e < KP * GA_DA + KP + GA_DA) dbv[e - KP * GA_DA - KP] = s;
-    else dbu[e - KP * GA_DA - KP - GA_DA] = s;
-}
-
 static size_t gb_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // [Wv; Wu] -> one [2 Da, Di] matrix and [bv; bu] -> [2 Da] (so the three products with the attention weights are single GEMMs),
@@ -225,9 +215,7 @@ __global__ __launch_bounds__(256) void gb_split_kernel(const float* __restrict__
     for (int e = blockIdx.x * 256 + threadIdx.x; e < 2 * per; e += gridDim.x * 256) (e < per ? dWv : dWu)[e < per ? e : e - per] = dWcat[e];
 }
 
-struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, total; };
-
-static GbWs gb_layout(int N, int D, int Di, int K) {
+GbWs gb_layout(int N, int D, int Di, int K) {
     GbWs w; size_t off = 0;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
     w.G = off;       off += gb_align((size_t)N * 2 * GA_DA * 4);
@@ -239,9 +227,10 @@ static GbWs gb_layout(int N, int D, int Di, int K) {
     w.wcat = off;    off += gb_align((size_t)2 * GA_DA * Di * 4);     // [Wv; Wu] as one [2 Da, Di] matrix
     w.bcat = off;    off += gb_align((size_t)2 * GA_DA * 4);
     w.dwcat = off;   off += gb_align((size_t)2 * GA_DA * Di * 4);
-    size_t g = acmil_gemm_workspace_bytes(Di, D, N, 1);
-    size_t g2 = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1);
-    w.gemm = off;    off += gb_align(g > g2 ? g : g2);
+    const size_t g = acmil_gemm_workspace_bytes(Di, D, N, 1);          // the two split-K products keep their partials until the
+    const size_t g2 = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1); // shared finishing launch: separate regions
+    w.gemm = off;    off += gb_align(g);
+    w.gemm2 = off;   off += gb_align(g2);
     w.total = off;
     return w;
 }
@@ -250,6 +239,76 @@ extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K,
     (void)C;
     if (N <= 0 || D <= 0 || Di <= 0 || K <= 0) return 0;
     return gb_layout(N, D, Di, K).total;
+}
+
+// Steps 3-7 of the header: G recompute, gate pass, dpre, the two weight-gradient products and ONE finishing launch (both
+// split-K reduces + the gate pass' partial records).  d_afeat, ck, stats are given (ws regions, filled by the caller).
+// GEMM arithmetic follows the forward mode: exact fp32 MFMA, or split products -- f16 halves for the recomputed
+// pre-activations (forward-sized values), bf16 halves wherever an operand is a gradient (values down to 1e-8).
+int gb_run(const GbRun& r) {
+    const int N = r.N, D = r.D, Di = r.Di, K = r.K;
+    if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;   // gate pass instances (FPL = Di/64)
+    const int x_fwd = (r.mode == ACMIL_MODE_F32) ? 0 : 1, x_grad = (r.mode == ACMIL_MODE_F32) ? 0 : 2;
+    hipStream_t st = r.st;
+    char* ws = r.ws;
+    const GbWs L = gb_layout(N, D, Di, K);
+    float* G = (float*)(ws + L.G);
+    float* dpre = (float*)(ws + L.dpre);
+    float* part = (float*)(ws + L.part);
+    // [Wv; Wu] and [bv; bu] as single operands: in place when the caller's tensors are adjacent (flat parameter / gradient
+    // buckets laid out that way), through a concat / split copy otherwise
+    const bool w_adj = (r.Wu == r.Wv + (size_t)GA_DA * Di) && (r.bu == r.bv + GA_DA);
+    const bool g_adj = (r.dWu == r.dWv + (size_t)GA_DA * Di);
+    const float* Wcat = w_adj ? r.Wv : (const float*)(ws + L.wcat);
+    const float* bcat = w_adj ? r.bv : (const float*)(ws + L.bcat);
+    float* dWcat = g_adj ? r.dWv : (float*)(ws + L.dwcat);
+    int rc;
+    if (!w_adj) {
+        hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, r.Wv, r.Wu, r.bv, r.bu, GA_DA * Di, (float*)(ws + L.wcat), (float*)(ws + L.bcat));
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
+    // 3 G = h [Wv;Wu]^T + [bv;bu]
+    GemmArgs gd;
+    rc = gemm_run_deferred(x_fwd, 0, 1, N, 2 * GA_DA, Di, 1.0f, r.h, Di, Wcat, ACMIL_DTYPE_F32, Di, 0.0f, G, 2 * GA_DA, bcat, 0, nullptr, ws + L.gemm, st, &gd);
+    if (rc != ACMIL_OK) return rc;
+    if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;     // K = Di: never split
+    // 4 gate pass
+    GaBwdGateArgs ga;
+    ga.h = r.h; ga.A = r.A_out; ga.dA_ext = r.dA_ext; ga.coef = r.coef; ga.d_afeat = r.d_afeat; ga.ck = r.ck; ga.stats = r.stats; ga.Ww = r.Ww;
+    ga.G = G; ga.dh0 = dpre; ga.part = part; ga.N = N; ga.K = K;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int FPL = Di / 64;
+    const int blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
+#define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
+    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
+    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
+    else return ACMIL_ERR_UNSUPPORTED;
+#undef GB_LAUNCH_GATE
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
+    rc = gemm_run_deferred(x_grad, 0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, Wcat, ACMIL_DTYPE_F32, Di, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
+    if (rc != ACMIL_OK) return rc;
+    if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
+    // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
+    GemmArgs g1, g2;
+    rc = gemm_run_deferred(x_grad, 1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, r.h, ACMIL_DTYPE_F32, Di, 0.0f, dWcat, Di, nullptr, 0, nullptr, ws + L.gemm2, st, &g1);
+    if (rc != ACMIL_OK) return rc;
+    rc = gemm_run_deferred(x_grad, 1, 0, Di, D, N, 1.0f, dpre, Di, r.x, r.x_dtype, D, 0.0f, r.dW1, D, nullptr, 0, nullptr, ws + L.gemm, st, &g2);
+    if (rc != ACMIL_OK) return rc;
+    // 7 one finishing launch: both split-K reduces and the gate pass' partial records (fixed order)
+    RowSumJob job;
+    job.part = part; job.records = blocks; job.stride = KP * GA_DA + KP + 2 * GA_DA; job.len = job.stride; job.nseg = 4;
+    job.off[0] = 0;                          job.cnt[0] = K * GA_DA; job.dst[0] = r.dWw;
+    job.off[1] = KP * GA_DA;                 job.cnt[1] = K;         job.dst[1] = r.dbw;
+    job.off[2] = KP * GA_DA + KP;            job.cnt[2] = GA_DA;     job.dst[2] = r.dbv;
+    job.off[3] = KP * GA_DA + KP + GA_DA;    job.cnt[3] = GA_DA;     job.dst[3] = r.dbu;
+    rc = gemm_finish(&g1, &g2, &job, st);
+    if (rc != ACMIL_OK) return rc;
+    if (!g_adj) {
+        hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, dWcat, GA_DA * Di, r.dWv, r.dWu);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    }
+    return ACMIL_OK;
 }
 
 extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const float* A_out,
@@ -262,27 +321,16 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     if (rc != ACMIL_OK) return rc;
     if (N <= 0) return ACMIL_ERR_SHAPE;
     if (mode != ACMIL_MODE_F32 && mode != ACMIL_MODE_F16X3 && mode != ACMIL_MODE_F16) return ACMIL_ERR_UNSUPPORTED;
-    // GEMM arithmetic follows the forward mode: exact fp32 MFMA, or split products -- f16 halves for the recomputed
-    // pre-activations (forward-sized values), bf16 halves wherever an operand is a gradient (values down to 1e-8)
-    typedef int (*gemm_fn)(int, int, int, int, int, float, const float*, int, long long, const void*, int, int, long long, float,
-                           float*, int, long long, const float*, int, const float*, int, void*, void*);
-    const gemm_fn gemm_fwd = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_f16x3;
-    const gemm_fn gemm_grad = (mode == ACMIL_MODE_F32) ? acmil_gemm_f32 : acmil_gemm_bf16x3;
-    if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;   // gate pass instances (FPL = Di/64)
+    if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;
     if (!x || !h || !A_out || !afeat || !Wv || !bv || !Wu || !bu || !Ww || !Wc || !d_sub || !workspace) return ACMIL_ERR_NULL;
     if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc) return ACMIL_ERR_NULL;
     if ((Ws != nullptr) != (d_slide != nullptr) || (Ws && (!dWs || !dbs))) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     const GbWs L = gb_layout(N, D, Di, K);
-    float* G = (float*)(ws + L.G);
-    float* dpre = (float*)(ws + L.dpre);
     float* d_afeat = (float*)(ws + L.d_afeat);
     float* ck = (float*)(ws + L.ck);
     float* stats = (float*)(ws + L.stats);
-    float* part = (float*)(ws + L.part);
-    void* gws = ws + L.gemm;
-    float* Wcat = (float*)(ws + L.wcat); float* bcat = (float*)(ws + L.bcat); float* dWcat = (float*)(ws + L.dwcat);
 
     // 1 heads
     GaBwdHeadArgs ha;
@@ -296,38 +344,10 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     // 2 stats
     hipLaunchKernelGGL(ga_bwd_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // 3 G = h [Wv;Wu]^T + [bv;bu]   (one GEMM on the concatenated weights)
-    hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, Wv, Wu, bv, bu, GA_DA * Di, Wcat, bcat);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    rc = gemm_fwd(0, 1, N, 2 * GA_DA, Di, 1.0f, h, Di, 0, Wcat, ACMIL_DTYPE_F32, Di, 0, 0.0f, G, 2 * GA_DA, 0, bcat, 0, nullptr, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
-    // 4 gate pass
-    GaBwdGateArgs ga;
-    ga.h = h; ga.A = A_out; ga.dA_ext = d_A; ga.d_afeat = d_afeat; ga.ck = ck; ga.stats = stats; ga.Ww = Ww;
-    ga.G = G; ga.dh0 = dpre; ga.part = part; ga.N = N; ga.K = K;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
-    const int FPL = Di / 64;
-    const int blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
-#define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
-    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
-    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
-    else return ACMIL_ERR_UNSUPPORTED;
-#undef GB_LAUNCH_GATE
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
-    rc = gemm_grad(0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, 0, Wcat, ACMIL_DTYPE_F32, Di, 0, 1.0f, dpre, Di, 0, nullptr, 2, h, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
-    // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
-    rc = gemm_grad(1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, 0, h, ACMIL_DTYPE_F32, Di, 0, 0.0f, dWcat, Di, 0, nullptr, 0, nullptr, 1, gws, st);
-    if (rc != ACMIL_OK) return rc;
-    hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, dWcat, GA_DA * Di, dWv, dWu);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    rc = gemm_grad(1, 0, Di, D, N, 1.0f, dpre, Di, 0, x, x_dtype, D, 0, 0.0f, dW1, D, 0, nullptr, 0, nullptr, 1, gws,
-                        st);
-    if (rc != ACMIL_OK) return rc;
-    // 7 reduce gate partials
-    const int prec = KP * GA_DA + KP + 2 * GA_DA;
-    if (KP == 1) hipLaunchKernelGGL(ga_bwd_reduce_kernel<1>, dim3((prec + 3) / 4), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
-    else hipLaunchKernelGGL(ga_bwd_reduce_kernel<5>, dim3((prec + 3) / 4), dim3(256), 0, st, part, blocks, K, dWw, dbw, dbv, dbu);
-    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+    GbRun r;
+    r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
+    r.dA_ext = d_A; r.coef = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
+    r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
+    r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = ws; r.st = st;
+    return gb_run(r);
 }

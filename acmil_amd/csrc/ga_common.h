@@ -75,6 +75,13 @@ static inline int ga_check_dims(int D, int Di, int Da, int K, int C) {
 __device__ static inline float ga_sigmoid(float u) { return __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
 __device__ static inline float ga_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * v)); }
 
-// merge + heads (ga_forward.hip), shared by the fused forward and the masked pooling pass
+// Control block = the FIRST GA_CTRL_BYTES of every GA workspace (32-bit words): 0 tile counter of the persistent forward,
+// 1 range status of the split-f16 arithmetic = result of the MOST RECENT launch on this workspace, 2 finished-workgroup
+// counter, 3 range-flag accumulator of the running launch, 4.. arrival counters of the single-launch STKIM / tail kernels.
+// The caller zeroes the block ONCE when it allocates the workspace; every kernel that counts in it leaves its counters at
+// zero again (the last workgroup resets them), so no memset sits on the stream between launches.
+#define GA_CTRL_BYTES 256
+
+// merge + heads (ga_forward.hip), shared by the fused forward and the masked pooling pass; the afeat scratch follows the partials
 int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
-              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st);
+              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, hipStream_t st);

@@ -154,7 +154,7 @@ extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, i
     b = (b + 255) & ~(size_t)255;
     b += (size_t)K * Di * sizeof(float);                                          // afeat scratch
     b = (b + 255) & ~(size_t)255;
-    return b + 256;                                                               // tile counter of the persistent kernel
+    return GA_CTRL_BYTES + b;                                                     // control block first (ga_common.h)
 }
 
 // merge + heads shared by the fused forward (batched) and the masked pooling pass.
@@ -178,11 +178,11 @@ static int ga_finish_batch(const float* part, const int* tile_start, int nbags, 
 }
 
 int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
-              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, void* workspace, hipStream_t st) {
+              float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, hipStream_t st) {
     const int ts[2] = {0, tiles};
-    size_t poff = ((size_t)tiles * L.K * ga_part_stride(L.Di) * sizeof(float) + 255) & ~(size_t)255;
+    size_t poff = ((size_t)tiles * L.K * ga_part_stride(L.Di) * sizeof(float) + 255) & ~(size_t)255;   // afeat scratch follows the partials
     return ga_finish_batch(part, ts, 1, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
-                           (float*)((char*)workspace + poff), st);
+                           (float*)((char*)part + poff), st);
 }
 
 static int ga_pick_waves(int maxN, long long total_patches = 0) {
@@ -202,7 +202,7 @@ extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D
     for (int b = 0; b < nbags; ++b) { if (Ns[b] <= 0) return 0; tiles += ga_pool_tiles(Ns[b]); }
     size_t bytes = (tiles * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     bytes += ((size_t)nbags * K * Di * sizeof(float) + 255) & ~(size_t)255;
-    return bytes + 256;                                                           // tile counter of the persistent kernel
+    return GA_CTRL_BYTES + bytes;
 }
 
 extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
@@ -232,20 +232,16 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         a.A_outs[b] = (b < nbags && A_outs) ? A_outs[b] : nullptr;
         a.tile_start[b + 1] = a.tile_start[b] + (b < nbags ? (Ns[b] + 32 * a.waves - 1) / (32 * a.waves) : 0);
     }
-    a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = nullptr;
+    a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)((char*)workspace + GA_CTRL_BYTES); a.h_save = nullptr;
     a.tile_counter = nullptr; a.status = nullptr;
-    if (ga_use_v2(mode)) {   // the last 256 bytes of the workspace: {tile counter, range status}, zeroed on the stream ahead of the launch
-        a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_batch_workspace_bytes(nbags, Ns, D, Di, K, C, mode) - 256);
-        a.status = a.tile_counter + 1;
-        if (hipMemsetAsync(a.tile_counter, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
-    }
+    if (ga_use_v2(mode)) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }   // control block, see ga_common.h
     a.L = ga_layout(D, Di, K, C, mode);
     rc = ga_dispatch(a, mode, x_dtype, true, st);
     if (rc != ACMIL_OK) return rc;
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
-                           (float*)((char*)workspace + poff), st);
+                           (float*)((char*)a.part + poff), st);
 }
 
 extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,
@@ -274,13 +270,9 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);
-    a.nbags = 1; a.packed = (const char*)packed; a.part = (float*)workspace; a.h_save = h_save;
+    a.nbags = 1; a.packed = (const char*)packed; a.part = workspace ? (float*)((char*)workspace + GA_CTRL_BYTES) : nullptr; a.h_save = h_save;
     a.tile_counter = nullptr; a.status = nullptr;
-    if (ga_use_v2(mode) && workspace) {
-        a.tile_counter = (unsigned*)((char*)workspace + acmil_ga_workspace_bytes(N, D, Di, K, C, mode) - 256);
-        a.status = a.tile_counter + 1;
-        if (hipMemsetAsync(a.tile_counter, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
-    }
+    if (ga_use_v2(mode) && workspace) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }
     a.L = ga_layout(D, Di, K, C, mode);
     return ga_dispatch(a, mode, x_dtype, false, st);
 }

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             // 65504 = largest finite f16; !(x < limit) also catches NaN
             const bool xbad = valid && xmax >= 0x477fe000u /* 65504.0f */, hbad = valid && !(hmax < 65504.0f);
             const unsigned bits = (__builtin_amdgcn_ballot_w64(xbad) != 0 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(hbad) != 0 ? 2u : 0u);
-            if (bits != 0 && lane == 0) atomicOr(a.status, bits);      // (ballots outside the one-lane branch: all lanes vote)
+            if (bits != 0 && lane == 0) atomicOr(a.status + 2, bits);  // accumulator word (ballots outside the one-lane branch: all lanes vote)
         }
         constexpr int NS = (KP + 1) / 2;
         float smax[KP], lsum[KP], pe[NS];
@@ -783,6 +783,21 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     }
 #undef GA2_DMA_AT
     ga_wait_vm<0>();   // the last tile's look-ahead pieces (re-fetched rows nobody reads) must land before the LDS is released
+    // Leave the tile counter at zero for the next launch: every draw of this workgroup has returned (its value was consumed),
+    // so the workgroup that arrives last resets both counters -- no memset on the stream between launches.
+    // The range flags were OR-ed into the accumulator word; the last workgroup moves them to the status word (= the result
+    // of THIS launch, overwritten by the next) and clears the accumulator.  vmcnt(0) above + the barrier: every wave's
+    // atomicOr has reached L2 before this workgroup counts itself as finished.
+    if (dynamic) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned done = atomicAdd(a.tile_counter + 2, 1u);
+            if (done == gridDim.x - 1) {
+                atomicExch(a.tile_counter + 2, 0u); atomicExch(a.tile_counter, 0u);
+                atomicExch(a.status, atomicExch(a.status + 2, 0u));
+            }
+        }
+    }
 }
 
 // persistent launch: two workgroups per CU (or one per tile when there are fewer tiles)

@@ -35,91 +35,121 @@ __device__ static inline unsigned long long block_max_key(unsigned long long key
     return m;
 }
 
-// grid (nchunks, K): each block extracts the k best keys of its chunk of row K -> cand[branch][chunk][k]
-__global__ __launch_bounds__(256) void stkim_local_topk_kernel(const float* __restrict__ scores, int N, int k,
-                                                               unsigned long long* __restrict__ cand) {
+// Single launch, grid (nchunks, K):
+//   every block extracts the k best keys of its chunk of row br -> cand[br][chunk][k], then counts itself in `arrive`;
+//   the block that arrives last (any block: the merge order is fixed by index, not by arrival) finishes all K branches,
+//   one wave per branch: merge the candidates into the sorted top-k, pick the masked subset (the columns with the m smallest
+//   uniforms, argsort ascending, first m, in that order) and -- when A_mask is given -- write the -1e9 mask into the scores
+//   (architecture/transformer.py:311-320).  `arrive` is left at zero for the next launch.
+#define STKIM_MERGE_E 32      // candidates per lane in the merge: nchunks * k <= 64 * 32
+__global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, int N, int K,
+                                                          int k, int m, const float* __restrict__ uniforms,
+                                                          unsigned long long* __restrict__ cand, unsigned* __restrict__ arrive,
+                                                          int64_t* __restrict__ topk_idx, int64_t* __restrict__ masked_idx) {
     __shared__ unsigned long long red[4];
+    __shared__ unsigned sel[4][64];
+    __shared__ int is_last;
     const int chunk = blockIdx.x, br = blockIdx.y, nch = gridDim.x;
-    const float* row = scores + (size_t)br * N;
-    unsigned long long keys[STKIM_EPT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const float* row = scores + (size_t)br * N;
+        unsigned long long keys[STKIM_EPT];
 #pragma unroll
-    for (int e = 0; e < STKIM_EPT; ++e) {
-        const unsigned idx = (unsigned)chunk * STKIM_CHUNK + e * 256 + threadIdx.x;
-        keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
-    }
-    unsigned long long* out = cand + ((size_t)br * nch + chunk) * k;
-    for (int j = 0; j < k; ++j) {
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int e = 0; e < STKIM_EPT; ++e) best = keys[e] > best ? keys[e] : best;
-        const unsigned long long win = block_max_key(best, red);
-        if (threadIdx.x == 0) out[j] = win;
-#pragma unroll
-        for (int e = 0; e < STKIM_EPT; ++e)
-            if (keys[e] == win) keys[e] = 0ull;  // keys are unique (index in the low word); 0 = taken / padding
-    }
-}
-
-// grid (K): merge the per-chunk candidates of one branch into the sorted top-k, then pick the masked subset
-__global__ __launch_bounds__(256) void stkim_merge_select_kernel(const unsigned long long* __restrict__ cand, int ncand,
-                                                                 int k, int m, const float* __restrict__ uniforms,
-                                                                 int64_t* __restrict__ topk_idx,
-                                                                 int64_t* __restrict__ masked_idx) {
-    __shared__ unsigned long long red[4];
-    __shared__ unsigned sel[64];
-    const int br = blockIdx.x;
-    const unsigned long long* c = cand + (size_t)br * ncand;
-    // each thread owns candidates tid, tid+256, ... (ncand = nchunks*k is small: <= 25*64)
-    unsigned long long keys[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int i = e * 256 + threadIdx.x;
-        keys[e] = i < ncand ? c[i] : 0ull;
-    }
-    for (int j = 0; j < k; ++j) {
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) best = keys[e] > best ? keys[e] : best;
-        const unsigned long long win = block_max_key(best, red);
-        if (threadIdx.x == 0) {
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(win & 0xFFFFFFFFull);
-            sel[j] = idx;
-            topk_idx[(size_t)br * k + j] = (int64_t)idx;
+        for (int e = 0; e < STKIM_EPT; ++e) {
+            const unsigned idx = (unsigned)chunk * STKIM_CHUNK + e * 256 + tid;
+            keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
         }
+        unsigned long long* out = cand + ((size_t)br * nch + chunk) * k;
+        for (int j = 0; j < k; ++j) {
+            unsigned long long best = 0ull;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (keys[e] == win) keys[e] = 0ull;
+            for (int e = 0; e < STKIM_EPT; ++e) best = keys[e] > best ? keys[e] : best;
+            const unsigned long long win = block_max_key(best, red);
+            if (tid == 0) out[j] = win;
+#pragma unroll
+            for (int e = 0; e < STKIM_EPT; ++e)
+                if (keys[e] == win) keys[e] = 0ull;  // keys are unique (index in the low word); 0 = taken / padding
+        }
+    }
+    // release the candidates, count this block, the last one acquires everybody's
+    if (tid == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(arrive, 1u);
+        is_last = (t == (unsigned)(gridDim.x * gridDim.y) - 1u) ? 1 : 0;
+        if (is_last) { __threadfence(); atomicExch(arrive, 0u); }
     }
     __syncthreads();
-    // masked subset: the columns with the m smallest uniforms (argsort ascending, first m), in that order
-    if ((int)threadIdx.x < k && m > 0) {
-        const float* u = uniforms + (size_t)br * k;
-        const float mine = u[threadIdx.x];
-        int rank = 0;
-        for (int j = 0; j < k; ++j) rank += (u[j] < mine || (u[j] == mine && j < (int)threadIdx.x)) ? 1 : 0;
-        if (rank < m) masked_idx[(size_t)br * m + rank] = (int64_t)sel[threadIdx.x];
+    if (!is_last) return;
+    const int ncand = nch * k;
+    for (int b = wave; b < K; b += 4) {
+        const unsigned long long* c = cand + (size_t)b * ncand;
+        unsigned long long keys[STKIM_MERGE_E];
+#pragma unroll
+        for (int e = 0; e < STKIM_MERGE_E; ++e) {
+            const int i = e * 64 + lane;
+            keys[e] = i < ncand ? __builtin_nontemporal_load(c + i) : 0ull;
+        }
+        for (int j = 0; j < k; ++j) {
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int e = 0; e < STKIM_MERGE_E; ++e) best = keys[e] > best ? keys[e] : best;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const unsigned long long other = __shfl_xor(best, o);
+                best = other > best ? other : best;
+            }
+            if (lane == 0) {
+                const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+                sel[wave][j] = idx;
+                topk_idx[(size_t)b * k + j] = (int64_t)idx;
+            }
+#pragma unroll
+            for (int e = 0; e < STKIM_MERGE_E; ++e)
+                if (keys[e] == best) keys[e] = 0ull;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // sel[] written by lane 0 is visible to the wave
+        if (lane < k && m > 0) {
+            const float* u = uniforms + (size_t)b * k;
+            const float mine = u[lane];
+            int rank = 0;
+            for (int j = 0; j < k; ++j) rank += (u[j] < mine || (u[j] == mine && j < lane)) ? 1 : 0;
+            if (rank < m) {
+                const unsigned n = sel[wave][lane];
+                masked_idx[(size_t)b * m + rank] = (int64_t)n;
+                if (A_mask && n < (unsigned)N) A_mask[(size_t)b * N + n] = -1e9f;
+            }
+        }
     }
 }
 
+// workspace: [256-byte control block: arrival counter][candidates]
 extern "C" size_t acmil_stkim_workspace_bytes(int N, int K, int k) {
     if (N <= 0 || K <= 0 || k <= 0) return 0;
     const size_t nch = (size_t)(N + STKIM_CHUNK - 1) / STKIM_CHUNK;
-    return ((size_t)K * nch * k * sizeof(unsigned long long) + 255) & ~(size_t)255;
+    return 256 + (((size_t)K * nch * k * sizeof(unsigned long long) + 255) & ~(size_t)255);
+}
+
+// shared by acmil_stkim_select and the fused training step (ga_step.hip): one launch; `arrive` must be zero and is left zero
+int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
+                 int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st) {
+    if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
+    if (!scores || !topk_idx || !cand || !arrive || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
+    const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
+    if ((size_t)nch * k > 64 * STKIM_MERGE_E) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
+    hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, N, K, k, m, uniforms, cand, arrive,
+                       topk_idx, masked_idx);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
 extern "C" int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
                                   int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
-    if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
-    if (!scores || !topk_idx || !workspace || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
-    const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
-    if ((size_t)nch * k > 8 * 256) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
+    if (!workspace) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long* cand = (unsigned long long*)workspace;
-    hipLaunchKernelGGL(stkim_local_topk_kernel, dim3(nch, K), dim3(256), 0, st, scores, N, k, cand);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(stkim_merge_select_kernel, dim3(K), dim3(256), 0, st, cand, nch * k, k, m, uniforms, topk_idx,
-                       masked_idx);
-    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+    // stand-alone call on a caller-provided scratch buffer: the arrival counter is zeroed here (the fused step keeps its own)
+    if (hipMemsetAsync(workspace, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    return stkim_launch(scores, nullptr, N, K, k, m, uniforms, topk_idx, masked_idx,
+                        (unsigned long long*)((char*)workspace + 256), (unsigned*)workspace, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -139,9 +169,12 @@ __global__ void ga_apply_mask_kernel(float* __restrict__ A, int N, int K, const 
 // the same format the fused forward emits (so ga_merge_kernel / ga_heads_kernel finish both).
 // 256 threads; LPR = Di/4 lanes cover one h row with float4 loads, RPI = 256/LPR rows per iteration.
 // ------------------------------------------------------------------------------------------------
+// gram != nullptr (training step): also the tile's Gram partial of the UNNORMALISED probabilities, gram[tile][i*KP+j] =
+// sum_n e_i(n) e_j(n), i <= j, e_k(n) = exp(s_k(n) - m_tile,k) -- rescaled by the tail kernel (ga_step.hip) for the
+// diversity loss (Step3_WSI_classification_ACMIL.py:207-212).
 template <int KP>
 __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ h, const float* __restrict__ A, int N,
-                                                      int K, int Di, float* __restrict__ part) {
+                                                      int K, int Di, float* __restrict__ part, float* __restrict__ gram) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* p_lds = (float*)smem;                     // [128][KP]
     float* stat = p_lds + 128 * KP;                  // [KP][2] : m, l
@@ -169,6 +202,18 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
         if (lane == 0) { stat[2 * k] = m; stat[2 * k + 1] = l; }
     }
     __syncthreads();
+    if (gram && wave == 0) {
+        float* go = gram + (size_t)blockIdx.x * KP * KP;
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+#pragma unroll
+            for (int j = i; j < KP; ++j) {
+                float v = fmaf(p_lds[lane * KP + i], p_lds[lane * KP + j], p_lds[(lane + 64) * KP + i] * p_lds[(lane + 64) * KP + j]);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                if (lane == 0) go[i * KP + j] = v;
+            }
+    }
     const int LPR = Di / 4, RPI = 256 / LPR;
     const int rsub = tid / LPR, c4 = tid % LPR;
     float acc[KP][4];
@@ -202,6 +247,21 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
     }
 }
 
+// one workgroup per 128-row tile; gram: see the kernel.  Shared by acmil_ga_pool, acmil_attn_pool and the fused step.
+int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st) {
+    if (Di % 64 != 0 || Di / 4 > 256 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
+    const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
+    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
+    void (*kern)(const float*, const float*, int, int, int, float*, float*) =
+        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(ga_pool_tiles(N)), dim3(256), lds, st, h, A, N, K, Di, part, gram);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
 extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed, int D, int Di, int Da, int K, int C,
                              int mode, const int64_t* masked_idx, int n_masked, float* sub_preds, float* slide_pred,
                              float* afeat, float* bag_feat, int has_bag_head, void* workspace, void* stream) {
@@ -218,18 +278,10 @@ extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed
     }
     const GaLayout L = ga_layout(D, Di, K, C, mode);
     const int tiles = ga_pool_tiles(N);
-    float* part = (float*)workspace;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
-    const int RPI = 256 / (Di / 4);
-    const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
-    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
-    void (*kern)(const float*, const float*, int, int, int, float*) =
-        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, h, (const float*)A, N, K, Di, part);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    return ga_finish(part, tiles, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head, workspace, st);
+    float* part = (float*)((char*)workspace + GA_CTRL_BYTES);     // same layout as acmil_ga_forward: control block first
+    rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st);
+    if (rc != ACMIL_OK) return rc;
+    return ga_finish(part, tiles, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head, st);
 }
 
 // Attention pooling without heads: afeat [K, Di] = softmax_N(A) h for raw scores A [K, N] (not modified) -- the
@@ -247,17 +299,8 @@ extern "C" int acmil_attn_pool(const float* h, const float* A, int N, int Di, in
     hipStream_t st = (hipStream_t)stream;
     const int tiles = ga_pool_tiles(N);
     float* part = (float*)workspace;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
-    const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
-    if (Di / 4 > 256) return ACMIL_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
-    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
-    void (*kern)(const float*, const float*, int, int, int, float*) =
-        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, h, A, N, K, Di, part);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    const int rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st);
+    if (rc != ACMIL_OK) return rc;
     GaLayout L; L.K = K; L.Di = Di; L.C = 1; L.D = 0; L.ND = Di / 32; L.mode = 0;
-    return ga_finish(part, tiles, nullptr, L, nullptr, nullptr, afeat, nullptr, 0, workspace, st);
+    return ga_finish(part, tiles, nullptr, L, nullptr, nullptr, afeat, nullptr, 0, st);
 }

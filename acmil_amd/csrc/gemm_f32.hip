@@ -15,18 +15,13 @@
 // Tall-K problems (weight gradients: K = number of patches) are split along K over gridDim.z into a
 // workspace and reduced in a fixed order (deterministic), the epilogue then runs in the reduce kernel.
 #include "ga_common.h"
+#include "gemm_internal.h"
+#include <string.h>
 
 #define GM_BM 128
 #define GM_BN 128
 #define GM_BK 32
 
-struct GemmArgs {
-    const float* A; const void* B; float* C; const float* bias; const float* aux; float* ws;
-    int M, N, K, lda, ldb, ldc;
-    long long sA, sB, sC;   // batch strides (elements)
-    int transA, transB, b_dtype, act, splits, kchunk;
-    float alpha, beta;
-};
 
 template <int BDT>
 __device__ __forceinline__ float gm_ldb(const void* B, long long idx) {
@@ -383,9 +378,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f16x3_kernel(GemmArgs g) {
     gm_epilogue<2>(g, acc, m0, n0, wm, wn, i31, hi, batch, split);
 }
 
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) {
+__device__ __forceinline__ void gm_reduce_body(const GemmArgs& g, int nbatch, int block, int nblocks) {
     const long long per = (long long)g.M * g.N, total = per * nbatch;
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    for (long long e = (long long)block * 256 + threadIdx.x; e < total; e += (long long)nblocks * 256) {
         const int b = e / per; const long long r = e % per;
         const float* src = g.ws + (long long)b * g.splits * per + r;
         float s = 0.0f;
@@ -407,6 +402,27 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
         if (g.beta != 0.0f) v += g.beta * *dst;
         *dst = gm_act(v, g.act, g.aux + (long long)b * g.sC, idx);
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) { gm_reduce_body(g, nbatch, blockIdx.x, gridDim.x); }
+
+// One launch that finishes up to two split-K products (their fixed-order reduces + epilogues) and one "sum of per-workgroup
+// partial records" job (the gate pass of the GA backward): blocks [0, b1) reduce g1, [b1, b1 + b2) reduce g2, the rest
+// take four record elements each -- one wave per element, lanes stride the records, shuffle tree (deterministic).
+__global__ __launch_bounds__(256) void gemm_finish_kernel(GemmArgs g1, GemmArgs g2, RowSumJob job, int b1, int b2) {
+    const int blk = blockIdx.x;
+    if (blk < b1) { gm_reduce_body(g1, 1, blk, b1); return; }
+    if (blk < b1 + b2) { gm_reduce_body(g2, 1, blk - b1, b2); return; }
+    const int e = (blk - b1 - b2) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= job.len) return;
+    float s = 0.0f;
+    for (int r = lane; r < job.records; r += 64) s += job.part[(size_t)r * job.stride + e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane != 0) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q < job.nseg && e >= job.off[q] && e < job.off[q] + job.cnt[q]) job.dst[q][e - job.off[q]] = s;
 }
 
 // 64 x 64 tiles when the 128 x 128 grid would leave most CUs idle and K is too short to split
@@ -434,7 +450,7 @@ extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch) {
 static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                   long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
                   float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
-                  int batch, void* workspace, void* stream) {
+                  int batch, void* workspace, void* stream, GemmArgs* defer = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
     if (!A || !B || !C) return ACMIL_ERR_NULL;
     if (act < 0 || act > 4) return ACMIL_ERR_UNSUPPORTED;
@@ -475,6 +491,7 @@ static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alp
         default: return ACMIL_ERR_UNSUPPORTED;
     }
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (defer) { *defer = g; return ACMIL_OK; }       // the caller finishes it with gemm_finish (splits may be 1: nothing left to do)
     if (g.splits > 1) {
         const long long total = (long long)M * N * batch;
         const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -506,4 +523,28 @@ extern "C" int acmil_gemm_bf16x3(int transA, int transB, int M, int N, int K, fl
                                  int batch, void* workspace, void* stream) {
     return gm_run(2, transA, transB, M, N, K, alpha, A, lda, strideA, B, b_dtype, ldb, strideB, beta, C, ldc, strideC, bias, act,
                   aux, batch, workspace, stream);
+}
+
+// ---- internal (gemm_internal.h): a split-K product whose reduce is left to gemm_finish, so that several products and a
+// record sum share ONE finishing launch (the GA training step).  batch = 1.
+int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B,
+                      int b_dtype, int ldb, float beta, float* C, int ldc, const float* bias, int act, const float* aux,
+                      void* workspace, hipStream_t stream, GemmArgs* out) {
+    if (!out) return ACMIL_ERR_NULL;
+    return gm_run(x3, transA, transB, M, N, K, alpha, A, lda, 0, B, b_dtype, ldb, 0, beta, C, ldc, 0, bias, act, aux, 1, workspace,
+                  (void*)stream, out);
+}
+
+int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hipStream_t st) {
+    GemmArgs z; memset(&z, 0, sizeof(z)); z.splits = 1;
+    RowSumJob zj; memset(&zj, 0, sizeof(zj));
+    auto nblk = [](const GemmArgs* g) {
+        if (!g || g->splits <= 1) return 0;
+        const long long total = (long long)g->M * g->N;
+        return (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    };
+    const int b1 = nblk(g1), b2 = nblk(g2), b3 = (job && job->len > 0) ? (job->len + 3) / 4 : 0;
+    if (b1 + b2 + b3 == 0) return ACMIL_OK;
+    hipLaunchKernelGGL(gemm_finish_kernel, dim3(b1 + b2 + b3), dim3(256), 0, st, g1 ? *g1 : z, g2 ? *g2 : z, job ? *job : zj, b1, b2);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

@@ -1,0 +1,27 @@
+// gemm_internal.h -- library-internal view of the GEMM launcher (gemm_f32.hip): products whose split-K reduce is deferred so
+// that one finishing launch serves several of them (ga_backward.hip / ga_step.hip).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GemmArgs {
+    const float* A; const void* B; float* C; const float* bias; const float* aux; float* ws;
+    int M, N, K, lda, ldb, ldc;
+    long long sA, sB, sC;   // batch strides (elements)
+    int transA, transB, b_dtype, act, splits, kchunk;
+    float alpha, beta;
+};
+
+// sum `records` partial records of `len` floats (record r at part + r * stride) in a fixed order; element e goes to the
+// segment q with off[q] <= e < off[q] + cnt[q] (elements outside every segment are dropped: padded branches)
+struct RowSumJob {
+    const float* part; int records, stride, len, nseg;
+    int off[4], cnt[4];
+    float* dst[4];
+};
+
+// x3: 0 exact fp32 MFMA, 1 split-f16, 2 split-bf16 (as acmil_gemm_f32 / _f16x3 / _bf16x3).  Launches the product only; `out`
+// receives what gemm_finish needs (out->splits == 1: the product already wrote C with its epilogue).
+int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B,
+                      int b_dtype, int ldb, float beta, float* C, int ldc, const float* bias, int act, const float* aux,
+                      void* workspace, hipStream_t stream, GemmArgs* out);
+int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hipStream_t stream);

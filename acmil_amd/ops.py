@@ -78,16 +78,33 @@ def ga_pack_weights(W1, Wv, bv, Wu, bu, Ww, bw, Wc: Sequence[torch.Tensor], bc: 
     return packed, dims
 
 
+_WS_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _ws_bytes(nbytes: int, device) -> torch.Tensor:
+    """Grow-only GA workspace per (device, stream).  The library's contract (csrc/ga_common.h): the first 256 bytes are a
+    control block that is zero when the workspace is first used and that every launch leaves zero again (apart from the
+    sticky range status), so the buffer is zero-filled once here and then reused -- no memset between launches.  Calls are
+    stream-ordered and a call's workspace contents are dead when it returns, so one buffer per stream is enough."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _WS_CACHE[key] = ws
+    return ws
+
+
 def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
-    n = _lib.load().acmil_ga_workspace_bytes(N, dims.D, dims.Di, dims.K, dims.C, mode)
-    return torch.empty(n, dtype=torch.uint8, device=device)
+    return _ws_bytes(_lib.load().acmil_ga_workspace_bytes(N, dims.D, dims.Di, dims.K, dims.C, mode), device)
 
 
 def _range_status(ws: torch.Tensor) -> torch.Tensor:
-    """Device view of the split-f16 range status the fused kernel leaves in its workspace (last 256 bytes: {tile counter,
-    status}).  Non-zero = a bag value (bit 0) or a projected feature (bit 1) left the f16 range / was not finite: the
-    f16x3 result is then not the fp32 result.  Reading it (`int(...)`) synchronises; the modules do that, the raw ops do not."""
-    return ws[-252:-248].view(torch.int32)
+    """Device view of the split-f16 range status word of a GA workspace (control block, word 1).  Non-zero = a bag value
+    (bit 0) or a projected feature (bit 1) left the f16 range / was not finite: the f16x3 result is then not the fp32
+    result.  The word is STICKY (the kernels OR flags in); whoever acts on it clears it (`status.zero_()`).  Reading it
+    (`int(...)`) synchronises; the modules do that, the raw ops do not."""
+    return ws[4:8].view(torch.int32)
 
 
 def _check_x(x: torch.Tensor, dims: GaDims) -> None:
@@ -144,7 +161,7 @@ def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaD
     slide = torch.empty(B, dims.C, **f32) if dims.has_bag_head else None
     af = torch.empty(B, dims.K, dims.Di, **f32) if want_afeat else None
     bf = torch.empty(B, dims.Di, **f32) if want_bag_feat else None
-    ws = torch.empty(lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, mode), dtype=torch.uint8, device=dev)
+    ws = _ws_bytes(lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, mode), dev)
     rc = lib.acmil_ga_forward_batch(B, xp, Ns, _DT[xs[0].dtype], packed.data_ptr(), *dims.args(), mode, Ap, sub.data_ptr(),
                                     _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_forward_batch")

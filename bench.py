@@ -399,13 +399,13 @@ def main(argv=None):
 
     # ---- dominant kernel alone (ga_fwd_kernel, same template instance): scores-only calls launch just it
     n_k = max(50, min(args.steps, 400))
-    ws = torch.empty(_lib.load().acmil_ga_workspace_bytes(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, ops.mode_id(args.precision)),
-                     dtype=torch.uint8, device=dev)
+    ws = torch.zeros(_lib.load().acmil_ga_workspace_bytes(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, ops.mode_id(args.precision)),
+                     dtype=torch.uint8, device=dev)      # zeroed once: the control block contract of the GA workspace
     a_out = torch.empty(N_TOKEN, N_PATCH, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     import ctypes
-    ws_b = torch.empty(_lib.load().acmil_ga_batch_workspace_bytes(B, (ctypes.c_int * B)(*[N_PATCH] * B), D_FEAT, D_INNER, N_TOKEN,
+    ws_b = torch.zeros(_lib.load().acmil_ga_batch_workspace_bytes(B, (ctypes.c_int * B)(*[N_PATCH] * B), D_FEAT, D_INNER, N_TOKEN,
                                                                   N_CLASS, ops.mode_id(args.precision)), dtype=torch.uint8, device=dev)
     a_outs = [torch.empty(N_TOKEN, N_PATCH, dtype=torch.float32, device=dev) for _ in range(B)]
     a_ptrs = (ctypes.c_void_p * B)(*[t.data_ptr() for t in a_outs])
