@@ -144,7 +144,8 @@ int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m,
 
 extern "C" int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
                                   int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
-    if (!workspace) return ACMIL_ERR_NULL;
+    if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
+    if (!scores || !topk_idx || !workspace || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     // stand-alone call on a caller-provided scratch buffer: the arrival counter is zeroed here (the fused step keeps its own)
     if (hipMemsetAsync(workspace, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
