@@ -80,6 +80,11 @@ SIGNATURES = {
     "acmil_ga_backward_workspace_bytes": (_sz, [_i] * 5),
     "acmil_ga_backward": (_i, [_vp, _i, _i] + [_vp] * 8 + [C.POINTER(_vp)] + [_vp] * 4 + [_vp] * 7 +
                           [C.POINTER(_vp), C.POINTER(_vp)] + [_vp, _vp] + [_i] * 6 + [_vp, _vp]),
+    "acmil_ga_train_step_workspace_bytes": (_sz, [_i] * 6),
+    # x, x_dtype, N, packed, repack | W1 Wv bv Wu bu Ww bw Wc[] bc[] Ws bs | dW1 dWv dbv dWu dbu dWw dbw dWc[] dbc[] dWs dbs |
+    # D Di Da K C mode | label uniforms k_top m_mask | losses sub slide A_out topk midx | workspace stream
+    "acmil_ga_train_step": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
+                            [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 6 + [_vp, _vp]),
 }
 
 _lib = None

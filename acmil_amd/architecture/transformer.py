@@ -140,9 +140,6 @@ class _GatedBase(nn.Module):
             if self.precision != "f16x3":
                 return ops.ga_scores(xb, packed, dims, self.precision)
             A, h, status = ops.ga_scores(xb, packed, dims, self.precision, with_status=True)
-            if getattr(self, "_defer_guard", False):
-                self._pending_status = status         # the fused training step checks it once, after its last launch
-                return A, h
             if self._out_of_range(status):
                 p32, d32 = self._packed("fp32")
                 self._bwd_dims = d32               # the backward of this step follows in exact fp32 as well
@@ -287,43 +284,59 @@ class ACMIL_GA(_GatedBase):
         Same mathematics as `loss = diff + loss0 + loss1; loss.backward()` of the reference's train_one_epoch
         (Step3_WSI_classification_ACMIL.py:200-219); the optimiser step stays with the caller.
         x [1,N,D_feat], label [1] int64 on the GPU.  Returns (losses [4] = loss0, loss1, diff_loss, total, on device; outputs dict)."""
-        packed, dims = self._packed()
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
+        k_top = min(self.n_masked_patch, xb.shape[0]) if masking else 0
         if masking and uniforms is None:      # drawn here so that an fp32 re-run of the step masks the same patches
-            uniforms = torch.rand(dims.K, min(self.n_masked_patch, xb.shape[0]), device=xb.device)
+            uniforms = torch.rand(self.attention.attention_weights.weight.shape[0], k_top, device=xb.device)
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        if self._is_fused() and getattr(self, "fused_step", True):
+            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top)
+        else:
+            losses, out = self._train_step_composed(xb, label, uniforms, params, masking)
+        self._last = out
+        return losses, out
+
+    def _train_step_fused(self, xb, label, uniforms, params, k_top):
+        """The whole step enqueued by one library call (csrc/ga_step.hip: 11 launches).  The packed weights are rebuilt inside
+        the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
+        after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
+        dev = xb.device
+        m_mask = int(k_top * self.mask_drop)
+        grads = [p.grad for p in params]
+        dets = [p.detach() for p in params]
+        label = label.to(torch.int64)
+
+        def run(precision):
+            mode = ops.mode_id(precision)
+            st = getattr(self, "_step_packed", None)
+            if st is None or st[0] != (mode, dev):
+                packed, dims = self._packed(precision) if precision != self.precision else self._packed()
+                st = ((mode, dev), packed.clone(), dims)         # a private buffer: the call rewrites it every step
+                self._step_packed = st
+            return ops.ga_train_step(xb, st[1], st[2], precision, dets, grads, label, uniforms, k_top, m_mask, repack=True)
+
+        out = run(self.precision)
+        if self.precision == "f16x3" and self._out_of_range(out["range_status"]):
+            out = run("fp32")
+            out["range_fallback"] = True
+        return out["losses"], out
+
+    def _train_step_composed(self, xb, label, uniforms, params, masking):
+        """Op-by-op step (the wide D_inner families, and the fused step's cross-check in the tests)."""
+        packed, dims = self._packed()
 
         def run():
             out = self._masked_forward(xb, packed, dims, uniforms, want_afeat=True, masking=masking)
             losses, d_sub, d_slide, d_A = ops.ga_loss(out["sub_preds"], out.get("slide_pred"), out["A_out"], label)
-            for p in params:
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
             ops.ga_backward(xb, out["h"], out["A_out"], out["afeat"], [p.detach() for p in params], out.get("dims_bwd", dims), d_sub,
                             d_slide, d_A, grads_out=[p.grad for p in params])
             return losses, out
 
-        # Range guard of the split-f16 score pass: the status word is read ONCE, after the step's last launch (a read in the
-        # middle would idle the GPU while the host enqueues the ~20 launches that follow); a flagged step is redone in fp32.
-        self._pending_status = None
-        self._defer_guard = (self.range_guard and getattr(self, "guard_deferred", True) and self.precision == "f16x3"
-                             and self._is_fused())
-        try:
-            losses, out = run()
-        finally:
-            self._defer_guard = False
-        if self._pending_status is not None and self._out_of_range(self._pending_status):
-            keep, self.precision = self.precision, "fp32"
-            self._pack_cache = None
-            try:
-                packed, dims = self._packed()
-                losses, out = run()
-            finally:
-                self.precision = keep
-                self._pack_cache = None
-        self._last = out
-        return losses, out
+        return run()       # (the score pass handles the split-f16 range guard itself: fp32 re-run + fp32 backward)
 
     @torch.no_grad()
     def forward_batch(self, bags):

@@ -255,15 +255,16 @@ int gb_run(const GbRun& r) {
     float* G = (float*)(ws + L.G);
     float* dpre = (float*)(ws + L.dpre);
     float* part = (float*)(ws + L.part);
-    // [Wv; Wu] and [bv; bu] as single operands: in place when the caller's tensors are adjacent (flat parameter / gradient
-    // buckets laid out that way), through a concat / split copy otherwise
+    // [Wv; Wu] and [bv; bu] as single operands: the copy inside the packed buffer when the caller has one (training step),
+    // the tensors themselves when they are adjacent in memory, a concat copy otherwise.  [dWv; dWu] are written by the
+    // finishing launch straight into the two gradient tensors whenever the weight-gradient product is split (always, at
+    // bag sizes worth a GPU); only the unsplit product of a tiny bag goes through a scratch matrix + split copy.
     const bool w_adj = (r.Wu == r.Wv + (size_t)GA_DA * Di) && (r.bu == r.bv + GA_DA);
     const bool g_adj = (r.dWu == r.dWv + (size_t)GA_DA * Di);
-    const float* Wcat = w_adj ? r.Wv : (const float*)(ws + L.wcat);
-    const float* bcat = w_adj ? r.bv : (const float*)(ws + L.bcat);
-    float* dWcat = g_adj ? r.dWv : (float*)(ws + L.dwcat);
+    const float* Wcat = r.Wcat ? r.Wcat : w_adj ? r.Wv : (const float*)(ws + L.wcat);
+    const float* bcat = r.Wcat ? r.bcat : w_adj ? r.bv : (const float*)(ws + L.bcat);
     int rc;
-    if (!w_adj) {
+    if (!r.Wcat && !w_adj) {
         hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, r.Wv, r.Wu, r.bv, r.bu, GA_DA * Di, (float*)(ws + L.wcat), (float*)(ws + L.bcat));
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
@@ -291,8 +292,12 @@ int gb_run(const GbRun& r) {
     if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
     // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
     GemmArgs g1, g2;
+    const bool will_split = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1) > 256;      // same rule as the launcher's
+    float* dWcat = (g_adj || will_split) ? r.dWv : (float*)(ws + L.dwcat);
     rc = gemm_run_deferred(x_grad, 1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, r.h, ACMIL_DTYPE_F32, Di, 0.0f, dWcat, Di, nullptr, 0, nullptr, ws + L.gemm2, st, &g1);
     if (rc != ACMIL_OK) return rc;
+    if (will_split != (g1.splits > 1)) return ACMIL_ERR_LAUNCH;
+    if (g1.splits > 1 && !g_adj) { g1.C2 = r.dWu; g1.split_row = GA_DA; }
     rc = gemm_run_deferred(x_grad, 1, 0, Di, D, N, 1.0f, dpre, Di, r.x, r.x_dtype, D, 0.0f, r.dW1, D, nullptr, 0, nullptr, ws + L.gemm, st, &g2);
     if (rc != ACMIL_OK) return rc;
     // 7 one finishing launch: both split-K reduces and the gate pass' partial records (fixed order)
@@ -304,7 +309,7 @@ int gb_run(const GbRun& r) {
     job.off[3] = KP * GA_DA + KP + GA_DA;    job.cnt[3] = GA_DA;     job.dst[3] = r.dbu;
     rc = gemm_finish(&g1, &g2, &job, st);
     if (rc != ACMIL_OK) return rc;
-    if (!g_adj) {
+    if (!g_adj && g1.splits <= 1) {
         hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, dWcat, GA_DA * Di, r.dWv, r.dWu);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
@@ -346,7 +351,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     GbRun r;
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
-    r.dA_ext = d_A; r.coef = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
+    r.dA_ext = d_A; r.coef = nullptr; r.Wcat = nullptr; r.bcat = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = ws; r.st = st;
     return gb_run(r);

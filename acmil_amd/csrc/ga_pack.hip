@@ -92,28 +92,42 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
         }
         return;
     }
-    // ---- tail: epilogue table, biases, classifier heads (handled by the first workgroup past the streams)
+    // ---- past the streams: one workgroup for the small vectors, then 1024 elements per workgroup of the raw fp32 copies
+    // (concatenated attention weights for the backward, classifier heads)
     const size_t tail_block = (L.g1_rows + L.g2_rows + 3) / 4;
-    if (blockIdx.x != tail_block) return;
     const int tid = threadIdx.x;
+    const int CD = L.C * L.Di;
+    if (blockIdx.x > tail_block) {
+        const size_t ncat = (size_t)2 * GA_DA * L.Di, nwc = (size_t)L.K * CD, total = ncat + nwc + CD;
+        float* wcat = (float*)(a.out + L.wcat_off);
+        float* wc = (float*)(a.out + L.wc_off);
+        float* ws = (float*)(a.out + L.ws_off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t e = ((size_t)blockIdx.x - tail_block - 1) * 1024 + q * 256 + tid;
+            if (e >= total) break;
+            if (e < ncat) wcat[e] = e < ncat / 2 ? a.Wv[e] : a.Wu[e - ncat / 2];
+            else if (e < ncat + nwc) { const size_t r = e - ncat; wc[r] = a.Wc[r / CD][r % CD]; }
+            else { const size_t r = e - ncat - nwc; ws[r] = a.Ws ? a.Ws[r] : 0.0f; }
+        }
+        return;
+    }
+    if (blockIdx.x != tail_block) return;
     float* tab = (float*)(a.out + L.tab_off);
+    float* bcat = (float*)(a.out + L.bcat_off);
     for (int e = tid; e < GA_DA; e += 256) {
         tab[e] = a.bv[e];
         tab[GA_DA + e] = a.bu[e];
+        bcat[e] = a.bv[e];
+        bcat[GA_DA + e] = a.bu[e];
         for (int k = 0; k < L.K; ++k) tab[(2 + k) * GA_DA + e] = a.Ww[(size_t)k * GA_DA + e];
     }
     float* bw = (float*)(a.out + L.bw_off);
     if (tid < 8) bw[tid] = (tid < L.K) ? a.bw[tid] : 0.0f;
-    float* wc = (float*)(a.out + L.wc_off);
     float* bc = (float*)(a.out + L.bc_off);
-    const int CD = L.C * L.Di;
-    for (int k = 0; k < L.K; ++k) {
-        for (int e = tid; e < CD; e += 256) wc[(size_t)k * CD + e] = a.Wc[k][e];
+    for (int k = 0; k < L.K; ++k)
         if (tid < L.C) bc[k * L.C + tid] = a.bc[k][tid];
-    }
-    float* ws = (float*)(a.out + L.ws_off);
     float* bs = (float*)(a.out + L.bs_off);
-    for (int e = tid; e < CD; e += 256) ws[e] = a.Ws ? a.Ws[e] : 0.0f;
     if (tid < L.C) bs[tid] = a.bs ? a.bs[tid] : 0.0f;
 }
 
@@ -140,7 +154,8 @@ extern "C" int acmil_ga_pack_weights(const float* W1, const float* Wv, const flo
     }
     a.out = (char*)packed;
     a.L = ga_layout(D, Di, K, C, mode);
-    const unsigned blocks = (unsigned)((a.L.g1_rows + a.L.g2_rows + 3) / 4) + 1;
+    const size_t aux = (size_t)2 * GA_DA * Di + (size_t)K * C * Di + (size_t)C * Di;
+    const unsigned blocks = (unsigned)((a.L.g1_rows + a.L.g2_rows + 3) / 4) + 1 + (unsigned)((aux + 1023) / 1024);
     hipLaunchKernelGGL(ga_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

@@ -1,0 +1,363 @@
+// ga_step.hip -- one ACMIL_GA training step as ONE call (C ABI: acmil_ga_train_step) and the "tail" kernel that folds the
+// small launches after the pooling pass into the merge.
+//
+// Replaces, for one slide, the reference's
+//   forward   architecture/transformer.py:305-330 (training branch: STKIM :311-320, masked softmax + pooling :322-324, heads :325-330)
+//   loss      Step3_WSI_classification_ACMIL.py:201-216 (branch CE, bag CE, diversity loss)
+//   backward  autograd of the above
+// The step is launch-bound at N = 10 000 (each kernel runs 5-25 us), so what matters is the number of launches and the host
+// time per launch.  Sequence (11 launches; the reference issues ~350 small torch kernels):
+//   1 pack (only when the parameters changed)   2 score pass (fused forward, keeps h)     3 STKIM + mask (single launch)
+//   4 pooling tiles + Gram partials              5 tail: merge | last workgroup: heads, losses, dL/d(logits), head gradients,
+//                                                   d_afeat, c_k, softmax statistics, diversity coefficients
+//   6 G recompute   7 gate pass (forms the diversity term of dA itself)   8 dpre   9, 10 the two split-K weight gradients
+//   11 one finishing launch (both reduces + gate partial records)
+// All of it is enqueued by one C call: the Python side does one ctypes call instead of ~26 tensor-op wrappers.
+#include "ga_train_internal.h"
+
+#define GA_MERGE_GROUPS 16
+#define GS_MAXK ACMIL_MAX_TOKENS
+
+extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
+extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K, int C);
+extern "C" size_t acmil_ga_packed_bytes(int D, int Di, int Da, int K, int C, int mode);
+extern "C" int acmil_ga_pack_weights(const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                     const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                                     const float* Ws, const float* bs, int D, int Di, int Da, int K, int C, int mode,
+                                     void* packed, void* stream);
+extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,
+                                int C, int mode, float* A_out, float* sub_preds, float* slide_pred, float* afeat,
+                                float* bag_feat, float* h_save, int has_bag_head, void* workspace, void* stream);
+
+struct GaTailArgs {
+    const float* part; int tiles; int K, Di, C, KP;
+    float* afeat;                 // [K][Di] out
+    unsigned* arrive;             // control-block word: zero on entry, zero on exit
+    const char* packed; GaLayout L; int has_bag_head;
+    float *sub_preds, *slide_pred;
+    // ---- training extension
+    const int64_t* label; const float* gram_part;
+    float *stats, *losses, *d_sub, *d_slide, *coef, *d_afeat, *ck;
+    float* dWc[GS_MAXK]; float* dbc[GS_MAXK];
+    float *dWs, *dbs;
+};
+
+// wave-wide sum / max over all 64 lanes
+__device__ static inline float gs_wsum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ static inline float gs_wmax(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// grid (K, Di/64), 1024 threads.
+// Every workgroup: the fixed-order merge of the pooling partials for 64 features of one branch (same arithmetic and order as
+// ga_merge_kernel, ga_forward.hip), branch statistics from the c == 0 workgroups.  The workgroup that arrives last (which one
+// does not matter: everything below is a function of completed global data, summed in index order) finishes the step's
+// small work with 16 waves instead of six further launches.
+template <int KP>
+__global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[GA_MERGE_GROUPS][66];
+    __shared__ float smx[GA_MERGE_GROUPS];
+    __shared__ int is_last;
+    const int K = a.K, Di = a.Di, C = a.C, tiles = a.tiles;
+    const int k = blockIdx.x, c = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const size_t PS = 2 + Di;
+    {
+        const float* base = a.part + (size_t)k * PS;
+        const size_t tstride = (size_t)K * PS;
+        float m = -INFINITY;
+        for (int t = tid; t < tiles; t += 1024) m = fmaxf(m, base[t * tstride]);
+        m = gs_wmax(m);
+        if (lane == 0) smx[g] = m;
+        __syncthreads();
+        float M = smx[0];
+#pragma unroll
+        for (int w = 1; w < GA_MERGE_GROUPS; ++w) M = fmaxf(M, smx[w]);
+        float acc = 0.0f, l = 0.0f;
+        const int di = 64 * c + lane;
+        for (int t0 = g; t0 < tiles; t0 += 4 * GA_MERGE_GROUPS) {
+            float pm[4], pl[4], pa[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * GA_MERGE_GROUPS;
+                const float* p = base + (size_t)(t < tiles ? t : t0) * tstride;
+                pm[u] = p[0]; pl[u] = p[1]; pa[u] = p[2 + di];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (t0 + u * GA_MERGE_GROUPS < tiles) {
+                    const float f = __expf(pm[u] - M);
+                    l = fmaf(f, pl[u], l);
+                    acc = fmaf(f, pa[u], acc);
+                }
+            }
+        }
+        red[g][lane] = acc;
+        if (lane == 0) red[g][64] = l;
+        __syncthreads();
+        if (g == 0) {
+            float A = 0.0f, Ls = 0.0f;
+#pragma unroll
+            for (int w = 0; w < GA_MERGE_GROUPS; ++w) { A += red[w][lane]; Ls += red[w][64]; }
+            a.afeat[(size_t)k * Di + di] = A / Ls;
+            if (a.stats && c == 0 && lane == 0) { a.stats[2 * k] = M; a.stats[2 * k + 1] = Ls; }
+            __threadfence();                       // release this workgroup's outputs before it counts itself
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(a.arrive, 1u);
+        is_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
+        if (is_last) atomicExch(a.arrive, 0u);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                               // acquire the other workgroups' afeat / stats
+
+    // ------------------------------------------------------------------ tail (one workgroup, 16 waves)
+    float* af = (float*)smem;                      // [K][Di]
+    float* bf = af + (size_t)K * Di;               // [Di]   bag feature = mean_k afeat
+    float* lsub = bf + Di;                         // [K*C]  branch logits
+    float* lslide = lsub + GS_MAXK * ACMIL_MAX_CLASSES;   // [C]
+    float* dsub = lslide + ACMIL_MAX_CLASSES;      // [K*C]
+    float* dslide = dsub + GS_MAXK * ACMIL_MAX_CLASSES;   // [C]
+    float* S = dslide + ACMIL_MAX_CLASSES;         // [KP*KP] Gram of the softmax rows
+    float* sc = S + 64;                            // scalars: [0..K) per-branch CE, [8] bag CE, [16 + 2k] M_k, [17 + 2k] L_k
+    const float invK = 1.0f / (float)K;
+    for (int e = tid; e < K * Di; e += 1024) af[e] = __builtin_nontemporal_load(a.afeat + e);
+    __syncthreads();
+    for (int di = tid; di < Di; di += 1024) {
+        float s = 0.0f;
+        for (int kk = 0; kk < K; ++kk) s += af[kk * Di + di];
+        bf[di] = s / (float)K;
+    }
+    __syncthreads();
+    // heads (ga_heads_kernel's arithmetic): one wave per output, lanes stride the Di-long dot product
+    {
+        const float* wc = (const float*)(a.packed + a.L.wc_off);
+        const float* bc = (const float*)(a.packed + a.L.bc_off);
+        const float* ws = (const float*)(a.packed + a.L.ws_off);
+        const float* bs = (const float*)(a.packed + a.L.bs_off);
+        const int nout = K * C + (a.has_bag_head ? C : 0);
+        for (int o = g; o < nout; o += 16) {
+            const float* w; const float* v; float b;
+            if (o < K * C) { w = wc + (size_t)o * Di; v = af + (size_t)(o / C) * Di; b = bc[o]; }
+            else { w = ws + (size_t)(o - K * C) * Di; v = bf; b = bs[o - K * C]; }
+            float s = 0.0f;
+            for (int di = lane; di < Di; di += 64) s = fmaf(w[di], v[di], s);
+            s = gs_wsum(s) + b;
+            if (lane == 0) {
+                if (o < K * C) { lsub[o] = s; if (a.sub_preds) a.sub_preds[o] = s; }
+                else { lslide[o - K * C] = s; if (a.slide_pred) a.slide_pred[o - K * C] = s; }
+            }
+        }
+    }
+    if (!a.label) return;
+    // softmax statistics of every branch (written by the c == 0 workgroups)
+    if (tid < 2 * K) sc[16 + tid] = __builtin_nontemporal_load(a.stats + tid);
+    __syncthreads();
+    // Gram of the softmax rows from the tile partials: S_ij = sum_t g_t[i][j] f_i(t) f_j(t), f_k(t) = exp(m_t,k - M_k) / L_k
+    for (int e = g; e < KP * KP; e += 16) {
+        const int i = e / KP, j = e % KP;
+        float s = 0.0f;
+        if (i <= j && j < K) {
+            const float Mi = sc[16 + 2 * i], Mj = sc[16 + 2 * j], iLi = 1.0f / sc[17 + 2 * i], iLj = 1.0f / sc[17 + 2 * j];
+            for (int t = lane; t < tiles; t += 64) {
+                const float* rec = a.part + (size_t)t * K * PS;
+                const float fi = __expf(rec[(size_t)i * PS] - Mi) * iLi, fj = __expf(rec[(size_t)j * PS] - Mj) * iLj;
+                s = fmaf(a.gram_part[(size_t)t * KP * KP + e], fi * fj, s);
+            }
+            s = gs_wsum(s);
+        }
+        if (lane == 0) S[e] = s;
+    }
+    // cross entropies: wave kk < K = branch kk, wave K = bag head; lane = class
+    const int y = (int)a.label[0];
+    if (g <= K && (g < K || a.has_bag_head)) {
+        const float* r = g < K ? lsub + g * C : lslide;
+        const float v = lane < C ? r[lane] : -INFINITY;
+        const float mx = gs_wmax(v);
+        const float se = gs_wsum(lane < C ? expf(v - mx) : 0.0f);
+        const float lse = mx + logf(se);
+        const float dl = lane < C ? expf(v - lse) - (lane == y ? 1.0f : 0.0f) : 0.0f;
+        if (g < K) {
+            const float d = (K > 1) ? dl * invK : 0.0f;
+            if (lane < C) { dsub[g * C + lane] = d; a.d_sub[g * C + lane] = d; }
+            if (lane == 0) sc[g] = lse - r[y];
+        } else {
+            if (lane < C) { dslide[lane] = dl; a.d_slide[lane] = dl; }
+            if (lane == 0) sc[8] = lse - r[y];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float loss0 = 0.0f;
+        for (int kk = 0; kk < K; ++kk) loss0 += sc[kk];
+        loss0 = (K > 1) ? loss0 * invK : 0.0f;
+        const float loss1 = a.has_bag_head ? sc[8] : 0.0f;
+        // diversity loss and the coefficient table of its gradient (ga_loss.hip, gl_scalar_kernel):
+        // coef[i][j] (i != j) = c / (n_i n_j) ; coef[i][i] = -c * sum_{j != i} S_ij / (n_i^3 n_j)
+        float diff = 0.0f;
+        const float cpair = (K > 1) ? 2.0f / (float)(K * (K - 1)) : 0.0f;
+        float nrm[KP];
+        for (int i = 0; i < KP; ++i) nrm[i] = i < K ? sqrtf(S[i * KP + i]) : 1.0f;
+        for (int i = 0; i < KP; ++i)
+            for (int j = 0; j < KP; ++j) a.coef[i * KP + j] = 0.0f;
+        for (int i = 0; i < K; ++i) {
+            float dsum = 0.0f;
+            for (int j = 0; j < K; ++j) {
+                if (j == i) continue;
+                const float sij = S[(i < j ? i : j) * KP + (i < j ? j : i)];
+                const float den = fmaxf(nrm[i] * nrm[j], 1e-8f);          // torch.cosine_similarity eps
+                if (i < j) diff += cpair * sij / den;
+                a.coef[i * KP + j] = cpair / den;
+                dsum += sij / (nrm[i] * nrm[i] * den);
+            }
+            a.coef[i * KP + i] = -cpair * dsum;
+        }
+        a.losses[0] = loss0; a.losses[1] = loss1; a.losses[2] = diff; a.losses[3] = loss0 + loss1 + diff;
+    }
+    // head gradients, d_afeat and c_k = d_afeat_k . afeat_k   (ga_bwd_heads_kernel's arithmetic)
+    {
+        const float* wc = (const float*)(a.packed + a.L.wc_off);
+        const float* ws = (const float*)(a.packed + a.L.ws_off);
+        for (int kk = 0; kk < K; ++kk) {
+            float cpart = 0.0f;
+            for (int di = tid; di < Di; di += 1024) {
+                float s = 0.0f;
+                for (int cc = 0; cc < C; ++cc) s = fmaf(wc[((size_t)kk * C + cc) * Di + di], dsub[kk * C + cc], s);
+                if (a.has_bag_head)
+                    for (int cc = 0; cc < C; ++cc) s = fmaf(ws[(size_t)cc * Di + di] * invK, dslide[cc], s);
+                a.d_afeat[(size_t)kk * Di + di] = s;
+                const float afv = af[kk * Di + di];
+                cpart = fmaf(s, afv, cpart);
+                for (int cc = 0; cc < C; ++cc) a.dWc[kk][(size_t)cc * Di + di] = dsub[kk * C + cc] * afv;
+            }
+            cpart = gs_wsum(cpart);
+            __syncthreads();
+            if (lane == 0) smx[g] = cpart;
+            __syncthreads();
+            if (tid == 0) {
+                float s = 0.0f;
+                for (int w = 0; w < 16; ++w) s += smx[w];
+                a.ck[kk] = s;
+            }
+            if (tid < C) a.dbc[kk][tid] = dsub[kk * C + tid];
+        }
+        if (a.has_bag_head) {
+            for (int di = tid; di < Di; di += 1024)
+                for (int cc = 0; cc < C; ++cc) a.dWs[(size_t)cc * Di + di] = dslide[cc] * bf[di];
+            if (tid < C) a.dbs[tid] = dslide[tid];
+        }
+    }
+}
+
+static size_t gs_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct GsWs { size_t part, h, gram, coef, dsub, dslide, afeat, cand, bwd, total; };
+
+static GsWs gs_layout(int N, int D, int Di, int K, int C, int k_top) {
+    GsWs w; size_t off = GA_CTRL_BYTES;
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    w.part = off;   off += gs_align(acmil_ga_workspace_bytes(N, D, Di, K, C, ACMIL_MODE_F16X3) - GA_CTRL_BYTES);
+    w.h = off;      off += gs_align((size_t)N * Di * 4);
+    w.gram = off;   off += gs_align((size_t)ga_pool_tiles(N) * KP * KP * 4);
+    w.coef = off;   off += 256;
+    w.dsub = off;   off += gs_align((size_t)K * C * 4);
+    w.dslide = off; off += 256;
+    w.afeat = off;  off += gs_align((size_t)K * Di * 4);
+    const size_t nch = (size_t)(N + 4095) / 4096;
+    w.cand = off;   off += gs_align((size_t)K * nch * (k_top > 0 ? k_top : 1) * 8);
+    w.bwd = off;    off += gs_align(acmil_ga_backward_workspace_bytes(N, D, Di, K, C));
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int K, int C, int k_top) {
+    if (N <= 0 || D <= 0 || Di <= 0 || K <= 0 || C <= 0 || k_top < 0) return 0;
+    return gs_layout(N, D, Di, K, C, k_top).total;
+}
+
+extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int repack,
+                                   const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                   const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                                   const float* Ws, const float* bs,
+                                   float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                                   float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                                   int D, int Di, int Da, int K, int C, int mode,
+                                   const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                                   float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                                   int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (N <= 0 || k_top < 0 || k_top > 64 || k_top > N || m_mask < 0 || m_mask > k_top) return ACMIL_ERR_SHAPE;
+    if (mode != ACMIL_MODE_F32 && mode != ACMIL_MODE_F16X3 && mode != ACMIL_MODE_F16) return ACMIL_ERR_UNSUPPORTED;
+    if (!x || !packed || !W1 || !Wv || !bv || !Wu || !bu || !Ww || !bw || !Wc || !bc || !label || !workspace) return ACMIL_ERR_NULL;
+    if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc || !losses || !sub_preds || !A_out) return ACMIL_ERR_NULL;
+    const int has_bag_head = Ws != nullptr;
+    if (has_bag_head && (!bs || !dWs || !dbs || !slide_pred)) return ACMIL_ERR_NULL;
+    if (k_top > 0 && (!topk_idx || (m_mask > 0 && (!uniforms || !masked_idx)))) return ACMIL_ERR_NULL;
+    for (int k = 0; k < K; ++k)
+        if (!Wc[k] || !bc[k] || !dWc[k] || !dbc[k]) return ACMIL_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const GsWs W = gs_layout(N, D, Di, K, C, k_top);
+    unsigned* ctrl = (unsigned*)ws;
+    float* h = (float*)(ws + W.h);
+    float* part = (float*)(ws + W.part);
+    float* gram = (float*)(ws + W.gram);
+    float* afeat = (float*)(ws + W.afeat);
+    float* coef = (float*)(ws + W.coef);
+    char* bws = ws + W.bwd;
+    const GbWs BL = gb_layout(N, D, Di, K);
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+
+    // 1 pack  2 score pass (the control block sits at the start of this workspace: tile counter, range status)
+    if (repack) {
+        rc = acmil_ga_pack_weights(W1, Wv, bv, Wu, bu, Ww, bw, Wc, bc, Ws, bs, D, Di, Da, K, C, mode, packed, stream);
+        if (rc != ACMIL_OK) return rc;
+    }
+    rc = acmil_ga_forward(x, x_dtype, N, packed, D, Di, Da, K, C, mode, A_out, nullptr, nullptr, nullptr, nullptr, h, has_bag_head,
+                          workspace, stream);
+    if (rc != ACMIL_OK) return rc;
+    // 3 STKIM + mask
+    if (k_top > 0) {
+        rc = stkim_launch(A_out, m_mask > 0 ? A_out : nullptr, N, K, k_top, m_mask, uniforms, topk_idx, masked_idx,
+                          (unsigned long long*)(ws + W.cand), ctrl + 4, st);
+        if (rc != ACMIL_OK) return rc;
+    }
+    // 4 pooling tiles + Gram partials
+    rc = ga_pool_launch(h, A_out, N, K, Di, part, gram, st);
+    if (rc != ACMIL_OK) return rc;
+    // 5 tail
+    GaTailArgs t;
+    t.part = part; t.tiles = ga_pool_tiles(N); t.K = K; t.Di = Di; t.C = C; t.KP = KP;
+    t.afeat = afeat; t.arrive = ctrl + 5; t.packed = (const char*)packed; t.L = ga_layout(D, Di, K, C, mode); t.has_bag_head = has_bag_head;
+    t.sub_preds = sub_preds; t.slide_pred = slide_pred; t.label = label; t.gram_part = gram;
+    t.stats = (float*)(bws + BL.stats); t.losses = losses; t.d_sub = (float*)(ws + W.dsub); t.d_slide = (float*)(ws + W.dslide);
+    t.coef = coef; t.d_afeat = (float*)(bws + BL.d_afeat); t.ck = (float*)(bws + BL.ck);
+    for (int k = 0; k < GS_MAXK; ++k) { t.dWc[k] = k < K ? dWc[k] : nullptr; t.dbc[k] = k < K ? dbc[k] : nullptr; }
+    t.dWs = dWs; t.dbs = dbs;
+    const size_t lds = ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64) * sizeof(float);
+    void (*tail)(GaTailArgs) = KP == 1 ? ga_tail_kernel<1> : KP == 5 ? ga_tail_kernel<5> : nullptr;
+    if (!tail) return ACMIL_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(tail, dim3(K, Di / 64), dim3(1024), lds, st, t);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    // 6-11 backward
+    GbRun r;
+    r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
+    r.Wcat = (const float*)((const char*)packed + t.L.wcat_off); r.bcat = (const float*)((const char*)packed + t.L.bcat_off);
+    r.dA_ext = nullptr; r.coef = (K > 1) ? coef : nullptr; r.d_afeat = t.d_afeat; r.ck = t.ck; r.stats = t.stats;
+    r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
+    r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = bws; r.st = st;
+    return gb_run(r);
+}

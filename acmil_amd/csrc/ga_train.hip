@@ -19,20 +19,65 @@ __device__ static inline unsigned long long stkim_key(float v, unsigned idx) {
     return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
 }
 
-__device__ static inline unsigned long long block_max_key(unsigned long long key, unsigned long long* red) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const unsigned long long other = __shfl_xor(key, o);
-        key = other > key ? other : key;
-    }
+// max of a 64-bit key over the wave with DPP row operations (no LDS round trips): row_shr 1,2,4,8 leave each row's max in its
+// lane 15, row_bcast15 / row_bcast31 carry it across the rows into lane 63.  Lanes a DPP step has no source for keep their own
+// value (old = self), which is harmless for a max.
+template <int CTRL, int ROW_MASK>
+__device__ static inline unsigned long long stkim_dpp_max(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned lo2 = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi2 = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi2 << 32) | lo2;
+    return o > v ? o : v;
+}
+__device__ static inline unsigned long long wave_max_key(unsigned long long v) {
+    v = stkim_dpp_max<0x111, 0xf>(v);
+    v = stkim_dpp_max<0x112, 0xf>(v);
+    v = stkim_dpp_max<0x114, 0xf>(v);
+    v = stkim_dpp_max<0x118, 0xf>(v);
+    v = stkim_dpp_max<0x142, 0xa>(v);
+    v = stkim_dpp_max<0x143, 0xc>(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// block-wide max: wave maxima through a double-buffered LDS row (ONE barrier per call; `round` alternates the row)
+__device__ static inline unsigned long long block_max_key(unsigned long long key, unsigned long long (*red)[4], int round) {
+    const unsigned long long wm = wave_max_key(key);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* row = red[round & 1];
+    if (lane == 0) row[wave] = wm;
     __syncthreads();
-    if (lane == 0) red[wave] = key;
-    __syncthreads();
-    unsigned long long m = red[0];
+    unsigned long long m = row[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+    for (int w = 1; w < 4; ++w) m = row[w] > m ? row[w] : m;
     return m;
+}
+
+// merge of one branch's candidates by one wave: E keys per lane, k rounds of wave-wide max
+template <int E>
+__device__ static inline void stkim_merge_wave(const unsigned long long* __restrict__ c, int ncand, int k, int lane, unsigned* sel,
+                                               int64_t* __restrict__ topk_row) {
+    unsigned long long keys[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        keys[e] = i < ncand ? __builtin_nontemporal_load(c + i) : 0ull;
+    }
+    for (int j = 0; j < k; ++j) {
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int e = 0; e < E; ++e) best = keys[e] > best ? keys[e] : best;
+        best = wave_max_key(best);
+        if (lane == 0) {
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+            sel[j] = idx;
+            topk_row[j] = (int64_t)idx;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (keys[e] == best) keys[e] = 0ull;      // keys are unique (index in the low word); 0 = taken / padding
+    }
 }
 
 // Single launch, grid (nchunks, K):
@@ -46,7 +91,7 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
                                                           int k, int m, const float* __restrict__ uniforms,
                                                           unsigned long long* __restrict__ cand, unsigned* __restrict__ arrive,
                                                           int64_t* __restrict__ topk_idx, int64_t* __restrict__ masked_idx) {
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[2][4];
     __shared__ unsigned sel[4][64];
     __shared__ int is_last;
     const int chunk = blockIdx.x, br = blockIdx.y, nch = gridDim.x;
@@ -64,11 +109,11 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
             unsigned long long best = 0ull;
 #pragma unroll
             for (int e = 0; e < STKIM_EPT; ++e) best = keys[e] > best ? keys[e] : best;
-            const unsigned long long win = block_max_key(best, red);
+            const unsigned long long win = block_max_key(best, red, j);
             if (tid == 0) out[j] = win;
 #pragma unroll
             for (int e = 0; e < STKIM_EPT; ++e)
-                if (keys[e] == win) keys[e] = 0ull;  // keys are unique (index in the low word); 0 = taken / padding
+                if (keys[e] == win) keys[e] = 0ull;  // 0 = taken / padding
         }
     }
     // release the candidates, count this block, the last one acquires everybody's
@@ -83,30 +128,12 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     const int ncand = nch * k;
     for (int b = wave; b < K; b += 4) {
         const unsigned long long* c = cand + (size_t)b * ncand;
-        unsigned long long keys[STKIM_MERGE_E];
-#pragma unroll
-        for (int e = 0; e < STKIM_MERGE_E; ++e) {
-            const int i = e * 64 + lane;
-            keys[e] = i < ncand ? __builtin_nontemporal_load(c + i) : 0ull;
-        }
-        for (int j = 0; j < k; ++j) {
-            unsigned long long best = 0ull;
-#pragma unroll
-            for (int e = 0; e < STKIM_MERGE_E; ++e) best = keys[e] > best ? keys[e] : best;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const unsigned long long other = __shfl_xor(best, o);
-                best = other > best ? other : best;
-            }
-            if (lane == 0) {
-                const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
-                sel[wave][j] = idx;
-                topk_idx[(size_t)b * k + j] = (int64_t)idx;
-            }
-#pragma unroll
-            for (int e = 0; e < STKIM_MERGE_E; ++e)
-                if (keys[e] == best) keys[e] = 0ull;
-        }
+        int64_t* trow = topk_idx + (size_t)b * k;
+        if (ncand <= 64) stkim_merge_wave<1>(c, ncand, k, lane, sel[wave], trow);
+        else if (ncand <= 128) stkim_merge_wave<2>(c, ncand, k, lane, sel[wave], trow);
+        else if (ncand <= 256) stkim_merge_wave<4>(c, ncand, k, lane, sel[wave], trow);
+        else if (ncand <= 512) stkim_merge_wave<8>(c, ncand, k, lane, sel[wave], trow);
+        else stkim_merge_wave<STKIM_MERGE_E>(c, ncand, k, lane, sel[wave], trow);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // sel[] written by lane 0 is visible to the wave
         if (lane < k && m > 0) {

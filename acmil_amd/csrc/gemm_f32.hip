@@ -395,8 +395,9 @@ __device__ __forceinline__ void gm_reduce_body(const GemmArgs& g, int nbatch, in
         for (; sp < g.splits; ++sp) s += src[(long long)sp * per];             // fixed order
         const int row = r / g.N, col = r % g.N;
         float v = g.alpha * s + (g.bias ? g.bias[col] : 0.0f);
-        const long long idx = (long long)row * g.ldc + col;
+        long long idx = (long long)row * g.ldc + col;
         float* dst = g.C + (long long)b * g.sC + idx;
+        if (g.C2 && row >= g.split_row) { idx = (long long)(row - g.split_row) * g.ldc + col; dst = g.C2 + idx; }
         if (g.act == 3) { *dst = (row == col ? g.beta : 0.0f) - g.alpha * s; continue; }
         if (g.act == 4) { *dst = g.alpha * s; const_cast<float*>(g.aux)[(long long)b * g.sC + idx] = (row == col ? g.beta : 0.0f) - g.alpha * s; continue; }
         if (g.beta != 0.0f) v += g.beta * *dst;
@@ -460,6 +461,7 @@ static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alp
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.transA = transA; g.transB = transB; g.b_dtype = b_dtype; g.act = act; g.alpha = alpha; g.beta = beta;
+    g.C2 = nullptr; g.split_row = 0;
     g.splits = gm_pick_splits(M, N, K, batch);
     if (g.splits > 1 && !workspace) return ACMIL_ERR_NULL;
     const int ktiles = (K + GM_BK - 1) / GM_BK;

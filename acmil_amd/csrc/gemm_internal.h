@@ -9,6 +9,7 @@ struct GemmArgs {
     long long sA, sB, sC;   // batch strides (elements)
     int transA, transB, b_dtype, act, splits, kchunk;
     float alpha, beta;
+    float* C2; int split_row;   // deferred split-K products only: rows >= split_row go to C2 (row - split_row); C2 null: one destination
 };
 
 // sum `records` partial records of `len` floats (record r at part + r * stride) in a fixed order; element e goes to the
@@ -24,4 +25,5 @@ struct RowSumJob {
 int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B,
                       int b_dtype, int ldb, float beta, float* C, int ldc, const float* bias, int act, const float* aux,
                       void* workspace, hipStream_t stream, GemmArgs* out);
+// (set out->C2 / out->split_row after the call to scatter the reduced rows over two tensors, e.g. [dWv; dWu])
 int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hipStream_t stream);

@@ -301,6 +301,39 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
     return grads
 
 
+def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
+                  grads: Sequence[torch.Tensor], label: torch.Tensor, uniforms: Optional[torch.Tensor], k_top: int, m_mask: int,
+                  repack: bool = True):
+    """acmil_ga_train_step: forward with STKIM masking + ACMIL loss + backward of one slide, enqueued by ONE library call.
+    params / grads = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0.., bc_0.., (Ws, bs)] (gradients are overwritten).
+    Returns a dict: losses [4] (loss0, loss1, diff, total), sub_preds [K,C], slide_pred [C] or None, A_out [K,N] (masked raw
+    scores), topk_idx, masked_idx, range_status (device int32 view, see _range_status)."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _check_x(x, dims)
+    K, Cc = dims.K, dims.C
+    N, dev = x.shape[0], x.device
+    fbuf = torch.empty(4 + K * Cc + Cc + K * N, dtype=torch.float32, device=dev)
+    losses, sub, slide, A = fbuf[:4], fbuf[4:4 + K * Cc].view(K, Cc), fbuf[4 + K * Cc:4 + K * Cc + Cc], fbuf[4 + K * Cc + Cc:].view(K, N)
+    ibuf = torch.empty(K * (k_top + m_mask) + 1, dtype=torch.int64, device=dev)
+    topk, midx = ibuf[:K * k_top].view(K, k_top), ibuf[K * k_top:K * (k_top + m_mask)].view(K, m_mask)
+    ws = _ws_bytes(lib.acmil_ga_train_step_workspace_bytes(N, dims.D, dims.Di, K, Cc, k_top), dev)
+    pp = [p.data_ptr() for p in params]
+    gp = [g.data_ptr() for g in grads]
+    vpK = ctypes.c_void_p * K
+    has_bag = dims.has_bag_head
+    rc = lib.acmil_ga_train_step(
+        x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), int(repack),
+        *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
+        *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
+        *dims.args(), mode, label.data_ptr(), _ptr(uniforms) if m_mask > 0 else None, k_top, m_mask,
+        losses.data_ptr(), sub.data_ptr(), slide.data_ptr() if has_bag else None, A.data_ptr(),
+        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_train_step")
+    return {"losses": losses, "sub_preds": sub, "slide_pred": slide if has_bag else None, "A_out": A,
+            "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
+
+
 def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int, debug: bool = False) -> Dict[str, torch.Tensor]:
     """acmil_transmil_forward.  x [N,D] fp32 CUDA; sd: parameters under the reference's state_dict names
     (fp32, CUDA, contiguous).  Returns {'logits': [C]} plus 'h1','hp','h2' [(side^2+1), Di] when debug."""

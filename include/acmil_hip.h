@@ -83,7 +83,12 @@ int acmil_ga_pack_weights(const float* W1, const float* Wv, const float* bv, con
  *   h_save [N,Di] fp32 (kept for the masked pooling pass and the backward of a training step).
  * If sub_preds, slide_pred, afeat and bag_feat are all NULL only the scores (and h_save) are produced.
  * ABMIL = K 1, has_bag_head 0: its logits are sub_preds[0].
- * workspace: acmil_ga_workspace_bytes(...) bytes, 256-byte aligned (may be NULL for a scores-only call).
+ * workspace: acmil_ga_workspace_bytes(...) bytes, 256-byte aligned (may be NULL for a scores-only call).  The FIRST 256
+ *   bytes of every GA workspace (acmil_ga_forward / _forward_batch / _pool / _train_step) are a control block of 32-bit words:
+ *   0 tile counter, 1 range status of the most recent split-f16 launch (0 = every bag value and projected feature was inside
+ *   the f16 range; bit 0: a bag value, bit 1: a feature was out of range or not finite -- repeat the call with
+ *   ACMIL_MODE_F32), 2.. internal counters.  Zero the block ONCE after allocating the workspace (hipMemset); every launch
+ *   leaves its counters at zero, so no memset is needed between launches.  One workspace serves one stream.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
 
@@ -177,6 +182,35 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
                       const float* d_A, float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw,
                       float* dbw, float* const* dWc, float* const* dbc, float* dWs, float* dbs, int D, int Di, int Da,
                       int K, int C, int mode, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * One ACMIL_GA training step for one slide in ONE call: forward with STKIM masking (architecture/transformer.py:305-330,
+ * training branch), the ACMIL loss (Step3_WSI_classification_ACMIL.py:201-216) and the backward through both (what
+ * loss.backward() computes, Step3_WSI_classification_ACMIL.py:217-218) -- 11 launches enqueued by one host call.
+ *   packed   acmil_ga_packed_bytes(...) device buffer; rewritten from the raw parameters when repack != 0 (call with
+ *            repack = 1 whenever the parameters changed since the last step, e.g. after every optimizer step)
+ *   W*, b*   raw fp32 parameters (as acmil_ga_pack_weights); d*: their gradients, OVERWRITTEN (not accumulated).
+ *            [dWv; dWu] / [Wv; Wu] adjacent in memory (flat buckets) are used in place
+ *   label    [1] int64 on the device; uniforms [K, k_top] fp32 (the torch.rand draw of transformer.py:314), may be
+ *            NULL when m_mask == 0; k_top = min(n_masked_patch, N), m_mask = int(k_top * mask_drop); k_top = 0: no masking
+ *   outputs  losses [4] = {loss0, loss1, diff_loss, total}; sub_preds [K,C]; slide_pred [C]; A_out [K,N] = the masked
+ *            raw scores the reference returns as `attn`; topk_idx [K,k_top], masked_idx [K,m_mask] int64
+ *   workspace acmil_ga_train_step_workspace_bytes(...) bytes.  Its first 256 bytes are the GA control block: zero them once
+ *            after allocation; word 1 (int32) is the split-f16 range status of this step (0 = in range; otherwise the
+ *            caller repeats the step with mode = ACMIL_MODE_F32).
+ * ------------------------------------------------------------------------------------------- */
+size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int K, int C, int k_top);
+
+int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int repack,
+                        const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                        const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                        const float* Ws, const float* bs,
+                        float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                        float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                        int D, int Di, int Da, int K, int C, int mode,
+                        const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                        float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                        int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216

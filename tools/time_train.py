@@ -1,5 +1,5 @@
-"""Same-process A/B of the fused training step's host-side options (run through gpurun): range guard off / read at the
-end of the step / read right after the score pass.  Prints ms per step (median of rounds) for each."""
+"""Same-process A/B of the training step's host-side options (run through gpurun): the one-call step (csrc/ga_step.hip)
+with and without the range-guard read-back, and the op-by-op step.  Prints ms per step (median of rounds) for each."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -36,8 +36,9 @@ def timeit(steps=200):
 
 res = {}
 for rnd in range(3):
-    for name, guard, defer in (("off", False, True), ("deferred", True, True), ("immediate", True, False)):
-        model.range_guard, model.guard_deferred = guard, defer
+    for name, guard, fused in (("one-call", True, True), ("one-call/noguard", False, True), ("op-by-op", True, False),
+                               ("op-by-op/noguard", False, False)):
+        model.range_guard, model.fused_step = guard, fused
         res.setdefault(name, []).append(timeit())
 for k, v in res.items():
-    print("%-10s ms/step %s  median %.4f" % (k, ["%.4f" % t for t in v], sorted(v)[1]))
+    print("%-18s ms/step %s  median %.4f" % (k, ["%.4f" % t for t in v], sorted(v)[1]))
