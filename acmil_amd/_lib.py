@@ -71,7 +71,8 @@ SIGNATURES = {
     "acmil_colsum": (_i, [_vp, C.c_longlong, _i, _vp, _vp, _vp]),
     "acmil_gate_fwd": (_i, [_vp, _vp, C.c_longlong, _i, _vp]),
     "acmil_gate_bwd": (_i, [_vp, _vp, _vp, C.c_longlong, _i, _vp]),
-    "acmil_adamw_step": (_i, [_vp, _vp, _vp, _vp, C.c_longlong] + [C.c_float] * 7 + [_vp]),
+    "acmil_adamw_step": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float,
+                              C.c_longlong, _vp, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),
@@ -82,9 +83,9 @@ SIGNATURES = {
                           [C.POINTER(_vp), C.POINTER(_vp)] + [_vp, _vp] + [_i] * 6 + [_vp, _vp]),
     "acmil_ga_train_step_workspace_bytes": (_sz, [_i] * 6),
     # x, x_dtype, N, packed, repack | W1 Wv bv Wu bu Ww bw Wc[] bc[] Ws bs | dW1 dWv dbv dWu dbu dWw dbw dWc[] dbc[] dWs dbs |
-    # D Di Da K C mode | label uniforms k_top m_mask | losses sub slide A_out topk midx | workspace stream
+    # D Di Da K C mode | label uniforms k_top m_mask | losses sub slide A_out topk midx guard_flag | workspace stream
     "acmil_ga_train_step": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
-                            [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 6 + [_vp, _vp]),
+                            [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp]),
 }
 
 _lib = None

@@ -278,12 +278,18 @@ class ACMIL_GA(_GatedBase):
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
 
     @torch.no_grad()
-    def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None):
+    def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None, guard_flag: Optional[torch.Tensor] = None,
+                   precision: Optional[str] = None):
         """One fused training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), fused ACMIL loss
         (acmil_ga_loss) and HIP backward, writing the gradients into `p.grad` (allocated on first use, overwritten).
         Same mathematics as `loss = diff + loss0 + loss1; loss.backward()` of the reference's train_one_epoch
         (Step3_WSI_classification_ACMIL.py:200-219); the optimiser step stays with the caller.
-        x [1,N,D_feat], label [1] int64 on the GPU.  Returns (losses [4] = loss0, loss1, diff_loss, total, on device; outputs dict)."""
+        x [1,N,D_feat], label [1] int64 on the GPU.  Returns (losses [4] = loss0, loss1, diff_loss, total, on device; outputs dict).
+        Range guard of the split-f16 arithmetic: by default the step's status word is read after the call (one
+        synchronisation) and a flagged step is repeated in fp32 before it returns.  guard_flag (a device float, e.g.
+        FlatAdamW.guard_flag): no read-back at all -- the step leaves 1.0 / 0.0 there for the optimizer launch to act on
+        (it skips a flagged step; train.train_one_epoch repeats the bag in fp32 two steps later).  precision overrides the
+        module's arithmetic for this call ("fp32": the repeat)."""
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
@@ -294,33 +300,38 @@ class ACMIL_GA(_GatedBase):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
         if self._is_fused() and getattr(self, "fused_step", True):
-            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top)
+            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision)
         else:
+            if precision is not None and precision != self.precision:
+                raise NotImplementedError("acmil_amd: per-call precision is a feature of the one-call step")
+            if guard_flag is not None:
+                guard_flag.zero_()          # the op-by-op step resolves the guard itself, before it returns
             losses, out = self._train_step_composed(xb, label, uniforms, params, masking)
         self._last = out
         return losses, out
 
-    def _train_step_fused(self, xb, label, uniforms, params, k_top):
+    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None):
         """The whole step enqueued by one library call (csrc/ga_step.hip: 11 launches).  The packed weights are rebuilt inside
         the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
         after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
         dev = xb.device
         m_mask = int(k_top * self.mask_drop)
         grads = [p.grad for p in params]
-        dets = [p.detach() for p in params]
-        label = label.to(torch.int64)
+        if label.dtype != torch.int64:
+            label = label.to(torch.int64)
 
         def run(precision):
-            mode = ops.mode_id(precision)
-            st = getattr(self, "_step_packed", None)
-            if st is None or st[0] != (mode, dev):
+            cache = self.__dict__.setdefault("_step_packed", {})
+            st = cache.get((precision, dev))
+            if st is None:
                 packed, dims = self._packed(precision) if precision != self.precision else self._packed()
-                st = ((mode, dev), packed.clone(), dims)         # a private buffer: the call rewrites it every step
-                self._step_packed = st
-            return ops.ga_train_step(xb, st[1], st[2], precision, dets, grads, label, uniforms, k_top, m_mask, repack=True)
+                st = cache[(precision, dev)] = (packed.clone(), dims)      # a private buffer: the call rewrites it every step
+            return ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=True,
+                                     guard_flag=guard_flag)
 
-        out = run(self.precision)
-        if self.precision == "f16x3" and self._out_of_range(out["range_status"]):
+        prec = precision or self.precision
+        out = run(prec)
+        if guard_flag is None and prec == "f16x3" and self._out_of_range(out["range_status"]):
             out = run("fp32")
             out["range_fallback"] = True
         return out["losses"], out

@@ -40,6 +40,7 @@ struct GaTailArgs {
     float *stats, *losses, *d_sub, *d_slide, *coef, *d_afeat, *ck;
     float* dWc[GS_MAXK]; float* dbc[GS_MAXK];
     float *dWs, *dbs;
+    const unsigned* status; float* guard_flag;    // range status of the score pass (control block word 1) -> 0 / 1 float flag
 };
 
 // wave-wide sum / max over all 64 lanes
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     float* S = dslide + ACMIL_MAX_CLASSES;         // [KP*KP] Gram of the softmax rows
     float* sc = S + 64;                            // scalars: [0..K) per-branch CE, [8] bag CE, [16 + 2k] M_k, [17 + 2k] L_k
     const float invK = 1.0f / (float)K;
+    if (tid == 0 && a.guard_flag) *a.guard_flag = (a.status && __builtin_nontemporal_load(a.status) != 0u) ? 1.0f : 0.0f;
     for (int e = tid; e < K * Di; e += 1024) af[e] = __builtin_nontemporal_load(a.afeat + e);
     __syncthreads();
     for (int di = tid; di < Di; di += 1024) {
@@ -294,7 +296,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
                                    int D, int Di, int Da, int K, int C, int mode,
                                    const int64_t* label, const float* uniforms, int k_top, int m_mask,
                                    float* losses, float* sub_preds, float* slide_pred, float* A_out,
-                                   int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
+                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (N <= 0 || k_top < 0 || k_top > 64 || k_top > N || m_mask < 0 || m_mask > k_top) return ACMIL_ERR_SHAPE;
@@ -345,6 +347,8 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     t.coef = coef; t.d_afeat = (float*)(bws + BL.d_afeat); t.ck = (float*)(bws + BL.ck);
     for (int k = 0; k < GS_MAXK; ++k) { t.dWc[k] = k < K ? dWc[k] : nullptr; t.dbc[k] = k < K ? dbc[k] : nullptr; }
     t.dWs = dWs; t.dbs = dbs;
+    t.status = (mode == ACMIL_MODE_F16X3) ? ctrl + 1 : nullptr;      // only the split-f16 score pass reports a range status
+    t.guard_flag = guard_flag;
     const size_t lds = ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64) * sizeof(float);
     void (*tail)(GaTailArgs) = KP == 1 ? ga_tail_kernel<1> : KP == 5 ? ga_tail_kernel<5> : nullptr;
     if (!tail) return ACMIL_ERR_UNSUPPORTED;

@@ -3,12 +3,30 @@
 // 26 small tensors = 10 foreach launches, or 38 us in torch's fused variant); the training step is launch-bound at small
 // bags, and parameters / gradients / moments already live in flat buffers (slide-level DP all-reduces one flat bucket).
 //   p *= 1 - lr * wd ;  m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-// with bc1 = 1 - b1^t, bc2 = 1 - b2^t computed by the caller (the step count lives on the host).
+// with bc1 = 1 - b1^t, bc2 = 1 - b2^t formed on the device in double (t = the caller's launch ordinal minus the skipped launches).
 #include "ga_common.h"
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                        float wd, float inv_bc1, float inv_sqrt_bc2) {
+                                                        float* __restrict__ v, long long n, float lr, double beta1, double beta2, float eps,
+                                                        float wd, long long launch, const float* __restrict__ skip_flag,
+                                                        int* __restrict__ skipped) {
+    // device-side skip (like an AMP overflow skip): a non-zero / NaN flag -- the all-reduced range flag of a split-f16 training
+    // step, csrc/ga_step.hip -- leaves parameters and moments untouched and is counted in *skipped; the host learns about it
+    // later (optim.py).  The step number of the bias corrections is the launch ordinal minus the launches skipped so far, so
+    // the update stays torch.optim.AdamW's for the steps that are applied.
+    __shared__ float s_bc[2];
+    if (skip_flag && !(skip_flag[0] == 0.0f)) {
+        if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const long long t = launch - (skipped ? (long long)*skipped : 0);
+        s_bc[0] = (float)(1.0 / (1.0 - pow(beta1, (double)t)));
+        s_bc[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+    }
+    __syncthreads();
+    const float inv_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
+    const float b1 = (float)beta1, b2 = (float)beta2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float gi = g[i];
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -20,12 +38,12 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 }
 
 extern "C" int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                                float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
-                                float bias_correction2, void* stream) {
-    if (n <= 0 || bias_correction1 <= 0.0f || bias_correction2 <= 0.0f) return ACMIL_ERR_SHAPE;
+                                double beta1, double beta2, float eps, float weight_decay, long long step, const float* skip_flag,
+                                int* skipped, void* stream) {
+    if (n <= 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return ACMIL_ERR_SHAPE;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return ACMIL_ERR_NULL;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, weight_decay, 1.0f / bias_correction1, 1.0f / sqrtf(bias_correction2));
+                       beta1, beta2, eps, weight_decay, step, skip_flag, skipped);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

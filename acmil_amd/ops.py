@@ -303,11 +303,12 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
 
 def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
                   grads: Sequence[torch.Tensor], label: torch.Tensor, uniforms: Optional[torch.Tensor], k_top: int, m_mask: int,
-                  repack: bool = True):
+                  repack: bool = True, guard_flag: Optional[torch.Tensor] = None):
     """acmil_ga_train_step: forward with STKIM masking + ACMIL loss + backward of one slide, enqueued by ONE library call.
     params / grads = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0.., bc_0.., (Ws, bs)] (gradients are overwritten).
     Returns a dict: losses [4] (loss0, loss1, diff, total), sub_preds [K,C], slide_pred [C] or None, A_out [K,N] (masked raw
-    scores), topk_idx, masked_idx, range_status (device int32 view, see _range_status)."""
+    scores), topk_idx, masked_idx, range_status (device int32 view, see _range_status).
+    guard_flag: a device float the step writes 1.0 / 0.0 into (range status != 0) without any host read-back."""
     lib = _lib.load()
     mode = mode_id(mode)
     _check_x(x, dims)
@@ -328,7 +329,7 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
         *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
         *dims.args(), mode, label.data_ptr(), _ptr(uniforms) if m_mask > 0 else None, k_top, m_mask,
         losses.data_ptr(), sub.data_ptr(), slide.data_ptr() if has_bag else None, A.data_ptr(),
-        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, ws.data_ptr(), _stream())
+        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, _ptr(guard_flag), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_train_step")
     return {"losses": losses, "sub_preds": sub, "slide_pred": slide if has_bag else None, "A_out": A,
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}

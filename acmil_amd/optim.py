@@ -10,7 +10,8 @@ The parameters are re-pointed to views of one flat buffer (values preserved, `st
 from __future__ import annotations
 
 import math
-from typing import Callable, Iterable, Optional
+from collections import deque
+from typing import Callable, Iterable, List, Optional
 
 import torch
 
@@ -26,9 +27,18 @@ class FlatAdamW:
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.grad = grad_buffer if grad_buffer is not None else torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        if self.grad.numel() != self.numel:
+        # one extra slot behind the gradients = the step's range flag (written by acmil_ga_train_step, all-reduced together with
+        # the gradients when data parallel, read by the AdamW launch on the device: non-zero -> the step is not applied)
+        self.grad = grad_buffer if grad_buffer is not None else torch.zeros(self.numel + 1, dtype=torch.float32, device=dev)
+        if self.grad.numel() not in (self.numel, self.numel + 1):
             raise RuntimeError("acmil_amd.FlatAdamW: grad_buffer size mismatch")
+        self.guard_flag = self.grad[self.numel:self.numel + 1] if self.grad.numel() == self.numel + 1 else None
+        self._host_flags = torch.zeros(16, dtype=torch.float32).pin_memory() if self.guard_flag is not None else None
+        self._pending = deque()    # (step id, event, host slot) of launches whose flag the host has not looked at yet
+        self._step_id = 0
+        self._launches = 0         # ordinal handed to the kernel; the device subtracts the launches it skipped (self._skipped_dev)
+        self._skipped_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.skipped_steps = 0
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -60,20 +70,49 @@ class FlatAdamW:
         self.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, track_flag: bool = False) -> int:
+        """One launch.  track_flag: also copy the range flag to pinned host memory (asynchronously) so that `poll_skipped`
+        can tell later whether the device applied this step.  Returns this call's id."""
         g = self.param_groups[0]
         self.step_count += 1
+        self._step_id += 1
+        self._launches += 1
         b1, b2 = g["betas"]
         lib = _lib.load()
         kept = [(o, self.flat[o:o + n].clone()) for o, n in self._frozen]
         rc = lib.acmil_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                   self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                  1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count, torch.cuda.current_stream().cuda_stream)
+                                  self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
+                                  self._skipped_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "acmil_adamw_step")
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
             self.on_step()
+        if track_flag and self.guard_flag is not None:
+            if len(self._pending) >= 12:
+                raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
+            slot = self._step_id % 16
+            self._host_flags[slot:slot + 1].copy_(self.guard_flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((self._step_id, ev, slot))
+        return self._step_id
+
+    def poll_skipped(self, lag: int = 2) -> List[int]:
+        """Ids of tracked steps the device did NOT apply (range flag set), looking only at steps at least `lag` calls old -- their
+        work has long finished, so the wait never idles the GPU and every rank of a data-parallel job decides on the same step.
+        lag = 0 waits for everything outstanding.  `step_count` (what state_dict reports) is put back for every skipped step; the
+        kernel's own bias-correction step number never counted it (it subtracts a device-side count of skipped launches)."""
+        out = []
+        while self._pending and self._pending[0][0] <= self._step_id - lag:
+            sid, ev, slot = self._pending.popleft()
+            ev.synchronize()
+            if float(self._host_flags[slot]) != 0.0:
+                out.append(sid)
+                self.step_count -= 1
+                self.skipped_steps += 1
+        return out
 
     def state_dict(self):
         """torch.optim.AdamW's layout (what the reference's checkpoints hold under 'optimizer', utils/utils.py:415-422): per-parameter
@@ -108,10 +147,12 @@ class FlatAdamW:
                     self.exp_avg[off:off + n].zero_(); self.exp_avg_sq[off:off + n].zero_()
                 off += n
             self.step_count = max(steps) if steps else 0
+            self._launches = self.step_count; self._skipped_dev.zero_()
             for g, s_ in zip(self.param_groups, sd["param_groups"]):
                 g.update({k: v for k, v in s_.items() if k in ("lr", "betas", "eps", "weight_decay")})
             return
         self.step_count = int(sd["step"])
+        self._launches = self.step_count; self._skipped_dev.zero_()
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         for g, s_ in zip(self.param_groups, sd["param_groups"]):
             g.update(s_)

@@ -169,7 +169,10 @@ class GradBucket:
         self.params = [p for p in params if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        # + 1: the range flag of the step rides behind the gradients (optim.FlatAdamW, csrc/ga_step.hip): one all-reduce tells
+        # every rank whether ANY rank's bag left the split-f16 range, and every rank's optimizer launch skips that step
+        self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=dev)
+        self.flag = self.flat[self.numel:]
         off = 0
         for p in self.params:   # gradients become views into the flat buffer: no copy in / out
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -217,13 +220,43 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     use_fused = fused and hasattr(model, "train_step")
     t0 = time.time()
     label_dev = torch.arange(conf.n_class, device=device)      # labels are picked on the device: no H2D per step
+    # Range guard of the split-f16 step without a host read-back per step: the step leaves a flag on the device, the optimizer
+    # launch skips a flagged step, and the host looks at flags two steps late; a skipped bag is then repeated in fp32 arithmetic
+    # (what the reference computes), two positions later in the epoch's order.
+    lagged = (use_fused and getattr(optimizer, "guard_flag", None) is not None and getattr(model, "range_guard", False)
+              and getattr(model, "precision", "") == "f16x3")
+    recent: Dict[int, tuple] = {}
+
+    def reduce_and_step(track):
+        if bucket is not None:
+            bucket.sync_from_grads()
+            bucket.allreduce_mean(world)
+        return optimizer.step(track_flag=True) if track else optimizer.step()
+
+    def settle(lag):
+        nonlocal acc
+        limit = optimizer._step_id - lag
+        skipped = optimizer.poll_skipped(lag)                    # tracked steps <= limit whose flag the device saw set
+        for sid in [k for k in sorted(recent) if k <= limit]:
+            idx, ls = recent.pop(sid)
+            if sid not in skipped:
+                acc += ls
+                continue
+            item = data[idx]                                     # the staging ring has long recycled the bag: read it again
+            xs = torch.as_tensor(item["input"]).to(device)
+            ys = label_dev[item["label"]:item["label"] + 1]
+            redo, _ = model.train_step(xs.unsqueeze(0), ys, precision="fp32", guard_flag=optimizer.guard_flag)
+            reduce_and_step(False)
+            acc += redo
+
     for it, item in enumerate(staged(data, order, device)):     # pinned double-buffered H2D on a copy stream (staging.py)
         x = item["input"]                                      # fp16 stays fp16: converted inside the kernel
         labels = label_dev[item["label"]:item["label"] + 1]
         adjust_learning_rate(optimizer, epoch + it / len(order), conf)
         if use_fused:
-            losses, _ = model.train_step(x.unsqueeze(0), labels)
-            acc += losses
+            losses, _ = model.train_step(x.unsqueeze(0), labels, guard_flag=optimizer.guard_flag if lagged else None)
+            if not lagged:
+                acc += losses
         else:
             out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
             if isinstance(out, tuple):                       # ACMIL: (sub_preds, slide_preds, attn)
@@ -236,10 +269,10 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
             optimizer.zero_grad(set_to_none=False)
             loss.backward()
             acc += torch.stack([loss0.detach(), loss1.detach(), diff_loss.detach(), loss.detach()])
-        if bucket is not None:
-            bucket.sync_from_grads()
-            bucket.allreduce_mean(world)
-        optimizer.step()
+        sid = reduce_and_step(lagged)
+        if lagged:
+            recent[sid] = (item["index"], losses)
+            settle(2)
         if rank == 0 and log_every and (it + 1) % log_every == 0:
             a = acc.tolist()
             sums = {"sub_loss": a[0], "slide_loss": a[1], "diff_loss": a[2]}
@@ -247,6 +280,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
             print("Epoch: [%d] [%d/%d] lr: %.6f sub_loss: %.4f diff_loss: %.4f slide_loss: %.4f (%.1f slides/s/rank)" % (
                 epoch, it + 1, len(order), optimizer.param_groups[0]["lr"], sums["sub_loss"] / (it + 1),
                 sums["diff_loss"] / (it + 1), sums["slide_loss"] / (it + 1), (it + 1) / (time.time() - t0)))
+    if lagged:
+        settle(0)
     n = max(1, len(order))
     a = acc.tolist()
     return {"sub_loss": a[0] / n, "slide_loss": a[1] / n, "diff_loss": a[2] / n}

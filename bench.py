@@ -244,11 +244,13 @@ def other_workloads(args):
     bags = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
 
-    def step(i):
-        model.train_step(bags[i % 8], labels[i % 8])
+    def step(i):      # as train.train_one_epoch: range flag left on the device, looked at two steps late (no host read-back per step)
+        model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag)
         bucket.sync_from_grads()
         bucket.allreduce_mean(world)
-        opt.step()
+        opt.step(track_flag=True)
+        if opt.poll_skipped(2):
+            raise SystemExit("bench: a synthetic bag left the split-f16 range")
     dt = _timed(step, args, world, dev)
     _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
     flops = fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)

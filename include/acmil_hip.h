@@ -198,6 +198,8 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
  *   workspace acmil_ga_train_step_workspace_bytes(...) bytes.  Its first 256 bytes are the GA control block: zero them once
  *            after allocation; word 1 (int32) is the split-f16 range status of this step (0 = in range; otherwise the
  *            caller repeats the step with mode = ACMIL_MODE_F32).
+ *   guard_flag (device float, may be NULL): receives 1.0f when that status is non-zero, else 0.0f -- written on the stream, so
+ *            it can be handed to acmil_adamw_step's skip_flag (and all-reduced) without the host reading anything.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int K, int C, int k_top);
 
@@ -210,7 +212,7 @@ int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int rep
                         int D, int Di, int Da, int K, int C, int mode,
                         const int64_t* label, const float* uniforms, int k_top, int m_mask,
                         float* losses, float* sub_preds, float* slide_pred, float* A_out,
-                        int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
+                        int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216
@@ -351,9 +353,14 @@ int acmil_gate_bwd(const float* G, const float* dy, float* dG, long long N, int 
 
 /* AdamW over one flat fp32 buffer (params, grads, both moments contiguous, n elements), torch.optim.AdamW update rule with
  * decoupled weight decay -- the optimizer.step() of Step3_WSI_classification_ACMIL.py:139,219 as ONE launch.
- * bias_correction{1,2} = 1 - beta{1,2}^t for the current step t >= 1 (computed by the caller). */
-int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1,
-                     float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2, void* stream);
+ * step = ordinal of this call (1, 2, ...); the bias corrections 1 - beta^t use t = step - *skipped.
+ * skip_flag (device, may be NULL): when it holds a non-zero (or NaN) value at execution time the launch changes nothing
+ * except *skipped += 1 (device int, may be NULL) -- the range flag of a split-f16 training step (acmil_ga_train_step's
+ * guard_flag, all-reduced with the gradients when data parallel), so that a step whose bag left the f16 range is never
+ * applied and the host may look at the flag later. */
+int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, double beta1,
+                     double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -144,3 +144,86 @@ def test_fused_step_shares_bucket_with_flat_adamw():
         ref.step()
     for (n, pm), pt in zip(model.named_parameters(), twin.parameters()):
         assert (pm - pt).abs().max().item() <= 3e-6 * max(1.0, pt.abs().max().item()), n
+
+
+class _ListBags:
+    """A dataset of given (bag, label) pairs with the interface train_one_epoch reads (item -> {'input', 'label'})."""
+    def __init__(self, items):
+        self.items = items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        x, y = self.items[i]
+        return {"input": x, "label": y}
+
+
+def _guard_setup(seed=11):
+    from acmil_amd import train as T
+    conf = T.Struct(train_epoch=3, warmup_epoch=0, wd=1e-2, lr=1e-3, min_lr=0, n_class=3, n_token=5, n_masked_patch=0,
+                    mask_drop=0.0, arch="ga", precision="f16x3", seed=1, D_feat=384, D_inner=128)
+    dev = torch.device("cuda", 0)
+    T.set_seed(seed)
+    model = T.build_model(conf).to(dev).train()
+    bucket = T.GradBucket(list(model.parameters()))
+    opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)
+    return T, conf, dev, model, bucket, opt
+
+
+def test_lagged_range_guard_skips_on_device_and_reports_late():
+    """The no-read-back guard: a bag outside the f16 range leaves flag = 1 on the device, the optimizer launch changes NOTHING
+    for that step (parameters, moments), poll_skipped names the step afterwards and puts the bias-correction count back; an
+    in-range bag leaves flag = 0 and is applied."""
+    T, conf, dev, model, bucket, opt = _guard_setup()
+    g = torch.Generator().manual_seed(0)
+    good = torch.randn(500, 384, generator=g).half()
+    bad = good.float().clone(); bad[17, 3] = 1.0e5
+    y = torch.tensor([1], device=dev)
+    before = opt.flat.clone()
+    model.train_step(bad.to(dev).unsqueeze(0), y, guard_flag=opt.guard_flag)
+    assert float(opt.guard_flag) == 1.0
+    sid = opt.step(track_flag=True)
+    assert torch.equal(opt.flat, before) and float(opt.exp_avg.abs().sum()) == 0.0
+    assert opt.poll_skipped(0) == [sid] and opt.step_count == 0 and opt.skipped_steps == 1
+    model.train_step(good.to(dev).unsqueeze(0), y, guard_flag=opt.guard_flag)
+    assert float(opt.guard_flag) == 0.0
+    opt.step(track_flag=True)
+    assert not torch.equal(opt.flat, before) and opt.poll_skipped(0) == [] and opt.step_count == 1
+    # the fp32 repeat of the flagged bag gives exactly what the read-back guard's fp32 fallback gives
+    T2, _, _, twin, bucket2, opt2 = _guard_setup()
+    twin.load_state_dict(model.state_dict())
+    model.train_step(bad.to(dev).unsqueeze(0), y, guard_flag=opt.guard_flag, precision="fp32")
+    twin.train_step(bad.to(dev).unsqueeze(0), y)
+    assert twin.range_fallbacks == 1 and float(opt.guard_flag) == 0.0
+    assert torch.equal(bucket.flat[:bucket.numel], bucket2.flat[:bucket2.numel])
+
+
+def test_train_one_epoch_repeats_a_flagged_bag_in_fp32():
+    """train_one_epoch with the lagged guard: the out-of-range bag is skipped by the device, found two steps later and trained
+    in fp32.  The model ends where a run ends that sees the same bags with the flagged one moved to where its repeat happened
+    (same arithmetic per step; only the order of one bag differs from the reference's loop)."""
+    T, conf, dev, model, bucket, opt = _guard_setup(seed=21)
+    g = torch.Generator().manual_seed(1)
+    bags = [(torch.randn(400 + 37 * i, 384, generator=g).half(), i % 3) for i in range(6)]
+    bad = bags[2][0].float().clone(); bad[5, 7] = 3.0e5
+    data = _ListBags(bags[:2] + [(bad, bags[2][1])] + bags[3:])
+    conf.seed = 0
+    order = T.epoch_order(len(data), 0, conf.seed, True, 0, 1)
+    stats = T.train_one_epoch(model, data, opt, dev, 0, conf, bucket=bucket, log_every=0)
+    assert opt.skipped_steps == 1 and all(v == v for v in stats.values())           # losses finite: the skipped step's are not summed
+    # replica: same order and learning-rate schedule, the flagged bag trained (fp32) right after the step at which the lagged
+    # loop found it (two iterations later, with that iteration's learning rate)
+    T2, conf2, _, twin, bucket2, opt2 = _guard_setup(seed=21)
+    pos = list(order).index(2)
+    found = min(pos + 2, len(order) - 1)
+    for it, i in enumerate(order):
+        T.adjust_learning_rate(opt2, 0 + it / len(order), conf2)
+        if i != 2:
+            twin.train_step(data[i]["input"].to(dev).unsqueeze(0), torch.tensor([data[i]["label"]], device=dev))
+            opt2.step()
+        if it == found:
+            twin.train_step(data[2]["input"].to(dev).unsqueeze(0), torch.tensor([data[2]["label"]], device=dev), precision="fp32")
+            opt2.step()
+    for (n, pm), pt in zip(model.named_parameters(), twin.parameters()):
+        assert (pm - pt).abs().max().item() <= 2e-5 * max(1.0, pt.abs().max().item()), n

@@ -17,7 +17,16 @@ bags = [S.synthetic_bag(N, 512, slide_idx=i)[0].half().to(dev).unsqueeze(0) for 
 labels = [torch.tensor([i % 7], device=dev) for i in range(8)]
 
 
+LAGGED = False
+
+
 def step(i):
+    if LAGGED:
+        model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag)
+        bucket.sync_from_grads()
+        opt.step(track_flag=True)
+        opt.poll_skipped(2)
+        return
     model.train_step(bags[i % 8], labels[i % 8])
     bucket.sync_from_grads()
     opt.step()
@@ -36,9 +45,10 @@ def timeit(steps=200):
 
 res = {}
 for rnd in range(3):
-    for name, guard, fused in (("one-call", True, True), ("one-call/noguard", False, True), ("op-by-op", True, False),
-                               ("op-by-op/noguard", False, False)):
-        model.range_guard, model.fused_step = guard, fused
+    for name, guard, fused, lag in (("one-call/lagged", True, True, True), ("one-call/readback", True, True, False),
+                                    ("one-call/noguard", False, True, False), ("op-by-op", True, False, False)):
+        model.range_guard, model.fused_step, LAGGED = guard, fused, lag
         res.setdefault(name, []).append(timeit())
+        opt.poll_skipped(0)
 for k, v in res.items():
     print("%-18s ms/step %s  median %.4f" % (k, ["%.4f" % t for t in v], sorted(v)[1]))
