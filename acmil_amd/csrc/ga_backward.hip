@@ -231,6 +231,7 @@ GbWs gb_layout(int N, int D, int Di, int K) {
     const size_t g2 = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1); // shared finishing launch: separate regions
     w.gemm = off;    off += gb_align(g);
     w.gemm2 = off;   off += gb_align(g2);
+    w.wg = off;      off += gb_align(wgrad_workspace_bytes(2 * GA_DA, Di, Di, D, N));   // partials of the dedicated kernel (wgrad.hip)
     w.total = off;
     return w;
 }
@@ -292,14 +293,24 @@ int gb_run(const GbRun& r) {
     if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
     // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
     GemmArgs g1, g2;
-    const bool will_split = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1) > 256;      // same rule as the launcher's
-    float* dWcat = (g_adj || will_split) ? r.dWv : (float*)(ws + L.dwcat);
-    rc = gemm_run_deferred(x_grad, 1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, r.h, ACMIL_DTYPE_F32, Di, 0.0f, dWcat, Di, nullptr, 0, nullptr, ws + L.gemm2, st, &g1);
-    if (rc != ACMIL_OK) return rc;
-    if (will_split != (g1.splits > 1)) return ACMIL_ERR_LAUNCH;
-    if (g1.splits > 1 && !g_adj) { g1.C2 = r.dWu; g1.split_row = GA_DA; }
-    rc = gemm_run_deferred(x_grad, 1, 0, Di, D, N, 1.0f, dpre, Di, r.x, r.x_dtype, D, 0.0f, r.dW1, D, nullptr, 0, nullptr, ws + L.gemm, st, &g2);
-    if (rc != ACMIL_OK) return rc;
+    rc = ACMIL_ERR_UNSUPPORTED;
+    if (r.mode != ACMIL_MODE_F32)       // dedicated kernel: both products in one launch, hardware-transposed LDS reads (wgrad.hip)
+        rc = wgrad_launch(G, 2 * GA_DA, r.h, ACMIL_DTYPE_F32, Di, 2 * GA_DA, Di, r.dWv, dpre, Di, r.x, r.x_dtype, D, Di, D, r.dW1,
+                          N, ws + L.wg, st, &g1, &g2);
+    if (rc == ACMIL_OK) {
+        if (!g_adj) { g1.C2 = r.dWu; g1.split_row = GA_DA; }
+    } else if (rc != ACMIL_ERR_UNSUPPORTED) {
+        return rc;
+    } else {
+        const bool will_split = acmil_gemm_workspace_bytes(2 * GA_DA, Di, N, 1) > 256;      // same rule as the launcher's
+        float* dWcat = (g_adj || will_split) ? r.dWv : (float*)(ws + L.dwcat);
+        rc = gemm_run_deferred(x_grad, 1, 0, 2 * GA_DA, Di, N, 1.0f, G, 2 * GA_DA, r.h, ACMIL_DTYPE_F32, Di, 0.0f, dWcat, Di, nullptr, 0, nullptr, ws + L.gemm2, st, &g1);
+        if (rc != ACMIL_OK) return rc;
+        if (will_split != (g1.splits > 1)) return ACMIL_ERR_LAUNCH;
+        if (g1.splits > 1 && !g_adj) { g1.C2 = r.dWu; g1.split_row = GA_DA; }
+        rc = gemm_run_deferred(x_grad, 1, 0, Di, D, N, 1.0f, dpre, Di, r.x, r.x_dtype, D, 0.0f, r.dW1, D, nullptr, 0, nullptr, ws + L.gemm, st, &g2);
+        if (rc != ACMIL_OK) return rc;
+    }
     // 7 one finishing launch: both split-K reduces and the gate pass' partial records (fixed order)
     RowSumJob job;
     job.part = part; job.records = blocks; job.stride = KP * GA_DA + KP + 2 * GA_DA; job.len = job.stride; job.nseg = 4;
@@ -310,7 +321,7 @@ int gb_run(const GbRun& r) {
     rc = gemm_finish(&g1, &g2, &job, st);
     if (rc != ACMIL_OK) return rc;
     if (!g_adj && g1.splits <= 1) {
-        hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, dWcat, GA_DA * Di, r.dWv, r.dWu);
+        hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + L.dwcat), GA_DA * Di, r.dWv, r.dWu);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
     return ACMIL_OK;

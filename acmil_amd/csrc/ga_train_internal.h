@@ -10,7 +10,7 @@ int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m,
 int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st);
 
 // ga_backward.hip
-struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, gemm2, total; };
+struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, gemm2, wg, total; };
 GbWs gb_layout(int N, int D, int Di, int K);
 
 struct GbRun {
@@ -26,3 +26,10 @@ struct GbRun {
     hipStream_t st;
 };
 int gb_run(const GbRun& r);
+
+// wgrad.hip: both weight-gradient products (contraction over the patches) in one launch; *_bytes == 0 / ACMIL_ERR_UNSUPPORTED
+// when the shapes do not fit its 128 x 128 tiles or the bag is tiny (callers then use the generic GEMM)
+size_t wgrad_workspace_bytes(int M1, int N1, int M2, int N2, int K);
+int wgrad_launch(const float* A1, int lda1, const void* B1, int b1_dtype, int ldb1, int M1, int N1, float* C1,
+                 const float* A2, int lda2, const void* B2, int b2_dtype, int ldb2, int M2, int N2, float* C2,
+                 int K, void* workspace, hipStream_t st, GemmArgs* g1, GemmArgs* g2);

@@ -1,0 +1,257 @@
+// wgrad.hip -- weight gradients of the GA backward: C = A^T B with the contraction over the N patches of the bag
+//   [dWv; dWu] = dS^T h     (2 Da x Di,  A = dS [N, 2 Da], B = h [N, Di])
+//   dW1        = dpre^T x   (Di x D,     A = dpre [N, Di], B = x [N, D], fp32 / fp16 / bf16 bag)
+// (autograd of architecture/transformer.py:305-330; the reference has no explicit backward code).
+//
+// Both operands are stored with the contraction index as the SLOW axis ([patch][column]), i.e. transposed with respect to
+// what an MFMA fragment wants (8 consecutive k per lane).  The generic GEMM (gemm_f32.hip) transposes through 16 scalar
+// loads per thread and K step; here the tiles go into LDS exactly as they lie in memory ([k][column], 16-bit hi / lo planes)
+// and the fragments come out through the CDNA4 hardware transpose ds_read_b64_tr_b16 -- no scalar loads, no VALU shuffles.
+//   * arithmetic: split-bf16 ("bf16x3", as the generic path of the backward): a = hi + lo in bf16, hi*hi + lo*hi + hi*lo on
+//     v_mfma_f32_32x32x16_bf16, fp32 accumulate -- gradients keep the fp32 exponent range without scaling;
+//   * tile: 128 x 128 outputs per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 each), K step = 32 patches;
+//   * pipeline: global loads are issued three K steps ahead into two register sets, the split + LDS store of step s+1 and
+//     the MFMAs of step s share one barrier per step (two LDS stages);
+//   * split-K over the patches, partials [split][M][N] finished by gemm_finish_kernel (fixed order, gemm_f32.hip); BOTH
+//     products are one launch (the grid is the concatenation of their (tile, split) lists).
+#include <string.h>
+#include <type_traits>
+
+#include "ga_train_internal.h"
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) h16x4* wg_ltr_t;
+
+#define WG_ROW 288                       // LDS bytes per k row of a plane: 128 x 2 B + 32 B pad (conflict-free transposed reads)
+#define WG_PLANE (32 * WG_ROW)           // one plane of one stage: 32 k rows
+#define WG_STAGE (4 * WG_PLANE)          // A hi, A lo, B hi, B lo
+#define WG_LDS (2 * WG_STAGE)
+
+struct WgProb {
+    const float* A; const void* B; float* ws;
+    int lda, ldb, b_dtype, M, N, tiles_n, tiles, splits, kchunk;
+};
+struct WgArgs { WgProb p[2]; int blocks0, K; };
+
+__device__ __forceinline__ void wg_split_store(char* hi_plane, char* lo_plane, int off, const f32x4 v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { h[q] = (__bf16)v[q]; l[q] = (__bf16)(v[q] - (float)h[q]); }
+    *(bf16x4*)(hi_plane + off) = h;
+    *(bf16x4*)(lo_plane + off) = l;
+}
+
+// fragment of a 32-column block (columns c0 .. c0+31 of the plane), k = kb .. kb+15: lane (i = lane & 31, hi = lane >> 5)
+// receives plane[kb + 8 hi + j][c0 + i], j < 8.  Supplier lane p = lane & 15 of 16-lane group g addresses row
+// kb + 8 (g >> 1) + (p >> 2) (+4 for the second read), columns c0 + 16 (g & 1) + 4 (p & 3) .. +3.
+__device__ __forceinline__ bf16x8 wg_frag(const char* plane, int rd_off) {
+    const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wg_ltr_t)(plane + rd_off));
+    const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((wg_ltr_t)(plane + rd_off + 4 * WG_ROW));
+    typedef h16x4 h16x4_t;
+    struct { h16x4_t a, b; } pr = {a0, a1};
+    return __builtin_bit_cast(bf16x8, pr);
+}
+
+template <int BDT>
+__device__ __forceinline__ void wg_body(const WgProb& P, int K, int tile, int split, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = (tile / P.tiles_n) * 128, n0 = (tile % P.tiles_n) * 128;
+    const int kbeg = split * P.kchunk;
+    const int kend = min(K, kbeg + P.kchunk);
+    const int nsteps = (kend - kbeg + 31) / 32;
+
+    // ---- global -> registers.  A: float4 (row = 8 j + tid / 32, columns 4 (tid % 32)), four per thread and step;
+    // B fp32 the same; B 16-bit: 16-byte chunks (row = 16 j + tid / 16, columns 8 (tid % 16)), two per thread and step.
+    const int lrow = tid >> 5, lc4 = tid & 31;
+    const int brow = tid >> 4, bc8 = tid & 15;
+    const float* Ap = P.A + (size_t)m0 + 4 * lc4;
+    f32x4 ra[2][4], rb[2][4];
+    u32x4 rh[2][2];
+    auto load = [&](auto SET, int step) {
+        constexpr int S = decltype(SET)::value;
+        const int kb = kbeg + 32 * step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kb + 8 * j + lrow;
+            ra[S][j] = (k < kend) ? *(const f32x4*)(Ap + (size_t)k * P.lda) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        if constexpr (BDT == ACMIL_DTYPE_F32) {
+            const float* Bp = (const float*)P.B + (size_t)n0 + 4 * lc4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kb + 8 * j + lrow;
+                rb[S][j] = (k < kend) ? *(const f32x4*)(Bp + (size_t)k * P.ldb) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        } else {
+            const uint16_t* Bp = (const uint16_t*)P.B + (size_t)n0 + 8 * bc8;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = kb + 16 * j + brow;
+                rh[S][j] = (k < kend) ? *(const u32x4*)(Bp + (size_t)k * P.ldb) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    // ---- registers -> LDS planes of stage `stage` ([k][column] as in memory, split into bf16 hi / lo)
+    auto store = [&](auto SET, int stage) {
+        constexpr int S = decltype(SET)::value;
+        char* base = smem + stage * WG_STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wg_split_store(base, base + WG_PLANE, (8 * j + lrow) * WG_ROW + lc4 * 8, ra[S][j]);
+        if constexpr (BDT == ACMIL_DTYPE_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wg_split_store(base + 2 * WG_PLANE, base + 3 * WG_PLANE, (8 * j + lrow) * WG_ROW + lc4 * 8, rb[S][j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = (16 * j + brow) * WG_ROW + bc8 * 16;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const uint32_t word = rh[S][j][2 * w + q];
+                        if constexpr (BDT == ACMIL_DTYPE_F16) {
+                            v[2 * q] = (float)__builtin_bit_cast(_Float16, (uint16_t)(word & 0xffffu));
+                            v[2 * q + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(word >> 16));
+                        } else {
+                            v[2 * q] = __builtin_bit_cast(float, word << 16);
+                            v[2 * q + 1] = __builtin_bit_cast(float, word & 0xffff0000u);
+                        }
+                    }
+                    wg_split_store(base + 2 * WG_PLANE, base + 3 * WG_PLANE, off + 8 * w, v);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // transposed-read offset of this lane inside a 32-column block (see wg_frag)
+    const int p16 = lane & 15, g4 = lane >> 4;
+    const int rd = (8 * (g4 >> 1) + (p16 >> 2)) * WG_ROW + (16 * (g4 & 1) + 4 * (p16 & 3)) * 2;
+    auto compute = [&](int stage) {
+        const char* base = smem + stage * WG_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int oa = rd + 16 * ks * WG_ROW + (64 * wm + 32 * t) * 2;
+                const int ob = rd + 16 * ks * WG_ROW + (64 * wn + 32 * t) * 2;
+                ah[t] = wg_frag(base, oa);
+                al[t] = wg_frag(base + WG_PLANE, oa);
+                bh[t] = wg_frag(base + 2 * WG_PLANE, ob);
+                bl[t] = wg_frag(base + 3 * WG_PLANE, ob);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    };
+
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    if (nsteps > 0) load(S0{}, 0);
+    if (nsteps > 1) load(S1{}, 1);
+    if (nsteps > 0) store(S0{}, 0);
+    if (nsteps > 2) load(S0{}, 2);
+    for (int s = 0; s < nsteps; s += 2) {
+        __syncthreads();                    // stage 0 holds step s; stage 1 (step s-1) has been consumed by every wave
+        if (s + 1 < nsteps) { store(S1{}, 1); if (s + 3 < nsteps) load(S1{}, s + 3); }
+        compute(0);
+        if (s + 1 >= nsteps) break;
+        __syncthreads();
+        if (s + 2 < nsteps) { store(S0{}, 0); if (s + 4 < nsteps) load(S0{}, s + 4); }
+        compute(1);
+    }
+    // ---- partial tile -> ws[split][M][N]; acc[a][b][r]: row = m0 + 64 wm + 32 a + mfma32_row(r, hi), col = n0 + 64 wn + 32 b + lane % 32
+    float* out = P.ws + (size_t)split * P.M * P.N;
+    const int i31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + 64 * wn + 32 * b + i31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + 64 * wm + 32 * a + mfma32_row(r, hi);
+                out[(size_t)row * P.N + col] = acc[a][b][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pr = (int)blockIdx.x >= a.blocks0 ? 1 : 0;
+    const WgProb& P = a.p[pr];
+    const int b = blockIdx.x - (pr ? a.blocks0 : 0);
+    const int tile = b % P.tiles, split = b / P.tiles;
+    if (P.b_dtype == ACMIL_DTYPE_F32) wg_body<ACMIL_DTYPE_F32>(P, a.K, tile, split, smem);
+    else if (P.b_dtype == ACMIL_DTYPE_F16) wg_body<ACMIL_DTYPE_F16>(P, a.K, tile, split, smem);
+    else wg_body<ACMIL_DTYPE_BF16>(P, a.K, tile, split, smem);
+}
+
+// K split shared by both products: about one workgroup per CU over the two tile lists, at least 4 K steps per workgroup
+static int wg_pick_splits(int tiles_total, int K) {
+    const int steps = (K + 31) / 32;
+    int s = (256 + tiles_total - 1) / tiles_total;
+    if (s > steps / 4) s = steps / 4;
+    if (s > 128) s = 128;
+    return s < 2 ? 0 : s;           // 0: not worth it (tiny bag) -> the caller keeps the generic path
+}
+
+size_t wgrad_workspace_bytes(int M1, int N1, int M2, int N2, int K) {
+    if (M1 % 128 || N1 % 128 || M2 % 128 || N2 % 128) return 0;
+    const int s = wg_pick_splits((M1 / 128) * (N1 / 128) + (M2 / 128) * (N2 / 128), K);
+    return s ? (((size_t)s * ((size_t)M1 * N1 + (size_t)M2 * N2) * sizeof(float) + 255) & ~(size_t)255) : 0;
+}
+
+// Launch both products; g1 / g2 receive what gemm_finish needs (C, ldc, M, N, splits, ws).  Returns ACMIL_ERR_UNSUPPORTED when
+// the shapes do not fit (the caller then uses the generic GEMM).
+int wgrad_launch(const float* A1, int lda1, const void* B1, int b1_dtype, int ldb1, int M1, int N1, float* C1,
+                 const float* A2, int lda2, const void* B2, int b2_dtype, int ldb2, int M2, int N2, float* C2,
+                 int K, void* workspace, hipStream_t st, GemmArgs* g1, GemmArgs* g2) {
+    if (M1 % 128 || N1 % 128 || M2 % 128 || N2 % 128 || K <= 0) return ACMIL_ERR_UNSUPPORTED;
+    if ((lda1 & 3) || (lda2 & 3) || (((size_t)A1 | (size_t)A2) & 15)) return ACMIL_ERR_UNSUPPORTED;
+    const int al1 = b1_dtype == ACMIL_DTYPE_F32 ? 3 : 7, al2 = b2_dtype == ACMIL_DTYPE_F32 ? 3 : 7;
+    if ((ldb1 & al1) || (ldb2 & al2) || (((size_t)B1 | (size_t)B2) & 15)) return ACMIL_ERR_UNSUPPORTED;
+    const int t1 = (M1 / 128) * (N1 / 128), t2 = (M2 / 128) * (N2 / 128);
+    const int s = wg_pick_splits(t1 + t2, K);
+    if (!s || !workspace) return ACMIL_ERR_UNSUPPORTED;
+    const int steps = (K + 31) / 32;
+    const int kchunk = ((steps + s - 1) / s) * 32;
+    const int splits = (K + kchunk - 1) / kchunk;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+    if (attr != hipSuccess) return ACMIL_ERR_LAUNCH;
+    WgArgs a;
+    a.K = K;
+    float* ws1 = (float*)workspace;
+    float* ws2 = ws1 + (size_t)splits * M1 * N1;
+    a.p[0] = WgProb{A1, B1, ws1, lda1, ldb1, b1_dtype, M1, N1, N1 / 128, t1, splits, kchunk};
+    a.p[1] = WgProb{A2, B2, ws2, lda2, ldb2, b2_dtype, M2, N2, N2 / 128, t2, splits, kchunk};
+    a.blocks0 = t1 * splits;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((t1 + t2) * splits), dim3(256), WG_LDS, st, a);
+    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    auto fill = [&](GemmArgs* g, float* C, int M, int N, float* ws) {
+        memset(g, 0, sizeof(*g));
+        g->C = C; g->ws = ws; g->M = M; g->N = N; g->K = K; g->ldc = N; g->splits = splits; g->kchunk = kchunk;
+        g->alpha = 1.0f; g->beta = 0.0f;
+    };
+    fill(g1, C1, M1, N1, ws1);
+    fill(g2, C2, M2, N2, ws2);
+    return ACMIL_OK;
+}
