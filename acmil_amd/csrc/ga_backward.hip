@@ -288,7 +288,10 @@ int gb_run(const GbRun& r) {
 #undef GB_LAUNCH_GATE
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
-    rc = gemm_run_deferred(x_grad, 0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, Wcat, ACMIL_DTYPE_F32, Di, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
+    if (r.WcatT)    // K-contiguous copy of the weights: the operand loads are float4 rows instead of 16 strided scalars per thread
+        rc = gemm_run_deferred(x_grad, 0, 1, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, r.WcatT, ACMIL_DTYPE_F32, 2 * GA_DA, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
+    else
+        rc = gemm_run_deferred(x_grad, 0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, Wcat, ACMIL_DTYPE_F32, Di, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
     if (rc != ACMIL_OK) return rc;
     if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
     // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
@@ -362,7 +365,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     GbRun r;
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
-    r.dA_ext = d_A; r.coef = nullptr; r.Wcat = nullptr; r.bcat = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
+    r.dA_ext = d_A; r.coef = nullptr; r.Wcat = nullptr; r.bcat = nullptr; r.WcatT = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = ws; r.st = st;
     return gb_run(r);

@@ -32,11 +32,11 @@ __host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3)
 //       half hi covers the 4 CONSECUTIVE units 32p + 8rq + 4hi + {0..3}, so the epilogue reads plain float4s)
 //  bw : 8 floats (bw[K], zero padded)
 //  heads: Wc [K][C][Di], bc [K][C], Ws [C][Di], bs [C]   (raw copies, fp32)
-//  wcat : [Wv; Wu] [2 Da][Di] and bcat [bv; bu] [2 Da]  (raw copies, fp32; read by the backward of a training step)
+//  wcat : [Wv; Wu] [2 Da][Di], bcat [bv; bu] [2 Da], wcatT = [Wv; Wu]^T [Di][2 Da]  (raw fp32; read by the backward of a training step)
 // ---------------------------------------------------------------------------------------------------
 struct GaLayout {
     int D, Di, K, C, ND, mode;
-    size_t g1_off, g1_rows, g2_off, g2_rows, tab_off, bw_off, wc_off, bc_off, ws_off, bs_off, wcat_off, bcat_off, total;
+    size_t g1_off, g1_rows, g2_off, g2_rows, tab_off, bw_off, wc_off, bc_off, ws_off, bs_off, wcat_off, bcat_off, wcatT_off, total;
 };
 
 __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C, int mode) {
@@ -56,6 +56,7 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
     off = (off + 255) & ~(size_t)255;
     L.wcat_off = off; off += (size_t)2 * GA_DA * Di * 4;     // [Wv; Wu] as one [2 Da, Di] matrix, [bv; bu]: the backward's
     L.bcat_off = off; off += (size_t)2 * GA_DA * 4;          // single-GEMM operands (ga_backward.hip)
+    L.wcatT_off = off; off += (size_t)2 * GA_DA * Di * 4;    // [Wv; Wu]^T [Di][2 Da]: K-contiguous operand of the dpre product
     L.total = (off + 255) & ~(size_t)255;
     return L;
 }

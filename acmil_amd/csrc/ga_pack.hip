@@ -98,8 +98,9 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
     const int tid = threadIdx.x;
     const int CD = L.C * L.Di;
     if (blockIdx.x > tail_block) {
-        const size_t ncat = (size_t)2 * GA_DA * L.Di, nwc = (size_t)L.K * CD, total = ncat + nwc + CD;
+        const size_t ncat = (size_t)2 * GA_DA * L.Di, nwc = (size_t)L.K * CD, total = ncat + nwc + CD + ncat;
         float* wcat = (float*)(a.out + L.wcat_off);
+        float* wcatT = (float*)(a.out + L.wcatT_off);
         float* wc = (float*)(a.out + L.wc_off);
         float* ws = (float*)(a.out + L.ws_off);
 #pragma unroll
@@ -108,7 +109,12 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
             if (e >= total) break;
             if (e < ncat) wcat[e] = e < ncat / 2 ? a.Wv[e] : a.Wu[e - ncat / 2];
             else if (e < ncat + nwc) { const size_t r = e - ncat; wc[r] = a.Wc[r / CD][r % CD]; }
-            else { const size_t r = e - ncat - nwc; ws[r] = a.Ws ? a.Ws[r] : 0.0f; }
+            else if (e < ncat + nwc + CD) { const size_t r = e - ncat - nwc; ws[r] = a.Ws ? a.Ws[r] : 0.0f; }
+            else {      // transposed copy: element (di, u) of [Di][2 Da]
+                const size_t r = e - ncat - nwc - CD;
+                const int di = (int)(r / (2 * GA_DA)), u = (int)(r % (2 * GA_DA));
+                wcatT[r] = u < GA_DA ? a.Wv[(size_t)u * L.Di + di] : a.Wu[(size_t)(u - GA_DA) * L.Di + di];
+            }
         }
         return;
     }
@@ -154,7 +160,7 @@ extern "C" int acmil_ga_pack_weights(const float* W1, const float* Wv, const flo
     }
     a.out = (char*)packed;
     a.L = ga_layout(D, Di, K, C, mode);
-    const size_t aux = (size_t)2 * GA_DA * Di + (size_t)K * C * Di + (size_t)C * Di;
+    const size_t aux = (size_t)4 * GA_DA * Di + (size_t)K * C * Di + (size_t)C * Di;
     const unsigned blocks = (unsigned)((a.L.g1_rows + a.L.g2_rows + 3) / 4) + 1 + (unsigned)((aux + 1023) / 1024);
     hipLaunchKernelGGL(ga_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;

@@ -360,6 +360,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     GbRun r;
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
     r.Wcat = (const float*)((const char*)packed + t.L.wcat_off); r.bcat = (const float*)((const char*)packed + t.L.bcat_off);
+    r.WcatT = (const float*)((const char*)packed + t.L.wcatT_off);
     r.dA_ext = nullptr; r.coef = (K > 1) ? coef : nullptr; r.d_afeat = t.d_afeat; r.ck = t.ck; r.stats = t.stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = bws; r.st = st;

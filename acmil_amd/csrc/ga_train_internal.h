@@ -17,6 +17,7 @@ struct GbRun {
     const void* x; int x_dtype; int N;
     const float *h, *A_out, *Wv, *bv, *Wu, *bu, *Ww;
     const float *Wcat, *bcat;   // [Wv; Wu] [2 Da][Di] and [bv; bu] as single operands (packed buffer), or null
+    const float* WcatT;         // [Wv; Wu]^T [Di][2 Da] (packed buffer), or null
     const float* dA_ext;     // [K][N] external gradient of the scores, or null
     const float* coef;       // [KP][KP] diversity-loss coefficients (ga_loss.hip), or null: that term of dA is formed in the gate pass
     const float *d_afeat, *ck, *stats;   // [K][Di], [K], [K][2] = (max, sum exp) of the masked scores

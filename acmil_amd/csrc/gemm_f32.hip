@@ -129,6 +129,18 @@ __device__ __forceinline__ void gm_epilogue(const GemmArgs& g, const f32x16 (&ac
             const int col = n0 + WS * wn + 32 * b + i31;
             if (col >= g.N) continue;
             const float bias = (g.splits > 1 || !g.bias) ? 0.0f : g.bias[col];
+            // accumulate / mask operands of the whole 32 x 32 tile first (32 independent loads in flight): read one by one
+            // between the stores they form a chain of 64 dependent round trips (the stores may alias them for the compiler)
+            float oldv[16], auxv[16];
+            const bool direct = g.splits <= 1 && g.act != 3 && g.act != 4;
+            const bool need_old = direct && g.beta != 0.0f, need_aux = direct && g.act == 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + WS * wm + 32 * a + mfma32_row(r, hi);
+                const long long idx = (long long)row * ldc + col;
+                oldv[r] = (need_old && row < g.M) ? Cb[idx] : 0.0f;
+                auxv[r] = (need_aux && row < g.M) ? g.aux[(long long)batch * g.sC + idx] : 1.0f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + WS * wm + 32 * a + mfma32_row(r, hi);
@@ -143,8 +155,8 @@ __device__ __forceinline__ void gm_epilogue(const GemmArgs& g, const f32x16 (&ac
                 }
                 else {
                     float v = g.alpha * acc[a][b][r] + bias;
-                    if (g.beta != 0.0f) v += g.beta * *dst;
-                    *dst = gm_act(v, g.act, g.aux + (long long)batch * g.sC, (long long)row * ldc + col);
+                    if (g.beta != 0.0f) v += g.beta * oldv[r];
+                    *dst = g.act == 1 ? fmaxf(v, 0.0f) : g.act == 2 ? (auxv[r] > 0.0f ? v : 0.0f) : v;
                 }
             }
         }

@@ -334,9 +334,16 @@ static TmWs tm_ws(const TmGeom& g) {
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
     w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
-    size_t gw = acmil_gemm_workspace_bytes(g.m, g.d, g.npad, TM_HEADS);
-    const size_t g2 = acmil_gemm_workspace_bytes(1, g.C, g.Di, 1);
-    if (g2 > gw) gw = g2;
+    // split-K scratch: the largest need over EVERY product of the forward (a small bag with a wide feature vector splits
+    // products that never split at slide scale, e.g. fc1 at N = 400, D = 1536)
+    const int H = TM_HEADS, m = g.m, d = g.d, np_ = g.npad, Di = g.Di;
+    const int shapes[][4] = {{np_, 3 * Di, Di, 1}, {np_, m, d, H}, {m, m, d, H}, {m, m, m, H}, {m, np_, d, H}, {m, d, np_, H},
+                             {m, d, m, H}, {np_, d, m, H}, {g.n, Di, Di, 1}, {g.N, Di, g.D, 1}, {1, g.C, Di, 1}};
+    size_t gw = 256;
+    for (const auto& sh : shapes) {
+        const size_t b = acmil_gemm_workspace_bytes(sh[0], sh[1], sh[2], sh[3]);
+        if (b > gw) gw = b;
+    }
     w.GEMM = off; off += tm_al(gw);
     w.total = off;
     return w;
