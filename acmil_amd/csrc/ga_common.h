@@ -87,6 +87,24 @@ __device__ static inline float ga_tanh(float v) { return 1.0f - 2.0f * __builtin
 // zero again (the last workgroup resets them), so no memset sits on the stream between launches.
 #define GA_CTRL_BYTES 256
 
+// ---- hi / lo splits of two fp32 values at a time (packed results: element 0 in the low half-word)
+// f16: hi = rn_f16(x) (packed convert), lo = rn_f16(x - hi) by v_fma_mix{lo,hi}_f16 (f16 source * -1.0 + f32 source, ONE rounding
+// to f16; x - hi is exact in fp32, so this equals the convert / subtract / convert sequence bit for bit): 3 VALU instructions
+// for two elements instead of 8.  The s_nops cover the partial-register-write forwarding hazard.
+__device__ __forceinline__ void ga_split_pair_f16(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\t"
+        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
+        : "=&v"(hi_pk), "=&v"(lo_pk) : "v"(x0), "v"(x1));
+}
+// bf16: hi = rn_bf16(x), lo = rn_bf16(x - hi) with the PACKED hardware convert (the compiler's scalar casts cost one
+// v_cvt_pk_bf16_f32 per element plus pack operations): 6 VALU instructions for two elements
+__device__ __forceinline__ void ga_split_pair_bf16(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi_pk) : "v"(x0), "v"(x1));
+    const float d0 = x0 - __builtin_bit_cast(float, hi_pk << 16);
+    const float d1 = x1 - __builtin_bit_cast(float, hi_pk & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo_pk) : "v"(d0), "v"(d1));
+}
+
 // merge + heads (ga_forward.hip), shared by the fused forward and the masked pooling pass; the afeat scratch follows the partials
 int ga_finish(const float* part, int tiles, const void* packed, const GaLayout& L, float* sub_preds,
               float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, hipStream_t st);

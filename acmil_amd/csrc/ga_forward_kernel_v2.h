@@ -97,14 +97,7 @@ __device__ __forceinline__ void ga2_dma(unsigned voff, const char* sbase, unsign
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(m0v), "n"(IMM) : "memory");
 }
 
-// f16 hi/lo split of two fp32 values in 3 VALU instructions: hi = rn_f16(x) (packed convert), lo = rn_f16(x - hi) by
-// v_fma_mix{lo,hi}_f16 (f16 source * -1.0 + f32 source, ONE rounding to f16; x - hi is exact in fp32, so this equals the
-// convert / subtract / convert sequence bit for bit).  The s_nops cover the partial-register-write forwarding hazard.
-__device__ __forceinline__ void ga2_split_pair(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {
-    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_fma_mixlo_f16 %1, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0\n\t"
-        "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
-        : "=&v"(hi_pk), "=&v"(lo_pk) : "v"(x0), "v"(x1));
-}
+__device__ __forceinline__ void ga2_split_pair(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) { ga_split_pair_f16(x0, x1, hi_pk, lo_pk); }
 
 // DPP move (no LDS): lanes the control / row mask leaves without a source keep `idv`, the identity of the reduction
 template <int CTRL, int ROW_MASK>

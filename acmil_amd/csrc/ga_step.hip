@@ -120,9 +120,13 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();                               // acquire the other workgroups' afeat / stats
+    if (tid == 0) __threadfence();                 // acquire the other workgroups' afeat / stats (cache-wide: one lane is enough)
+    __syncthreads();
 
     // ------------------------------------------------------------------ tail (one workgroup, 16 waves)
+    // Every global read the tail needs is issued in ONE batch (a dependent chain of ~10 round trips at ~2 us each was most
+    // of this kernel): afeat, branch statistics, label, the tile maxima + Gram partials.  Head weights are read where they
+    // are used (two batches: logits, gradients).
     float* af = (float*)smem;                      // [K][Di]
     float* bf = af + (size_t)K * Di;               // [Di]   bag feature = mean_k afeat
     float* lsub = bf + Di;                         // [K*C]  branch logits
@@ -130,15 +134,61 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     float* dsub = lslide + ACMIL_MAX_CLASSES;      // [K*C]
     float* dslide = dsub + GS_MAXK * ACMIL_MAX_CLASSES;   // [C]
     float* S = dslide + ACMIL_MAX_CLASSES;         // [KP*KP] Gram of the softmax rows
-    float* sc = S + 64;                            // scalars: [0..K) per-branch CE, [8] bag CE, [16 + 2k] M_k, [17 + 2k] L_k
+    float* sc = S + 64;                            // scalars: [0..K) per-branch CE, [8] bag CE, [16 + 2k] M_k, [17 + 2k] L_k, [32] label
+    float* ckp = sc + 64;                          // [16 waves][KP + 3] partial c_k
     const float invK = 1.0f / (float)K;
+    const bool train = a.label != nullptr;
     if (tid == 0 && a.guard_flag) *a.guard_flag = (a.status && __builtin_nontemporal_load(a.status) != 0u) ? 1.0f : 0.0f;
     for (int e = tid; e < K * Di; e += 1024) af[e] = __builtin_nontemporal_load(a.afeat + e);
+    if (train) {
+        if (tid < 2 * K) sc[16 + tid] = __builtin_nontemporal_load(a.stats + tid);
+        if (tid == 2 * K) sc[32] = (float)(int)a.label[0];
+    }
+    // Gram of the softmax rows from the tile partials: S_ij = sum_t g_t[i][j] f_i(t) f_j(t), f_k(t) = exp(m_t,k - M_k) / L_k.
+    // Loads first (raw tile maxima and partials of up to GS_GT tiles per lane), scaling after the barrier that publishes M, L.
+    constexpr int GS_GT = 4;
+    float gm_i[2][GS_GT], gm_j[2][GS_GT], gv[2][GS_GT];
+    if (train) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = g + 16 * q, i = e / KP, j = e % KP;
+            const bool on = e < KP * KP && i <= j && j < K;
+#pragma unroll
+            for (int u = 0; u < GS_GT; ++u) {
+                const int t = lane + 64 * u;
+                const bool ok = on && t < tiles;
+                const float* rec = a.part + (size_t)(ok ? t : 0) * K * PS;
+                gm_i[q][u] = ok ? rec[(size_t)i * PS] : 0.0f;
+                gm_j[q][u] = ok ? rec[(size_t)j * PS] : 0.0f;
+                gv[q][u] = ok ? a.gram_part[(size_t)t * KP * KP + e] : 0.0f;
+            }
+        }
+    }
     __syncthreads();
     for (int di = tid; di < Di; di += 1024) {
         float s = 0.0f;
         for (int kk = 0; kk < K; ++kk) s += af[kk * Di + di];
         bf[di] = s / (float)K;
+    }
+    if (train) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = g + 16 * q, i = e / KP, j = e % KP;
+            if (e >= KP * KP) continue;
+            float s = 0.0f;
+            if (i <= j && j < K) {
+                const float Mi = sc[16 + 2 * i], Mj = sc[16 + 2 * j], iLi = 1.0f / sc[17 + 2 * i], iLj = 1.0f / sc[17 + 2 * j];
+#pragma unroll
+                for (int u = 0; u < GS_GT; ++u)
+                    if (lane + 64 * u < tiles) s = fmaf(gv[q][u], (__expf(gm_i[q][u] - Mi) * iLi) * (__expf(gm_j[q][u] - Mj) * iLj), s);
+                for (int t = lane + 64 * GS_GT; t < tiles; t += 64) {          // bags beyond 64 * GS_GT tiles (N > 32 768)
+                    const float* rec = a.part + (size_t)t * K * PS;
+                    s = fmaf(a.gram_part[(size_t)t * KP * KP + e], (__expf(rec[(size_t)i * PS] - Mi) * iLi) * (__expf(rec[(size_t)j * PS] - Mj) * iLj), s);
+                }
+                s = gs_wsum(s);
+            }
+            if (lane == 0) S[e] = s;
+        }
     }
     __syncthreads();
     // heads (ga_heads_kernel's arithmetic): one wave per output, lanes stride the Di-long dot product
@@ -161,27 +211,10 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             }
         }
     }
-    if (!a.label) return;
-    // softmax statistics of every branch (written by the c == 0 workgroups)
-    if (tid < 2 * K) sc[16 + tid] = __builtin_nontemporal_load(a.stats + tid);
+    if (!train) return;
     __syncthreads();
-    // Gram of the softmax rows from the tile partials: S_ij = sum_t g_t[i][j] f_i(t) f_j(t), f_k(t) = exp(m_t,k - M_k) / L_k
-    for (int e = g; e < KP * KP; e += 16) {
-        const int i = e / KP, j = e % KP;
-        float s = 0.0f;
-        if (i <= j && j < K) {
-            const float Mi = sc[16 + 2 * i], Mj = sc[16 + 2 * j], iLi = 1.0f / sc[17 + 2 * i], iLj = 1.0f / sc[17 + 2 * j];
-            for (int t = lane; t < tiles; t += 64) {
-                const float* rec = a.part + (size_t)t * K * PS;
-                const float fi = __expf(rec[(size_t)i * PS] - Mi) * iLi, fj = __expf(rec[(size_t)j * PS] - Mj) * iLj;
-                s = fmaf(a.gram_part[(size_t)t * KP * KP + e], fi * fj, s);
-            }
-            s = gs_wsum(s);
-        }
-        if (lane == 0) S[e] = s;
-    }
     // cross entropies: wave kk < K = branch kk, wave K = bag head; lane = class
-    const int y = (int)a.label[0];
+    const int y = (int)sc[32];
     if (g <= K && (g < K || a.has_bag_head)) {
         const float* r = g < K ? lsub + g * C : lslide;
         const float v = lane < C ? r[lane] : -INFINITY;
@@ -226,37 +259,43 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
         }
         a.losses[0] = loss0; a.losses[1] = loss1; a.losses[2] = diff; a.losses[3] = loss0 + loss1 + diff;
     }
-    // head gradients, d_afeat and c_k = d_afeat_k . afeat_k   (ga_bwd_heads_kernel's arithmetic)
+    // head gradients, d_afeat and c_k = d_afeat_k . afeat_k   (ga_bwd_heads_kernel's arithmetic); all branches in one sweep:
+    // element e = kk * Di + di, partial c_k per wave through LDS, ONE barrier
     {
         const float* wc = (const float*)(a.packed + a.L.wc_off);
         const float* ws = (const float*)(a.packed + a.L.ws_off);
-        for (int kk = 0; kk < K; ++kk) {
-            float cpart = 0.0f;
-            for (int di = tid; di < Di; di += 1024) {
-                float s = 0.0f;
-                for (int cc = 0; cc < C; ++cc) s = fmaf(wc[((size_t)kk * C + cc) * Di + di], dsub[kk * C + cc], s);
-                if (a.has_bag_head)
-                    for (int cc = 0; cc < C; ++cc) s = fmaf(ws[(size_t)cc * Di + di] * invK, dslide[cc], s);
-                a.d_afeat[(size_t)kk * Di + di] = s;
-                const float afv = af[kk * Di + di];
-                cpart = fmaf(s, afv, cpart);
-                for (int cc = 0; cc < C; ++cc) a.dWc[kk][(size_t)cc * Di + di] = dsub[kk * C + cc] * afv;
-            }
-            cpart = gs_wsum(cpart);
-            __syncthreads();
-            if (lane == 0) smx[g] = cpart;
-            __syncthreads();
-            if (tid == 0) {
-                float s = 0.0f;
-                for (int w = 0; w < 16; ++w) s += smx[w];
-                a.ck[kk] = s;
-            }
-            if (tid < C) a.dbc[kk][tid] = dsub[kk * C + tid];
+        float cp[KP];
+#pragma unroll
+        for (int kk = 0; kk < KP; ++kk) cp[kk] = 0.0f;
+        for (int e = tid; e < K * Di; e += 1024) {
+            const int kk = e / Di, di = e - kk * Di;
+            float s = 0.0f;
+            for (int cc = 0; cc < C; ++cc) s = fmaf(wc[((size_t)kk * C + cc) * Di + di], dsub[kk * C + cc], s);
+            if (a.has_bag_head)
+                for (int cc = 0; cc < C; ++cc) s = fmaf(ws[(size_t)cc * Di + di] * invK, dslide[cc], s);
+            a.d_afeat[e] = s;
+            const float afv = af[e];
+            const float prod = s * afv;
+#pragma unroll
+            for (int q = 0; q < KP; ++q) cp[q] += (q == kk) ? prod : 0.0f;
+            for (int cc = 0; cc < C; ++cc) a.dWc[kk][(size_t)cc * Di + di] = dsub[kk * C + cc] * afv;
+        }
+#pragma unroll
+        for (int q = 0; q < KP; ++q) {
+            const float v = gs_wsum(cp[q]);
+            if (lane == 0) ckp[g * (KP + 3) + q] = v;
         }
         if (a.has_bag_head) {
             for (int di = tid; di < Di; di += 1024)
                 for (int cc = 0; cc < C; ++cc) a.dWs[(size_t)cc * Di + di] = dslide[cc] * bf[di];
             if (tid < C) a.dbs[tid] = dslide[tid];
+        }
+        if (tid < K * C) a.dbc[tid / C][tid % C] = dsub[tid];
+        __syncthreads();
+        if (tid < K) {
+            float s = 0.0f;
+            for (int w = 0; w < 16; ++w) s += ckp[w * (KP + 3) + tid];
+            a.ck[tid] = s;
         }
     }
 }
@@ -349,7 +388,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     t.dWs = dWs; t.dbs = dbs;
     t.status = (mode == ACMIL_MODE_F16X3) ? ctrl + 1 : nullptr;      // only the split-f16 score pass reports a range status
     t.guard_flag = guard_flag;
-    const size_t lds = ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64) * sizeof(float);
+    const size_t lds = ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64 + 16 * 16) * sizeof(float);
     void (*tail)(GaTailArgs) = KP == 1 ? ga_tail_kernel<1> : KP == 5 ? ga_tail_kernel<5> : nullptr;
     if (!tail) return ACMIL_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -239,18 +239,22 @@ __device__ __forceinline__ f32x16 gx_mfma(typename GxT<BF>::V8 a, typename GxT<B
 }
 
 template <bool BF>
+__device__ __forceinline__ void gx_split_pair(float x0, float x1, unsigned& h, unsigned& l) {
+    if constexpr (BF) ga_split_pair_bf16(x0, x1, h, l); else ga_split_pair_f16(x0, x1, h, l);
+}
+
+template <bool BF>
 __device__ __forceinline__ void gx_store_split(char* S, int tid, const float (&reg)[4][4]) {
-    typedef typename GxT<BF>::T T;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const int kq = 4 * (tid & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (tid >> 3) + 32 * i;
-        T h[4], l[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { h[q] = (T)reg[i][q]; l[q] = (T)(reg[i][q] - (float)h[q]); }
-        typedef T tx4 __attribute__((ext_vector_type(4)));
-        *(tx4*)(S + r * GX_LDB + kq * 2) = tx4{h[0], h[1], h[2], h[3]};
-        *(tx4*)(S + 128 * GX_LDB + r * GX_LDB + kq * 2) = tx4{l[0], l[1], l[2], l[3]};
+        unsigned h0, l0, h1, l1;
+        gx_split_pair<BF>(reg[i][0], reg[i][1], h0, l0);
+        gx_split_pair<BF>(reg[i][2], reg[i][3], h1, l1);
+        *(u32x2*)(S + r * GX_LDB + kq * 2) = u32x2{h0, h1};
+        *(u32x2*)(S + 128 * GX_LDB + r * GX_LDB + kq * 2) = u32x2{l0, l1};
     }
 }
 
@@ -303,24 +307,22 @@ __device__ __forceinline__ void gx_load_rows(const void* P, int ld, int r0, int 
 
 template <bool BF, bool PAIRS>
 __device__ __forceinline__ void gx_store_split_rows(char* S, int tid, const float (&reg)[4][4]) {
-    typedef typename GxT<BF>::T T;
-    typedef typename GxT<BF>::V8 V8;
-    V8 h[2], l[2];
+    u32x4 h[2], l[2];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float v = reg[j >> 2][j & 3];
-        const T hv = (T)v;
-        h[j >> 3][j & 7] = hv;
-        l[j >> 3][j & 7] = (T)(v - (float)hv);
+    for (int j = 0; j < 16; j += 2) {
+        unsigned hp, lp;
+        gx_split_pair<BF>(reg[j >> 2][j & 3], reg[(j + 1) >> 2][(j + 1) & 3], hp, lp);
+        h[j >> 3][(j & 7) >> 1] = hp;
+        l[j >> 3][(j & 7) >> 1] = lp;
     }
     if constexpr (PAIRS) {       // registers 0-7: row r, k 0..7; 8-15: row r + 1 (see gx_load_rows, 16-bit operand)
         char* d = S + 2 * (tid & 63) * GX_LDB + 8 * (tid >> 6) * 2;
-        *(V8*)(d) = h[0]; *(V8*)(d + GX_LDB) = h[1];
-        *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + GX_LDB) = l[1];
+        *(u32x4*)(d) = h[0]; *(u32x4*)(d + GX_LDB) = h[1];
+        *(u32x4*)(d + 128 * GX_LDB) = l[0]; *(u32x4*)(d + 128 * GX_LDB + GX_LDB) = l[1];
     } else {
         char* d = S + (tid & 127) * GX_LDB + 16 * (tid >> 7) * 2;
-        *(V8*)(d) = h[0]; *(V8*)(d + 16) = h[1];
-        *(V8*)(d + 128 * GX_LDB) = l[0]; *(V8*)(d + 128 * GX_LDB + 16) = l[1];
+        *(u32x4*)(d) = h[0]; *(u32x4*)(d + 16) = h[1];
+        *(u32x4*)(d + 128 * GX_LDB) = l[0]; *(u32x4*)(d + 128 * GX_LDB + 16) = l[1];
     }
 }
 

@@ -36,11 +36,12 @@ struct WgProb {
 struct WgArgs { WgProb p[2]; int blocks0, K; };
 
 __device__ __forceinline__ void wg_split_store(char* hi_plane, char* lo_plane, int off, const f32x4 v) {
-    bf16x4 h, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { h[q] = (__bf16)v[q]; l[q] = (__bf16)(v[q] - (float)h[q]); }
-    *(bf16x4*)(hi_plane + off) = h;
-    *(bf16x4*)(lo_plane + off) = l;
+    unsigned h0, l0, h1, l1;
+    ga_split_pair_bf16(v[0], v[1], h0, l0);
+    ga_split_pair_bf16(v[2], v[3], h1, l1);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    *(u32x2*)(hi_plane + off) = u32x2{h0, h1};
+    *(u32x2*)(lo_plane + off) = u32x2{l0, l1};
 }
 
 // fragment of a 32-column block (columns c0 .. c0+31 of the plane), k = kb .. kb+15: lane (i = lane & 31, hi = lane >> 5)
