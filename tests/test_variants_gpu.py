@@ -55,10 +55,12 @@ def test_clam_sb(name, size_arg, d, di):
     assert set(m.state_dict()) == set(sd)
     m.load_state_dict(sd); m = m.cuda().eval()
     x = torch.from_numpy(case["x"]).cuda()
-    np.testing.assert_allclose(m(x).cpu().numpy(), case["logits"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(m(x, attention_only=True).cpu().numpy(), case["A_raw"], rtol=0, atol=1e-5)
-    with pytest.raises(NotImplementedError):
-        m(x, label=torch.tensor([1]), instance_eval=True)
+    with torch.no_grad():                                     # fused eval ops
+        np.testing.assert_allclose(m(x).cpu().numpy(), case["logits"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(m(x, attention_only=True).cpu().numpy(), case["A_raw"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m(x).detach().cpu().numpy(), case["logits"], rtol=0, atol=1e-4)      # op-by-op differentiable path
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        m(x, label=torch.tensor([1]), instance_eval=True)      # a training loss: needs gradients enabled
 
 
 def test_generic_blocks_large_bag_vs_oracle():

@@ -77,3 +77,48 @@ def test_ibmil_gradients_match_reference():
     np.testing.assert_allclose(a.detach().cpu().numpy(), case["A"], rtol=0, atol=1e-6)
     assert abs(loss.item() - float(case["loss"])) < 1e-4
     _check_grads(m, case)
+
+
+@pytest.mark.parametrize("name,ncls,d,di,label", [("train_clam_bin_n600_d384_c2", 2, 384, 128, 1), ("train_clam_sub_n500_d512_c3", 3, 512, 256, 2)])
+def test_clam_sb_training_step_matches_reference(name, ncls, d, di, label):
+    """CLAM_SB training forward with the instance-level clustering loss (clam.py:159-197, :130-157) + backward, against the
+    reference's own loss and gradients (dropout=False fixture; bag_weight 0.7 as in the CLAM trainer)."""
+    import torch.nn as nn
+    from acmil_amd.architecture.clam import CLAM_SB
+    case, sd = load_golden(name)
+
+    class Conf:
+        D_feat, D_inner, n_class = d, di, ncls
+    m = CLAM_SB(Conf, size_arg="small", k_sample=8, dropout=False, instance_loss_fn=nn.CrossEntropyLoss())
+    m.load_state_dict(sd); m = m.cuda().train()
+    y = torch.tensor([label]).cuda()
+    logits, inst_loss = m(torch.from_numpy(case["x"]).cuda(), label=y, instance_eval=True)
+    loss = 0.7 * F.cross_entropy(logits, y) + 0.3 * inst_loss
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), case["logits"], rtol=0, atol=1e-4)
+    assert abs(float(inst_loss) - float(case["inst_loss"])) < 1e-4 and abs(float(loss) - float(case["loss"])) < 1e-4
+    for pname, p in m.named_parameters():
+        ref = case["grad." + pname]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()       # unused instance classifiers: no gradient
+        err = np.abs(got - ref).max()
+        assert err <= 3e-3 * max(1e-3, np.abs(ref).max()), "%s: %.3e vs max %.3e" % (pname, err, np.abs(ref).max())
+
+
+def test_clam_sb_dropout_configuration_trains():
+    """dropout=True (the reference default): masks are drawn, every used parameter receives a finite gradient, eval() is unaffected."""
+    from acmil_amd.architecture.clam import CLAM_SB
+
+    class Conf:
+        D_feat, D_inner, n_class = 384, 128, 2
+    torch.manual_seed(0)
+    m = CLAM_SB(Conf, size_arg="small", k_sample=8, dropout=True).cuda().train()
+    x = torch.randn(1, 300, 384, device="cuda")
+    y = torch.tensor([0]).cuda()
+    logits, inst = m(x, label=y, instance_eval=True)
+    (F.cross_entropy(logits, y) + inst).backward()
+    used = [p for n, p in m.named_parameters() if not n.startswith("instance_classifiers.1")]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in used)
+    m.eval()
+    with torch.no_grad():
+        l1, l2 = m(x), m(x)
+    assert torch.equal(l1, l2)
