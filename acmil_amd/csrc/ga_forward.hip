@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "ga_forward_kernel.h"
+#include "ga_train_internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // merge: afeat[k][:] = (sum_t e^{m_t-M} acc_t) / (sum_t e^{m_t-M} l_t), fixed summation order.
@@ -240,6 +241,12 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     if (rc != ACMIL_OK) return rc;
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
+    // merge + heads in one launch (ga_step.hip); per-bag arrival counters = control-block words 8 .. 8 + nbags
+    static_assert(GA_MAX_BATCH == GA_TAIL_MAX_BAGS, "batch limits");
+    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    if (KP <= 5)
+        return ga_tail_eval(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat ? afeat : (float*)((char*)a.part + poff),
+                            bag_feat, has_bag_head, (unsigned*)workspace + 8, st);
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
                            (float*)((char*)a.part + poff), st);
 }

@@ -13,6 +13,8 @@
 //   6 G recompute   7 gate pass (forms the diversity term of dA itself)   8 dpre   9, 10 the two split-K weight gradients
 //   11 one finishing launch (both reduces + gate partial records)
 // All of it is enqueued by one C call: the Python side does one ctypes call instead of ~26 tensor-op wrappers.
+#include <string.h>
+
 #include "ga_train_internal.h"
 
 #define GA_MERGE_GROUPS 16
@@ -30,11 +32,11 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
                                 float* bag_feat, float* h_save, int has_bag_head, void* workspace, void* stream);
 
 struct GaTailArgs {
-    const float* part; int tiles; int K, Di, C, KP;
-    float* afeat;                 // [K][Di] out
-    unsigned* arrive;             // control-block word: zero on entry, zero on exit
+    const float* part; GaTailBatch bt; int K, Di, C, KP;      // tile partials of all bags back to back; bt.start[b] = first tile of bag b
+    float* afeat;                 // [bags][K][Di] out
+    unsigned* arrive;             // control-block words (one per bag): zero on entry, zero on exit
     const char* packed; GaLayout L; int has_bag_head;
-    float *sub_preds, *slide_pred;
+    float *sub_preds, *slide_pred, *bag_feat;                 // [bags][K][C], [bags][C], [bags][Di] (any may be null)
     // ---- training extension
     const int64_t* label; const float* gram_part;
     float *stats, *losses, *d_sub, *d_slide, *coef, *d_afeat, *ck;
@@ -55,7 +57,8 @@ __device__ static inline float gs_wmax(float v) {
     return v;
 }
 
-// grid (K, Di/64), 1024 threads.
+// grid (K, Di/64, bags), 1024 threads.  Eval (label == nullptr): merge + heads of every bag of a batched forward in ONE launch
+// (was ga_merge_kernel + ga_heads_kernel); training: one bag, plus everything listed below.
 // Every workgroup: the fixed-order merge of the pooling partials for 64 features of one branch (same arithmetic and order as
 // ga_merge_kernel, ga_forward.hip), branch statistics from the c == 0 workgroups.  The workgroup that arrives last (which one
 // does not matter: everything below is a function of completed global data, summed in index order) finishes the step's
@@ -66,8 +69,15 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     __shared__ float red[GA_MERGE_GROUPS][66];
     __shared__ float smx[GA_MERGE_GROUPS];
     __shared__ int is_last;
-    const int K = a.K, Di = a.Di, C = a.C, tiles = a.tiles;
-    const int k = blockIdx.x, c = blockIdx.y;
+    const int K = a.K, Di = a.Di, C = a.C;
+    const int k = blockIdx.x, c = blockIdx.y, bag = blockIdx.z;
+    const int tiles = a.bt.start[bag + 1] - a.bt.start[bag];
+    a.part += (size_t)a.bt.start[bag] * K * (2 + Di);
+    a.afeat += (size_t)bag * K * Di;
+    a.arrive += bag;
+    if (a.sub_preds) a.sub_preds += (size_t)bag * K * C;
+    if (a.slide_pred) a.slide_pred += (size_t)bag * C;
+    if (a.bag_feat) a.bag_feat += (size_t)bag * Di;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const size_t PS = 2 + Di;
     {
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
         float s = 0.0f;
         for (int kk = 0; kk < K; ++kk) s += af[kk * Di + di];
         bf[di] = s / (float)K;
+        if (a.bag_feat) a.bag_feat[di] = bf[di];
     }
     if (train) {
 #pragma unroll
@@ -300,6 +311,33 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     }
 }
 
+static size_t gs_tail_lds(int K, int Di) {
+    return ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64 + 16 * 16) * sizeof(float);
+}
+
+static int gs_tail_launch(const GaTailArgs& t, int nbags, hipStream_t st) {
+    const size_t lds = gs_tail_lds(t.K, t.Di);
+    void (*tail)(GaTailArgs) = t.KP == 1 ? ga_tail_kernel<1> : t.KP == 5 ? ga_tail_kernel<5> : nullptr;
+    if (!tail) return ACMIL_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return ACMIL_ERR_LAUNCH;
+    hipLaunchKernelGGL(tail, dim3(t.K, t.Di / 64, nbags), dim3(1024), lds, st, t);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+// eval: merge + heads of a batched forward as one launch (ga_forward.hip).  arrive: nbags zeroed control-block words.
+int ga_tail_eval(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L, float* sub_preds,
+                 float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, unsigned* arrive, hipStream_t st) {
+    GaTailArgs t;
+    memset(&t, 0, sizeof(t));
+    t.part = part;
+    for (int b = 0; b <= GA_TAIL_MAX_BAGS; ++b) t.bt.start[b] = tile_start[b <= nbags ? b : nbags];
+    t.K = L.K; t.Di = L.Di; t.C = L.C; t.KP = (L.K <= 1) ? 1 : (L.K <= 5) ? 5 : 8;
+    t.afeat = afeat; t.arrive = arrive; t.packed = (const char*)packed; t.L = L; t.has_bag_head = has_bag_head;
+    t.sub_preds = sub_preds; t.slide_pred = slide_pred; t.bag_feat = bag_feat;
+    return gs_tail_launch(t, nbags, st);
+}
+
 static size_t gs_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct GsWs { size_t part, h, gram, coef, dsub, dslide, afeat, cand, bwd, total; };
@@ -379,7 +417,9 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     if (rc != ACMIL_OK) return rc;
     // 5 tail
     GaTailArgs t;
-    t.part = part; t.tiles = ga_pool_tiles(N); t.K = K; t.Di = Di; t.C = C; t.KP = KP;
+    memset(&t, 0, sizeof(t));
+    t.part = part; t.K = K; t.Di = Di; t.C = C; t.KP = KP;
+    for (int b = 1; b <= GA_TAIL_MAX_BAGS; ++b) t.bt.start[b] = ga_pool_tiles(N);
     t.afeat = afeat; t.arrive = ctrl + 5; t.packed = (const char*)packed; t.L = ga_layout(D, Di, K, C, mode); t.has_bag_head = has_bag_head;
     t.sub_preds = sub_preds; t.slide_pred = slide_pred; t.label = label; t.gram_part = gram;
     t.stats = (float*)(bws + BL.stats); t.losses = losses; t.d_sub = (float*)(ws + W.dsub); t.d_slide = (float*)(ws + W.dslide);
@@ -388,13 +428,8 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     t.dWs = dWs; t.dbs = dbs;
     t.status = (mode == ACMIL_MODE_F16X3) ? ctrl + 1 : nullptr;      // only the split-f16 score pass reports a range status
     t.guard_flag = guard_flag;
-    const size_t lds = ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64 + 16 * 16) * sizeof(float);
-    void (*tail)(GaTailArgs) = KP == 1 ? ga_tail_kernel<1> : KP == 5 ? ga_tail_kernel<5> : nullptr;
-    if (!tail) return ACMIL_ERR_UNSUPPORTED;
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(tail, dim3(K, Di / 64), dim3(1024), lds, st, t);
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+    rc = gs_tail_launch(t, 1, st);
+    if (rc != ACMIL_OK) return rc;
     // 6-11 backward
     GbRun r;
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;

@@ -4,6 +4,13 @@
 #include "ga_common.h"
 #include "gemm_internal.h"
 
+// ga_step.hip: merge + heads of up to GA_TAIL_MAX_BAGS bags in one launch (the eval forward's finish); arrive = that many zeroed
+// control-block words, left zero
+#define GA_TAIL_MAX_BAGS 16
+struct GaTailBatch { int start[GA_TAIL_MAX_BAGS + 1]; };
+int ga_tail_eval(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L, float* sub_preds,
+                 float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, unsigned* arrive, hipStream_t st);
+
 // ga_train.hip
 int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
                  int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st);
