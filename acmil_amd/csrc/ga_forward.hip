@@ -241,10 +241,11 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     if (rc != ACMIL_OK) return rc;
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
-    // merge + heads in one launch (ga_step.hip); per-bag arrival counters = control-block words 8 .. 8 + nbags
-    static_assert(GA_MAX_BATCH == GA_TAIL_MAX_BAGS, "batch limits");
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
-    if (KP <= 5)
+    // (measured: the single-launch finish of ga_step.hip -- ga_tail_eval -- costs 26 us against 12 us for these two launches at one
+    // bag: its release / acquire fences and the one-workgroup heads outweigh the saved launch; it pays off only where it
+    // replaces the six further launches of a training step.  ACMIL_GA_TAIL_EVAL=1 selects it for experiments.)
+    static const bool tail_eval = getenv("ACMIL_GA_TAIL_EVAL") != nullptr;
+    if (tail_eval && K <= 5)
         return ga_tail_eval(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat ? afeat : (float*)((char*)a.part + poff),
                             bag_feat, has_bag_head, (unsigned*)workspace + 8, st);
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,

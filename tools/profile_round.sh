@@ -20,6 +20,12 @@ python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cf
 python bench.py --batch 1 --no-cpu-baseline > $OUT/bench_b1.json 2>> $OUT/bench_default.log
 run_stats bench_f16x3_b16 --steps 50 --warmup 5 --no-b1 --no-cpu-baseline
 run_stats bench_ga_cfg3 --workload ga_cfg3 --steps 50 --warmup 5 --no-b1 --no-cpu-baseline
+run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
+run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
+run_stats bench_train_n50k --workload train --train-n 50000 --steps 200 --warmup 20 --no-cpu-baseline
+python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
+python bench.py --workload train > $OUT/bench_train_n10k.json 2> $OUT/bench_train.log
+python bench.py --workload train --train-n 50000 > $OUT/bench_train_n50k.json 2>> $OUT/bench_train.log
 python tools/pmc_ga.py --batch 16 --out $OUT/pmc > $OUT/pmc_ga_eval.log 2>&1
 python tools/pmc_ga.py --workload ga_cfg3 --batch 16 --out $OUT/pmc > $OUT/pmc_ga_cfg3.log 2>&1
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
