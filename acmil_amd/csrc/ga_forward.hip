@@ -138,6 +138,10 @@ static int ga_dephase() {
     return env > 0 ? env : 0;
 }
 
+// A/B knob (timing experiments): ACMIL_GA_MEMSET=1 zeroes the control block with a memset ahead of every launch and the
+// kernel skips its end-of-kernel counter reset (the round-2 scheme before the self-resetting block)
+static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
+
 static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
     const int ND = a.L.ND, K = a.L.K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
@@ -236,6 +240,8 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
     a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)((char*)workspace + GA_CTRL_BYTES); a.h_save = nullptr;
     a.tile_counter = nullptr; a.status = nullptr;
     if (ga_use_v2(mode)) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }   // control block, see ga_common.h
+    a.self_reset = ga_memset_mode() ? 0 : 1;
+    if (a.tile_counter && !a.self_reset && hipMemsetAsync(a.tile_counter, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     a.L = ga_layout(D, Di, K, C, mode);
     rc = ga_dispatch(a, mode, x_dtype, true, st);
     if (rc != ACMIL_OK) return rc;
@@ -281,6 +287,8 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     a.nbags = 1; a.packed = (const char*)packed; a.part = workspace ? (float*)((char*)workspace + GA_CTRL_BYTES) : nullptr; a.h_save = h_save;
     a.tile_counter = nullptr; a.status = nullptr;
     if (ga_use_v2(mode) && workspace) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }
+    a.self_reset = ga_memset_mode() ? 0 : 1;
+    if (a.tile_counter && !a.self_reset && hipMemsetAsync(a.tile_counter, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     a.L = ga_layout(D, Di, K, C, mode);
     return ga_dispatch(a, mode, x_dtype, false, st);
 }

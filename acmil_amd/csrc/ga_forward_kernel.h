@@ -47,6 +47,7 @@ struct GaFwdArgs {
     unsigned* tile_counter;   // v2: zeroed word the persistent workgroups draw their next tiles from (null = static striding)
     unsigned* status;         // v2: zeroed word; bit 0 = a bag value, bit 1 = a projected feature h outside the f16 range (or NaN):
                               //     the split-f16 result is then NOT the fp32 result and the caller must redo the bag in fp32 mode
+    int self_reset;  // v2: 1 = the last workgroup leaves the control block's counters at zero (default); 0 = the host memsets (A/B knob)
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
     GaLayout L;
 };

@@ -285,8 +285,7 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 
         // range guard of the split-f16 arithmetic: largest |bag value| this lane converted (as a bit pattern, so that inf and
         // NaN rank above every finite value), largest feature it produced
-        unsigned xmax = 0u;
-        float hmax = 0.0f;
+        unsigned hmax = 0u;
         // ======================================================= GEMM1: h^T = W1 * x^T
         {
             const int ln = ga2_lane();
@@ -319,9 +318,6 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 unsigned h, l;
                 ga2_split_pair(v0, v1, h, l);
                 xhw[j] = h; xlw[j] = l;
-                // range guard on the bit patterns of |x| (orders finite < inf < NaN)
-                const unsigned b0 = __builtin_bit_cast(unsigned, v0) & 0x7fffffffu, b1 = __builtin_bit_cast(unsigned, v1) & 0x7fffffffu;
-                xmax = xmax > b0 ? xmax : b0; xmax = xmax > b1 ? xmax : b1;
             };
             auto split_done = [&](f16x8& h8, f16x8& l8) {
                 if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
@@ -398,14 +394,21 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         // ======================================================= relu + f16 split of h
         // acc1[d][r] holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)].  The empty asm statements keep LLVM from
         // sinking the relu / split into the GEMM2 steps (old and new values live together -> hundreds of spills).
+        // Range guard, once per tile and OUTSIDE the GEMM loop: the largest pre-activation as a bit pattern (orders finite < inf
+        // < NaN).  A bag value outside the f16 range converts to inf in its hi half and turns every feature of its patch into
+        // inf / NaN, so this one test covers the bag values too (checking them inside the loop cost ~9 % of the kernel).
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {     // sign shifted out: magnitudes order as unsigned integers, inf / NaN of either sign on top
+                const unsigned b0 = __builtin_bit_cast(unsigned, acc1[d][r]) << 1, b1 = __builtin_bit_cast(unsigned, acc1[d][r + 1]) << 1;
+                const unsigned m = b0 > b1 ? b0 : b1;
+                hmax = hmax > m ? hmax : m;
+            }
 #pragma unroll
         for (int d = 0; d < ND; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) hmax = fmaxf(hmax, fmaxf(acc1[d][r], acc1[d][r + 1]));
 #pragma unroll
         for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
         f16x8 hh[ND][2], hl[ND][2];
@@ -556,10 +559,10 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         const int row = m0 + i31;
         const bool valid = row < N;
         if (a.status) {
-            // 65504 = largest finite f16; !(x < limit) also catches NaN
-            const bool xbad = valid && xmax >= 0x477fe000u /* 65504.0f */, hbad = valid && !(hmax < 65504.0f);
-            const unsigned bits = (__builtin_amdgcn_ballot_w64(xbad) != 0 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(hbad) != 0 ? 2u : 0u);
-            if (bits != 0 && lane == 0) atomicOr(a.status + 2, bits);  // accumulator word (ballots outside the one-lane branch: all lanes vote)
+            // 65504 = largest finite f16 (the features are split into f16 halves for the second GEMM); inf / NaN rank above it
+            const bool hbad = valid && hmax >= (0x477fe000u << 1) /* |v| >= 65504.0f, inf, NaN */;
+            const unsigned bits = __builtin_amdgcn_ballot_w64(hbad) != 0 ? 2u : 0u;
+            if (bits != 0 && lane == 0) atomicOr(a.self_reset ? a.status + 2 : a.status, bits);  // accumulator word (ballots outside the one-lane branch: all lanes vote)
         }
         constexpr int NS = (KP + 1) / 2;
         float smax[KP], lsum[KP], pe[NS];
@@ -781,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     // The range flags were OR-ed into the accumulator word; the last workgroup moves them to the status word (= the result
     // of THIS launch, overwritten by the next) and clears the accumulator.  vmcnt(0) above + the barrier: every wave's
     // atomicOr has reached L2 before this workgroup counts itself as finished.
-    if (dynamic) {
+    if (dynamic && a.self_reset) {
         __syncthreads();
         if (tid == 0) {
             const unsigned done = atomicAdd(a.tile_counter + 2, 1u);

@@ -100,9 +100,9 @@ def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
 
 
 def _range_status(ws: torch.Tensor) -> torch.Tensor:
-    """Device view of the split-f16 range status word of a GA workspace (control block, word 1).  Non-zero = a bag value
-    (bit 0) or a projected feature (bit 1) left the f16 range / was not finite: the f16x3 result is then not the fp32
-    result.  The word is STICKY (the kernels OR flags in); whoever acts on it clears it (`status.zero_()`).  Reading it
+    """Device view of the split-f16 range status word of a GA workspace (control block, word 1).  Non-zero = a projected
+    feature left the f16 range or was not finite (which is also what a bag value outside the range causes: its hi half
+    converts to inf): the f16x3 result is then not the fp32 result.  The word is STICKY (the kernels OR flags in); whoever acts on it clears it (`status.zero_()`).  Reading it
     (`int(...)`) synchronises; the modules do that, the raw ops do not."""
     return ws[4:8].view(torch.int32)
 

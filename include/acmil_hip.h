@@ -85,9 +85,9 @@ int acmil_ga_pack_weights(const float* W1, const float* Wv, const float* bv, con
  * ABMIL = K 1, has_bag_head 0: its logits are sub_preds[0].
  * workspace: acmil_ga_workspace_bytes(...) bytes, 256-byte aligned (may be NULL for a scores-only call).  The FIRST 256
  *   bytes of every GA workspace (acmil_ga_forward / _forward_batch / _pool / _train_step) are a control block of 32-bit words:
- *   0 tile counter, 1 range status of the most recent split-f16 launch (0 = every bag value and projected feature was inside
- *   the f16 range; bit 0: a bag value, bit 1: a feature was out of range or not finite -- repeat the call with
- *   ACMIL_MODE_F32), 2.. internal counters.  Zero the block ONCE after allocating the workspace (hipMemset); every launch
+ *   0 tile counter, 1 range status of the most recent split-f16 launch (0 = every projected feature was finite and inside the
+ *   f16 range -- which a bag value outside that range never leaves it: its f16 hi half is inf and poisons every feature of
+ *   its patch; non-zero -- repeat the call with ACMIL_MODE_F32), 2.. internal counters.  Zero the block ONCE after allocating the workspace (hipMemset); every launch
  *   leaves its counters at zero, so no memset is needed between launches.  One workspace serves one stream.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
