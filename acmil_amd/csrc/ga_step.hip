@@ -71,17 +71,20 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     __shared__ int is_last;
     const int K = a.K, Di = a.Di, C = a.C;
     const int k = blockIdx.x, c = blockIdx.y, bag = blockIdx.z;
-    const int tiles = a.bt.start[bag + 1] - a.bt.start[bag];
-    a.part += (size_t)a.bt.start[bag] * K * (2 + Di);
-    a.afeat += (size_t)bag * K * Di;
-    a.arrive += bag;
-    if (a.sub_preds) a.sub_preds += (size_t)bag * K * C;
-    if (a.slide_pred) a.slide_pred += (size_t)bag * C;
-    if (a.bag_feat) a.bag_feat += (size_t)bag * Di;
+    // (the argument struct is only READ: writing a member or indexing its pointer arrays dynamically makes hipcc keep a private
+    // copy of it in scratch memory -- 512 B per lane and a 2x slower kernel)
+    const int tile0 = bag == 0 ? 0 : a.bt.start[bag < GA_TAIL_MAX_BAGS ? bag : GA_TAIL_MAX_BAGS];
+    const int tiles = a.bt.start[bag + 1 < GA_TAIL_MAX_BAGS ? bag + 1 : GA_TAIL_MAX_BAGS] - tile0;
+    const float* const part_b = a.part + (size_t)tile0 * K * (2 + Di);
+    float* const afeat_b = a.afeat + (size_t)bag * K * Di;
+    unsigned* const arrive_b = a.arrive + bag;
+    float* const sub_b = a.sub_preds ? a.sub_preds + (size_t)bag * K * C : nullptr;
+    float* const slide_b = a.slide_pred ? a.slide_pred + (size_t)bag * C : nullptr;
+    float* const bagf_b = a.bag_feat ? a.bag_feat + (size_t)bag * Di : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const size_t PS = 2 + Di;
     {
-        const float* base = a.part + (size_t)k * PS;
+        const float* base = part_b + (size_t)k * PS;
         const size_t tstride = (size_t)K * PS;
         float m = -INFINITY;
         for (int t = tid; t < tiles; t += 1024) m = fmaxf(m, base[t * tstride]);
@@ -117,20 +120,25 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             float A = 0.0f, Ls = 0.0f;
 #pragma unroll
             for (int w = 0; w < GA_MERGE_GROUPS; ++w) { A += red[w][lane]; Ls += red[w][64]; }
-            a.afeat[(size_t)k * Di + di] = A / Ls;
-            if (a.stats && c == 0 && lane == 0) { a.stats[2 * k] = M; a.stats[2 * k + 1] = Ls; }
-            __threadfence();                       // release this workgroup's outputs before it counts itself
+            // publish: WRITE-THROUGH (sc1) stores, drained, then the arrival ticket.  No release fence: buffer_wbl2 would write
+            // back every dirty line of the XCD's L2 -- the 10-50 MB of h the score pass just wrote -- and took 10-35 us here.
+            __hip_atomic_store(afeat_b + (size_t)k * Di + di, A / Ls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.stats && c == 0 && lane == 0) {
+                __hip_atomic_store(a.stats + 2 * k, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.stats + 2 * k + 1, Ls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
     __syncthreads();
     if (tid == 0) {
-        const unsigned t = atomicAdd(a.arrive, 1u);
+        const unsigned t = atomicAdd(arrive_b, 1u);
         is_last = (t == gridDim.x * gridDim.y - 1u) ? 1 : 0;
-        if (is_last) atomicExch(a.arrive, 0u);
+        if (is_last) atomicExch(arrive_b, 0u);
     }
     __syncthreads();
     if (!is_last) return;
-    if (tid == 0) __threadfence();                 // acquire the other workgroups' afeat / stats (cache-wide: one lane is enough)
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // drop this CU's L1 (one lane + barrier covers the workgroup)
     __syncthreads();
 
     // ------------------------------------------------------------------ tail (one workgroup, 16 waves)
@@ -149,9 +157,9 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     const float invK = 1.0f / (float)K;
     const bool train = a.label != nullptr;
     if (tid == 0 && a.guard_flag) *a.guard_flag = (a.status && __builtin_nontemporal_load(a.status) != 0u) ? 1.0f : 0.0f;
-    for (int e = tid; e < K * Di; e += 1024) af[e] = __builtin_nontemporal_load(a.afeat + e);
+    for (int e = tid; e < K * Di; e += 1024) af[e] = __hip_atomic_load(afeat_b + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: written sc1 by other CUs
     if (train) {
-        if (tid < 2 * K) sc[16 + tid] = __builtin_nontemporal_load(a.stats + tid);
+        if (tid < 2 * K) sc[16 + tid] = __hip_atomic_load(a.stats + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 2 * K) sc[32] = (float)(int)a.label[0];
     }
     // Gram of the softmax rows from the tile partials: S_ij = sum_t g_t[i][j] f_i(t) f_j(t), f_k(t) = exp(m_t,k - M_k) / L_k.
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             for (int u = 0; u < GS_GT; ++u) {
                 const int t = lane + 64 * u;
                 const bool ok = on && t < tiles;
-                const float* rec = a.part + (size_t)(ok ? t : 0) * K * PS;
+                const float* rec = part_b + (size_t)(ok ? t : 0) * K * PS;
                 gm_i[q][u] = ok ? rec[(size_t)i * PS] : 0.0f;
                 gm_j[q][u] = ok ? rec[(size_t)j * PS] : 0.0f;
                 gv[q][u] = ok ? a.gram_part[(size_t)t * KP * KP + e] : 0.0f;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
         float s = 0.0f;
         for (int kk = 0; kk < K; ++kk) s += af[kk * Di + di];
         bf[di] = s / (float)K;
-        if (a.bag_feat) a.bag_feat[di] = bf[di];
+        if (bagf_b) bagf_b[di] = bf[di];
     }
     if (train) {
 #pragma unroll
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
                 for (int u = 0; u < GS_GT; ++u)
                     if (lane + 64 * u < tiles) s = fmaf(gv[q][u], (__expf(gm_i[q][u] - Mi) * iLi) * (__expf(gm_j[q][u] - Mj) * iLj), s);
                 for (int t = lane + 64 * GS_GT; t < tiles; t += 64) {          // bags beyond 64 * GS_GT tiles (N > 32 768)
-                    const float* rec = a.part + (size_t)t * K * PS;
+                    const float* rec = part_b + (size_t)t * K * PS;
                     s = fmaf(a.gram_part[(size_t)t * KP * KP + e], (__expf(rec[(size_t)i * PS] - Mi) * iLi) * (__expf(rec[(size_t)j * PS] - Mj) * iLj), s);
                 }
                 s = gs_wsum(s);
@@ -217,8 +225,8 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             for (int di = lane; di < Di; di += 64) s = fmaf(w[di], v[di], s);
             s = gs_wsum(s) + b;
             if (lane == 0) {
-                if (o < K * C) { lsub[o] = s; if (a.sub_preds) a.sub_preds[o] = s; }
-                else { lslide[o - K * C] = s; if (a.slide_pred) a.slide_pred[o - K * C] = s; }
+                if (o < K * C) { lsub[o] = s; if (sub_b) sub_b[o] = s; }
+                else { lslide[o - K * C] = s; if (slide_b) slide_b[o - K * C] = s; }
             }
         }
     }
@@ -289,7 +297,10 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             const float prod = s * afv;
 #pragma unroll
             for (int q = 0; q < KP; ++q) cp[q] += (q == kk) ? prod : 0.0f;
-            for (int cc = 0; cc < C; ++cc) a.dWc[kk][(size_t)cc * Di + di] = dsub[kk * C + cc] * afv;
+            float* dw = a.dWc[0];
+#pragma unroll
+            for (int q = 1; q < GS_MAXK; ++q) dw = (kk == q) ? a.dWc[q] : dw;
+            for (int cc = 0; cc < C; ++cc) dw[(size_t)cc * Di + di] = dsub[kk * C + cc] * afv;
         }
 #pragma unroll
         for (int q = 0; q < KP; ++q) {
@@ -301,7 +312,12 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
                 for (int cc = 0; cc < C; ++cc) a.dWs[(size_t)cc * Di + di] = dslide[cc] * bf[di];
             if (tid < C) a.dbs[tid] = dslide[tid];
         }
-        if (tid < K * C) a.dbc[tid / C][tid % C] = dsub[tid];
+        if (tid < K * C) {
+            float* db = a.dbc[0];
+#pragma unroll
+            for (int q = 1; q < GS_MAXK; ++q) db = (tid / C == q) ? a.dbc[q] : db;
+            db[tid % C] = dsub[tid];
+        }
         __syncthreads();
         if (tid < K) {
             float s = 0.0f;

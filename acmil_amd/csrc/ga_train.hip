@@ -62,7 +62,7 @@ __device__ static inline void stkim_merge_wave(const unsigned long long* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * 64 + lane;
-        keys[e] = i < ncand ? __builtin_nontemporal_load(c + i) : 0ull;
+        keys[e] = i < ncand ? __hip_atomic_load(c + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     }
     for (int j = 0; j < k; ++j) {
         unsigned long long best = 0ull;
@@ -110,18 +110,20 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < STKIM_EPT; ++e) best = keys[e] > best ? keys[e] : best;
             const unsigned long long win = block_max_key(best, red, j);
-            if (tid == 0) out[j] = win;
+            if (tid == 0) __hip_atomic_store(out + j, win, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through (sc1): see below
 #pragma unroll
             for (int e = 0; e < STKIM_EPT; ++e)
                 if (keys[e] == win) keys[e] = 0ull;  // 0 = taken / padding
         }
     }
-    // release the candidates, count this block, the last one acquires everybody's
+    // publish the candidates: they were stored write-through (sc1) by this lane, so draining its stores is the release (an
+    // agent release fence would write back every dirty L2 line -- here the scores and the saved h of the score pass);
+    // count this block; the last one reads everybody's candidates with sc1 loads
     if (tid == 0) {
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = atomicAdd(arrive, 1u);
         is_last = (t == (unsigned)(gridDim.x * gridDim.y) - 1u) ? 1 : 0;
-        if (is_last) { __threadfence(); atomicExch(arrive, 0u); }
+        if (is_last) atomicExch(arrive, 0u);
     }
     __syncthreads();
     if (!is_last) return;
