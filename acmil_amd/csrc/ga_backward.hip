@@ -14,6 +14,8 @@
 //   6 dWv, dWu   = dGv^T h, dGu^T h ; dW1 = dpre^T x              (split-K GEMMs over the N patches)
 //   7 reduce     the per-workgroup partials of step 4 in a fixed order
 // Everything heavy is exact-fp32 MFMA (gemm_f32.hip); the row pass is HBM-streaming with one wave per row.
+#include <stdlib.h>
+
 #include "ga_common.h"
 
 #include "ga_train_internal.h"
@@ -223,7 +225,8 @@ GbWs gb_layout(int N, int D, int Di, int K) {
     w.d_afeat = off; off += gb_align((size_t)K * Di * 4);
     w.ck = off;      off += 256;
     w.stats = off;   off += 256;
-    w.part = off;    off += gb_align((size_t)GB_GATE_BLOCKS * (KP * GA_DA + KP + 2 * GA_DA) * 4);
+    const size_t recs = ga_bwd_tile_part_records(N) > GB_GATE_BLOCKS ? ga_bwd_tile_part_records(N) : GB_GATE_BLOCKS;
+    w.part = off;    off += gb_align(recs * (KP * GA_DA + KP + 2 * GA_DA) * 4);
     w.wcat = off;    off += gb_align((size_t)2 * GA_DA * Di * 4);     // [Wv; Wu] as one [2 Da, Di] matrix
     w.bcat = off;    off += gb_align((size_t)2 * GA_DA * 4);
     w.dwcat = off;   off += gb_align((size_t)2 * GA_DA * Di * 4);
@@ -246,6 +249,9 @@ extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K,
 // split-K reduces + the gate pass' partial records).  d_afeat, ck, stats are given (ws regions, filled by the caller).
 // GEMM arithmetic follows the forward mode: exact fp32 MFMA, or split products -- f16 halves for the recomputed
 // pre-activations (forward-sized values), bf16 halves wherever an operand is a gradient (values down to 1e-8).
+// ACMIL_GA_BWD_TILE=0 keeps launches 3-5 separate (A/B measurements); read once
+static bool gb_use_tile() { static const bool v = [] { const char* e = getenv("ACMIL_GA_BWD_TILE"); return !(e && e[0] == '0'); }(); return v; }
+
 int gb_run(const GbRun& r) {
     const int N = r.N, D = r.D, Di = r.Di, K = r.K;
     if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;   // gate pass instances (FPL = Di/64)
@@ -269,31 +275,42 @@ int gb_run(const GbRun& r) {
         hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, r.Wv, r.Wu, r.bv, r.bu, GA_DA * Di, (float*)(ws + L.wcat), (float*)(ws + L.bcat));
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
-    // 3 G = h [Wv;Wu]^T + [bv;bu]
-    GemmArgs gd;
-    rc = gemm_run_deferred(x_fwd, 0, 1, N, 2 * GA_DA, Di, 1.0f, r.h, Di, Wcat, ACMIL_DTYPE_F32, Di, 0.0f, G, 2 * GA_DA, bcat, 0, nullptr, ws + L.gemm, st, &gd);
-    if (rc != ACMIL_OK) return rc;
-    if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;     // K = Di: never split
-    // 4 gate pass
-    GaBwdGateArgs ga;
-    ga.h = r.h; ga.A = r.A_out; ga.dA_ext = r.dA_ext; ga.coef = r.coef; ga.d_afeat = r.d_afeat; ga.ck = r.ck; ga.stats = r.stats; ga.Ww = r.Ww;
-    ga.G = G; ga.dh0 = dpre; ga.part = part; ga.N = N; ga.K = K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
-    const int FPL = Di / 64;
-    const int blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
+    int blocks = 0;
+    // 3-5 as ONE kernel per 64-patch tile when the caller holds the pre-split operands (training step, split arithmetic)
+    rc = ACMIL_ERR_UNSUPPORTED;
+    if (r.w16 && r.wT16 && !r.dA_ext && r.mode != ACMIL_MODE_F32 && gb_use_tile())
+        rc = ga_bwd_tile_launch(r.h, r.A_out, r.stats, r.ck, r.coef, r.Ww, r.d_afeat, bcat, r.w16, r.wT16, G, dpre, part, N, K, Di, st);
+    if (rc == ACMIL_OK) {
+        blocks = (int)ga_bwd_tile_part_records(N);
+    } else if (rc != ACMIL_ERR_UNSUPPORTED) {
+        return rc;
+    } else {
+        // 3 G = h [Wv;Wu]^T + [bv;bu]
+        GemmArgs gd;
+        rc = gemm_run_deferred(x_fwd, 0, 1, N, 2 * GA_DA, Di, 1.0f, r.h, Di, Wcat, ACMIL_DTYPE_F32, Di, 0.0f, G, 2 * GA_DA, bcat, 0, nullptr, ws + L.gemm, st, &gd);
+        if (rc != ACMIL_OK) return rc;
+        if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;     // K = Di: never split
+        // 4 gate pass
+        GaBwdGateArgs ga;
+        ga.h = r.h; ga.A = r.A_out; ga.dA_ext = r.dA_ext; ga.coef = r.coef; ga.d_afeat = r.d_afeat; ga.ck = r.ck; ga.stats = r.stats; ga.Ww = r.Ww;
+        ga.G = G; ga.dh0 = dpre; ga.part = part; ga.N = N; ga.K = K;
+        const int FPL = Di / 64;
+        blocks = (N + 3) / 4 < GB_GATE_BLOCKS ? (N + 3) / 4 : GB_GATE_BLOCKS;
 #define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
-    if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
-    else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
-    else return ACMIL_ERR_UNSUPPORTED;
+        if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
+        else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
+        else return ACMIL_ERR_UNSUPPORTED;
 #undef GB_LAUNCH_GATE
-    if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
-    if (r.WcatT)    // K-contiguous copy of the weights: the operand loads are float4 rows instead of 16 strided scalars per thread
-        rc = gemm_run_deferred(x_grad, 0, 1, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, r.WcatT, ACMIL_DTYPE_F32, 2 * GA_DA, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
-    else
-        rc = gemm_run_deferred(x_grad, 0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, Wcat, ACMIL_DTYPE_F32, Di, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
-    if (rc != ACMIL_OK) return rc;
-    if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+        // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)
+        if (r.WcatT)    // K-contiguous copy of the weights: the operand loads are float4 rows instead of 16 strided scalars per thread
+            rc = gemm_run_deferred(x_grad, 0, 1, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, r.WcatT, ACMIL_DTYPE_F32, 2 * GA_DA, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
+        else
+            rc = gemm_run_deferred(x_grad, 0, 0, N, Di, 2 * GA_DA, 1.0f, G, 2 * GA_DA, Wcat, ACMIL_DTYPE_F32, Di, 1.0f, dpre, Di, nullptr, 2, r.h, ws + L.gemm, st, &gd);
+        if (rc != ACMIL_OK) return rc;
+        if (gd.splits > 1) return ACMIL_ERR_UNSUPPORTED;
+    }
     // 6 weight gradients (contraction over the N patches, split-K): [dWv; dWu] = dS^T h in one product, then dW1
     GemmArgs g1, g2;
     rc = ACMIL_ERR_UNSUPPORTED;
@@ -365,7 +382,7 @@ extern "C" int acmil_ga_backward(const void* x, int x_dtype, int N, const float*
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     GbRun r;
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
-    r.dA_ext = d_A; r.coef = nullptr; r.Wcat = nullptr; r.bcat = nullptr; r.WcatT = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
+    r.dA_ext = d_A; r.coef = nullptr; r.Wcat = nullptr; r.bcat = nullptr; r.WcatT = nullptr; r.w16 = nullptr; r.wT16 = nullptr; r.d_afeat = d_afeat; r.ck = ck; r.stats = stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = ws; r.st = st;
     return gb_run(r);

@@ -17,6 +17,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define GA_WAVES 8          // waves per workgroup (2 per SIMD); each wave owns 32 consecutive patches
 #define GA_ROWS_PER_WG 256  // 8 waves x 32 patches (fused forward tile)
 #define GA_POOL_ROWS 128    // rows per workgroup of the h-streaming pooling kernel (ga_train.hip)
+#define GA_WT_KX 288        // K of the backward's third product (2 Da + 16 extension slots), padded to 32-wide steps (ga_bwd_tile.hip)
 #define GA_FRAG_ROW 1024    // one "fragment row" of the packed weight stream: 64 lanes x 16 B
 
 // Row index inside a 32x32 MFMA C/D tile held by (register r, lane-half hi): the gfx950 C/D map is
@@ -36,7 +37,7 @@ __host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3)
 // ---------------------------------------------------------------------------------------------------
 struct GaLayout {
     int D, Di, K, C, ND, mode;
-    size_t g1_off, g1_rows, g2_off, g2_rows, tab_off, bw_off, wc_off, bc_off, ws_off, bs_off, wcat_off, bcat_off, wcatT_off, total;
+    size_t g1_off, g1_rows, g2_off, g2_rows, tab_off, bw_off, wc_off, bc_off, ws_off, bs_off, wcat_off, bcat_off, wcatT_off, w16_off, wT16_off, total;
 };
 
 __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C, int mode) {
@@ -57,6 +58,8 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
     L.wcat_off = off; off += (size_t)2 * GA_DA * Di * 4;     // [Wv; Wu] as one [2 Da, Di] matrix, [bv; bu]: the backward's
     L.bcat_off = off; off += (size_t)2 * GA_DA * 4;          // single-GEMM operands (ga_backward.hip)
     L.wcatT_off = off; off += (size_t)2 * GA_DA * Di * 4;    // [Wv; Wu]^T [Di][2 Da]: K-contiguous operand of the dpre product
+    L.w16_off = off;   off += (size_t)2 * 2 * GA_DA * Di * 2;    // f16 hi / lo planes of [Wv; Wu] [2 Da][Di]              } operands of the fused
+    L.wT16_off = off;  off += (size_t)2 * Di * GA_WT_KX * 2;     // bf16 hi / lo planes of [[Wv;Wu]^T | d_afeat^T | 0] [Di][288] } backward tile kernel
     L.total = (off + 255) & ~(size_t)255;
     return L;
 }

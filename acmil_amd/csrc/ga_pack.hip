@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
     const int tid = threadIdx.x;
     const int CD = L.C * L.Di;
     if (blockIdx.x > tail_block) {
-        const size_t ncat = (size_t)2 * GA_DA * L.Di, nwc = (size_t)L.K * CD, total = ncat + nwc + CD + ncat;
+        const size_t ncat = (size_t)2 * GA_DA * L.Di, nwc = (size_t)L.K * CD, nT = (size_t)L.Di * GA_WT_KX;
+        const size_t total = ncat + nwc + CD + ncat + ncat + nT;
         float* wcat = (float*)(a.out + L.wcat_off);
         float* wcatT = (float*)(a.out + L.wcatT_off);
         float* wc = (float*)(a.out + L.wc_off);
@@ -110,10 +111,23 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
             if (e < ncat) wcat[e] = e < ncat / 2 ? a.Wv[e] : a.Wu[e - ncat / 2];
             else if (e < ncat + nwc) { const size_t r = e - ncat; wc[r] = a.Wc[r / CD][r % CD]; }
             else if (e < ncat + nwc + CD) { const size_t r = e - ncat - nwc; ws[r] = a.Ws ? a.Ws[r] : 0.0f; }
-            else {      // transposed copy: element (di, u) of [Di][2 Da]
+            else if (e < ncat + nwc + CD + ncat) {      // transposed copy: element (di, u) of [Di][2 Da]
                 const size_t r = e - ncat - nwc - CD;
                 const int di = (int)(r / (2 * GA_DA)), u = (int)(r % (2 * GA_DA));
                 wcatT[r] = u < GA_DA ? a.Wv[(size_t)u * L.Di + di] : a.Wu[(size_t)(u - GA_DA) * L.Di + di];
+            } else if (e < ncat + nwc + CD + 2 * ncat) {  // f16 hi / lo planes of [Wv; Wu] [2 Da][Di]
+                const size_t r = e - ncat - nwc - CD - ncat;
+                const float w = r < ncat / 2 ? a.Wv[r] : a.Wu[r - ncat / 2];
+                _Float16 h, l; split_f16(w, h, l);
+                _Float16* p16 = (_Float16*)(a.out + L.w16_off);
+                p16[r] = h; p16[ncat + r] = l;
+            } else {                                      // bf16 hi / lo planes of [[Wv;Wu]^T | (d_afeat^T: filled by the step's tail kernel) | 0] [Di][288]
+                const size_t r = e - ncat - nwc - CD - 2 * ncat;
+                const int di = (int)(r / GA_WT_KX), u = (int)(r % GA_WT_KX);
+                const float w = u < GA_DA ? a.Wv[(size_t)u * L.Di + di] : u < 2 * GA_DA ? a.Wu[(size_t)(u - GA_DA) * L.Di + di] : 0.0f;
+                const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
+                __bf16* pT = (__bf16*)(a.out + L.wT16_off);
+                pT[r] = h; pT[nT + r] = l;
             }
         }
         return;
@@ -160,7 +174,7 @@ extern "C" int acmil_ga_pack_weights(const float* W1, const float* Wv, const flo
     }
     a.out = (char*)packed;
     a.L = ga_layout(D, Di, K, C, mode);
-    const size_t aux = (size_t)4 * GA_DA * Di + (size_t)K * C * Di + (size_t)C * Di;
+    const size_t aux = (size_t)6 * GA_DA * Di + (size_t)K * C * Di + (size_t)C * Di + (size_t)Di * GA_WT_KX;
     const unsigned blocks = (unsigned)((a.L.g1_rows + a.L.g2_rows + 3) / 4) + 1 + (unsigned)((aux + 1023) / 1024);
     hipLaunchKernelGGL(ga_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;

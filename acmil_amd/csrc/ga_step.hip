@@ -43,6 +43,7 @@ struct GaTailArgs {
     float* dWc[GS_MAXK]; float* dbc[GS_MAXK];
     float *dWs, *dbs;
     const unsigned* status; float* guard_flag;    // range status of the score pass (control block word 1) -> 0 / 1 float flag
+    __bf16* wT16;                                 // packed buffer: d_afeat columns of the backward tile kernel's operand (or null)
 };
 
 // wave-wide sum / max over all 64 lanes
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             if (a.has_bag_head)
                 for (int cc = 0; cc < C; ++cc) s = fmaf(ws[(size_t)cc * Di + di] * invK, dslide[cc], s);
             a.d_afeat[e] = s;
+            if (a.wT16) {      // extension K slot kk of row di of the backward tile kernel's [[Wv;Wu]^T | d_afeat^T] operand (bf16 hi / lo planes)
+                const __bf16 dh = (__bf16)s, dl = (__bf16)(s - (float)dh);
+                a.wT16[(size_t)di * GA_WT_KX + 2 * GA_DA + kk] = dh;
+                a.wT16[(size_t)Di * GA_WT_KX + (size_t)di * GA_WT_KX + 2 * GA_DA + kk] = dl;
+            }
             const float afv = af[e];
             const float prod = s * afv;
 #pragma unroll
@@ -444,6 +450,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     t.dWs = dWs; t.dbs = dbs;
     t.status = (mode == ACMIL_MODE_F16X3) ? ctrl + 1 : nullptr;      // only the split-f16 score pass reports a range status
     t.guard_flag = guard_flag;
+    t.wT16 = (__bf16*)((char*)packed + t.L.wT16_off);
     rc = gs_tail_launch(t, 1, st);
     if (rc != ACMIL_OK) return rc;
     // 6-11 backward
@@ -451,6 +458,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     r.x = x; r.x_dtype = x_dtype; r.N = N; r.h = h; r.A_out = A_out; r.Wv = Wv; r.bv = bv; r.Wu = Wu; r.bu = bu; r.Ww = Ww;
     r.Wcat = (const float*)((const char*)packed + t.L.wcat_off); r.bcat = (const float*)((const char*)packed + t.L.bcat_off);
     r.WcatT = (const float*)((const char*)packed + t.L.wcatT_off);
+    r.w16 = (const char*)packed + t.L.w16_off; r.wT16 = (const char*)packed + t.L.wT16_off;
     r.dA_ext = nullptr; r.coef = (K > 1) ? coef : nullptr; r.d_afeat = t.d_afeat; r.ck = t.ck; r.stats = t.stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = bws; r.st = st;

@@ -25,6 +25,7 @@ struct GbRun {
     const float *h, *A_out, *Wv, *bv, *Wu, *bu, *Ww;
     const float *Wcat, *bcat;   // [Wv; Wu] [2 Da][Di] and [bv; bu] as single operands (packed buffer), or null
     const float* WcatT;         // [Wv; Wu]^T [Di][2 Da] (packed buffer), or null
+    const void *w16, *wT16;     // pre-split operands of the fused backward tile kernel (packed buffer: GaLayout::w16_off / wT16_off), or null
     const float* dA_ext;     // [K][N] external gradient of the scores, or null
     const float* coef;       // [KP][KP] diversity-loss coefficients (ga_loss.hip), or null: that term of dA is formed in the gate pass
     const float *d_afeat, *ck, *stats;   // [K][Di], [K], [K][2] = (max, sum exp) of the masked scores
@@ -41,3 +42,10 @@ size_t wgrad_workspace_bytes(int M1, int N1, int M2, int N2, int K);
 int wgrad_launch(const float* A1, int lda1, const void* B1, int b1_dtype, int ldb1, int M1, int N1, float* C1,
                  const float* A2, int lda2, const void* B2, int b2_dtype, int ldb2, int M2, int N2, float* C2,
                  int K, void* workspace, hipStream_t st, GemmArgs* g1, GemmArgs* g2);
+
+// ga_bwd_tile.hip: G recompute + gate pass + dpre as one kernel per 64-patch tile (needs the pre-split operands of the packed
+// buffer, with the d_afeat columns of wT16 filled); one partial record per tile
+size_t ga_bwd_tile_part_records(int N);
+int ga_bwd_tile_launch(const float* h, const float* A, const float* stats, const float* ck, const float* coef, const float* Ww,
+                       const float* d_afeat, const float* bcat, const void* w16, const void* wT16, float* dS, float* dpre,
+                       float* part, int N, int K, int Di, hipStream_t st);
