@@ -311,7 +311,7 @@ class ACMIL_GA(_GatedBase):
         return losses, out
 
     def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None):
-        """The whole step enqueued by one library call (csrc/ga_step.hip: 11 launches).  The packed weights are rebuilt inside
+        """The whole step enqueued by one library call (csrc/ga_step.hip: 8 launches).  The packed weights are rebuilt inside
         the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
         after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
         dev = xb.device

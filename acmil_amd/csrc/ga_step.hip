@@ -5,13 +5,13 @@
 //   forward   architecture/transformer.py:305-330 (training branch: STKIM :311-320, masked softmax + pooling :322-324, heads :325-330)
 //   loss      Step3_WSI_classification_ACMIL.py:201-216 (branch CE, bag CE, diversity loss)
 //   backward  autograd of the above
-// The step is launch-bound at N = 10 000 (each kernel runs 5-25 us), so what matters is the number of launches and the host
-// time per launch.  Sequence (11 launches; the reference issues ~350 small torch kernels):
-//   1 pack (only when the parameters changed)   2 score pass (fused forward, keeps h)     3 STKIM + mask (single launch)
-//   4 pooling tiles + Gram partials              5 tail: merge | last workgroup: heads, losses, dL/d(logits), head gradients,
-//                                                   d_afeat, c_k, softmax statistics, diversity coefficients
-//   6 G recompute   7 gate pass (forms the diversity term of dA itself)   8 dpre   9, 10 the two split-K weight gradients
-//   11 one finishing launch (both reduces + gate partial records)
+// The step is latency-bound at N = 10 000 (each kernel runs 5-50 us), so what matters is the number of launches and the host
+// time per launch.  Sequence (8 launches; the reference issues ~350 small torch kernels):
+//   1 pack (the parameters changed since the last step)   2 score pass (fused forward, keeps h)   3 STKIM + mask (single launch)
+//   4 pooling tiles + Gram partials      5 tail: merge | last workgroup: heads, losses, dL/d(logits), head gradients,
+//                                           d_afeat, c_k, softmax statistics, diversity coefficients, range flag
+//   6 backward tile kernel (ga_bwd_tile.hip): G recompute + gate pass + dpre per 64-patch tile
+//   7 both split-K weight gradients (wgrad.hip)   8 one finishing launch (both reduces + gate partial records)
 // All of it is enqueued by one C call: the Python side does one ctypes call instead of ~26 tensor-op wrappers.
 #include <string.h>
 

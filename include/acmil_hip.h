@@ -186,7 +186,7 @@ int acmil_ga_backward(const void* x, int x_dtype, int N, const float* h, const f
 /* ---------------------------------------------------------------------------------------------
  * One ACMIL_GA training step for one slide in ONE call: forward with STKIM masking (architecture/transformer.py:305-330,
  * training branch), the ACMIL loss (Step3_WSI_classification_ACMIL.py:201-216) and the backward through both (what
- * loss.backward() computes, Step3_WSI_classification_ACMIL.py:217-218) -- 11 launches enqueued by one host call.
+ * loss.backward() computes, Step3_WSI_classification_ACMIL.py:217-218) -- 8 launches enqueued by one host call.
  *   packed   acmil_ga_packed_bytes(...) device buffer; rewritten from the raw parameters when repack != 0 (call with
  *            repack = 1 whenever the parameters changed since the last step, e.g. after every optimizer step)
  *   W*, b*   raw fp32 parameters (as acmil_ga_pack_weights); d*: their gradients, OVERWRITTEN (not accumulated).
