@@ -58,6 +58,12 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
     const int i31 = lane & 31, hi = lane >> 5;
     const int N = a.N, K = a.K;
     const int n0 = blockIdx.x * BT_ROWS;
+    constexpr int MASK_OFF = (BT_GT_BYTES + 2 * ST3 > BT_GT_BYTES + ST3 + 8 * PREC * 4) ? BT_GT_BYTES + 2 * ST3 : BT_GT_BYTES + ST3 + 8 * PREC * 4;
+    static_assert(MASK_OFF >= 2 * ST1, "the mask outlives the first product's stages");
+    unsigned char* const mask_lds = (unsigned char*)(smem + MASK_OFF);                  // [64 rows][64 bytes]: 4 relu bits per byte
+#ifdef BT_PROF
+    const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+#endif
 
     // ================================================================ 1: G = h W^T + b  (wave w: columns 32 w .. 32 w + 31, all 64 rows)
     f32x16 acc[2];
@@ -80,9 +86,11 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
             rw[S][0] = wp_hi[4 * s]; rw[S][1] = wp_hi[4 * s + 1];
             rw[S][2] = wp_lo[4 * s]; rw[S][3] = wp_lo[4 * s + 1];
         };
-        auto store = [&](auto SET, int stage) {
+        auto store = [&](auto SET, int stage, int step) {
             constexpr int S = decltype(SET)::value;
             char* St = smem + stage * ST1;
+            // relu mask of the tile for the third product's epilogue: 4 bits per thread and step, one byte each (kept past both products)
+            mask_lds[hrow * 64 + 8 * step + hq] = (unsigned char)((rh[S][0] > 0.0f ? 1 : 0) | (rh[S][1] > 0.0f ? 2 : 0) | (rh[S][2] > 0.0f ? 4 : 0) | (rh[S][3] > 0.0f ? 8 : 0));
             unsigned h0, l0, h1, l1;
             ga_split_pair_f16(rh[S][0], rh[S][1], h0, l0);
             ga_split_pair_f16(rh[S][2], rh[S][3], h1, l1);
@@ -121,19 +129,23 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
         static_assert(S1 % 2 == 0 && S1 >= 4, "the loop below is unrolled by two");
         load(BtS0{}, 0);
         load(BtS1{}, 1);
-        store(BtS0{}, 0);
+        store(BtS0{}, 0, 0);
         load(BtS0{}, 2);
         for (int s = 0; s < S1; s += 2) {
-            __syncthreads();                     // stage 0 holds step s; stage 1 (step s - 1) consumed by every wave
-            store(BtS1{}, 1);                    // step s + 1
+            ga_lds_barrier();                     // stage 0 holds step s; stage 1 (step s - 1) consumed by every wave
+            store(BtS1{}, 1, s + 1);             // step s + 1
             if (s + 3 < S1) load(BtS1{}, s + 3);
             compute(0);
-            __syncthreads();
-            if (s + 2 < S1) { store(BtS0{}, 0); if (s + 4 < S1) load(BtS0{}, s + 4); }
+            ga_lds_barrier();
+            if (s + 2 < S1) { store(BtS0{}, 0, s + 2); if (s + 4 < S1) load(BtS0{}, s + 4); }
             compute(1);
         }
     }
-    __syncthreads();                                                 // every wave done with the stages: the fp32 tile takes their place
+    ga_lds_barrier();                                                 // every wave done with the stages: the fp32 tile takes their place
+#ifdef BT_PROF
+    const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+    unsigned long long pt1c = 0;
+#endif
     float* Gt = (float*)smem;
     {
         const int col = 32 * wave + i31;
@@ -183,21 +195,33 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
             const int k = lane >> 3, n = n0 + 8 * wave + (lane & 7);
             if (k < K && n < N) sA = a.A[(size_t)k * N + n];
         }
+        // small per-step tables: ONE vector load each, broadcast by v_readlane (as ~40 scalar loads in unrolled conditional code
+        // they were waited for one by one: ~16 k cycles per tile)
+        static_assert(KP * KP <= 64, "coefficient table fits a wave");
+        const float cfv = (a.coef && lane < KP * KP) ? a.coef[lane] : 0.0f;       // rows / columns >= K are zero in the table
+        const float ckv = lane < K ? a.ck[lane] : 0.0f;
+        const float stv = lane < 2 * K ? a.stats[lane] : 1.0f;
         float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KP][KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const bool on = k < K;
 #pragma unroll
-            for (int j = 0; j < KP; ++j) cf[k][j] = (a.coef && on && j < K) ? a.coef[k * KP + j] : 0.0f;
-#pragma unroll
             for (int f = 0; f < FPL; ++f) daf[k][f] = on ? a.d_afeat[(size_t)k * DI + FPL * lane + f] : 0.0f;
             ww[k][0] = on ? a.Ww[k * GA_DA + 2 * lane] : 0.0f;
             ww[k][1] = on ? a.Ww[k * GA_DA + 2 * lane + 1] : 0.0f;
-            ck[k] = on ? a.ck[k] : 0.0f;
-            Mk[k] = on ? a.stats[2 * k] : 0.0f;
-            iL[k] = on ? 1.0f / a.stats[2 * k + 1] : 0.0f;
         }
-        __syncthreads();                                             // G tile complete (all waves' columns)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+#pragma unroll
+            for (int j = 0; j < KP; ++j) cf[k][j] = ga_readlane(cfv, k * KP + j);
+            ck[k] = ga_readlane(ckv, k);
+            Mk[k] = ga_readlane(stv, (2 * k) & 63);
+            iL[k] = 1.0f / ga_readlane(stv, (2 * k + 1) & 63);
+        }
+        ga_lds_barrier();                                             // G tile complete (all waves' columns)
+#ifdef BT_PROF
+        pt1c = __builtin_amdgcn_s_memtime();
+#endif
         float aWw[KP][2], abw[KP], abv[2] = {0.f, 0.f}, abu[2] = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KP; ++k) { aWw[k][0] = aWw[k][1] = 0.0f; abw[k] = 0.0f; }
@@ -212,9 +236,8 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
                 float dp = 0.0f;
 #pragma unroll
                 for (int f = 0; f < FPL; ++f) dp = fmaf(daf[k][f], hv[rr][f], dp);
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) dp += __shfl_xor(dp, o);
-                const float s = __shfl(sA, 8 * k + rr);
+                dp = ga_wave_sum(dp);
+                const float s = ga_readlane(sA, (8 * k + rr) & 63);
                 const bool masked = !(s > -5e8f);                     // masked_fill(-1e9) positions, padded branches, rows past the bag
                 P[k] = masked ? 0.0f : __expf(s - Mk[k]) * iL[k];
                 dA[k] = masked ? 0.0f : P[k] * (dp - ck[k]);
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
         }
         rec[KP * GA_DA + KP + 2 * lane] = abv[0]; rec[KP * GA_DA + KP + 2 * lane + 1] = abv[1];
         rec[KP * GA_DA + KP + GA_DA + 2 * lane] = abu[0]; rec[KP * GA_DA + KP + GA_DA + 2 * lane + 1] = abu[1];
-        __syncthreads();
+        ga_lds_barrier();
         float* out = a.part + (size_t)blockIdx.x * PREC;
         for (int e = tid; e < PREC; e += BT_THREADS) {
             float t = 0.0f;
@@ -274,6 +297,9 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
             out[e] = t;
         }
     }
+#ifdef BT_PROF
+    const unsigned long long pt2 = __builtin_amdgcn_s_memtime();
+#endif
     store3(BtS0{}, 0);
     load3(BtS0{}, 2);
 
@@ -311,32 +337,35 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
         }
     };
     for (int t = 0; t < S3; t += 2) {
-        __syncthreads();                     // stage 0 holds step t (and, t = 0: dS / P rows written, partial records read)
+        ga_lds_barrier();                     // stage 0 holds step t (and, t = 0: dS / P rows written, partial records read)
         if (t + 1 < S3) { store3(BtS1{}, 1); if (t + 3 < S3) load3(BtS1{}, t + 3); }
         compute3(0, t);
         if (t + 1 >= S3) break;
-        __syncthreads();
+        ga_lds_barrier();
         if (t + 2 < S3) { store3(BtS0{}, 0); if (t + 4 < S3) load3(BtS0{}, t + 4); }
         compute3(1, t + 1);
     }
+#ifdef BT_PROF
+    const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
+#endif
     // relu mask + store: lane = column, registers = rows (128-byte row segments per half wave)
     {
         const int col = 32 * ct + i31;
 #pragma unroll
         for (int m = 0; m < MT3; ++m) {
-            float hm[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 32 * (mt0 + m) + mfma32_row(r, hi);
-                hm[r] = n < N ? a.h[(size_t)n * DI + col] : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + 32 * (mt0 + m) + mfma32_row(r, hi);
-                if (n < N) a.dpre[(size_t)n * DI + col] = hm[r] > 0.0f ? acc3[m][r] : 0.0f;
+                const int row = 32 * (mt0 + m) + mfma32_row(r, hi), n = n0 + row;
+                const bool pos = (mask_lds[row * 64 + (col >> 2)] >> (col & 3)) & 1;
+                if (n < N) a.dpre[(size_t)n * DI + col] = pos ? acc3[m][r] : 0.0f;
             }
         }
     }
+#ifdef BT_PROF
+    if (blockIdx.x == 3 && tid == 0)
+        printf("BT phases (cycles): gemm1 %llu  prefetch+Gt %llu  gate %llu  gemm3 %llu  epilogue %llu  total %llu\n", pt1 - pt0, pt1c - pt1, pt2 - pt1c, pt3 - pt2,
+               __builtin_amdgcn_s_memtime() - pt3, __builtin_amdgcn_s_memtime() - pt0);
+#endif
 }
 
 size_t ga_bwd_tile_part_records(int N) { return (size_t)(N + BT_ROWS - 1) / BT_ROWS; }
@@ -353,10 +382,11 @@ int ga_bwd_tile_launch(const float* h, const float* A, const float* stats, const
     void (*kern)(GbTileArgs) = nullptr;
     size_t lds1 = 0, lds3 = 0;
 #define BT_PICK(KP_, DI_) { kern = ga_bwd_tile_kernel<KP_, DI_>; lds1 = 2 * (2 * BT_ROWS * BT_LDP + 2 * 256 * BT_LDP); lds3 = BT_GT_BYTES + 2 * (2 * DI_ * BT_LDP); \
-                           const size_t rec = BT_GT_BYTES + (2 * DI_ * BT_LDP) + (size_t)8 * (KP_ * GA_DA + KP_ + 2 * GA_DA) * 4; if (rec > lds3) lds3 = rec; }
+                           const size_t rec = BT_GT_BYTES + (2 * DI_ * BT_LDP) + (size_t)8 * (KP_ * GA_DA + KP_ + 2 * GA_DA) * 4; if (rec > lds3) lds3 = rec; \
+                           lds3 += 4096 /* relu mask */; }
     if (KP == 1 && Di == 128) BT_PICK(1, 128) else if (KP == 1) BT_PICK(1, 256) else if (Di == 128) BT_PICK(5, 128) else BT_PICK(5, 256)
 #undef BT_PICK
-    const size_t lds = lds1 > lds3 ? lds1 : lds3;
+    const size_t lds = (lds1 > lds3 ? lds1 : lds3);
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3((unsigned)ga_bwd_tile_part_records(N)), dim3(BT_THREADS), lds, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;

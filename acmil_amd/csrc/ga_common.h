@@ -90,6 +90,36 @@ __device__ static inline float ga_tanh(float v) { return 1.0f - 2.0f * __builtin
 // zero again (the last workgroup resets them), so no memset sits on the stream between launches.
 #define GA_CTRL_BYTES 256
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also waits vmcnt(0),
+// i.e. for every global load in flight -- which turns a "loads issued N steps ahead" pipeline into one full memory latency
+// per step.  A ds_write of loaded data still waits for exactly its own source registers.
+__device__ __forceinline__ void ga_lds_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Sum over the 64 lanes with DPP row operations (VALU, no LDS round trips; a __shfl_xor butterfly is 6 dependent ds_bpermutes):
+// inclusive scan inside each row of 16 (row_shr 1, 2, 4, 8, missing sources read 0), row_bcast15 / row_bcast31 carry the row
+// totals across, lane 63 holds the total, v_readlane broadcasts it.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ga_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float ga_wave_sum(float v) {
+    v = ga_dpp_add<0x111, 0xf>(v);
+    v = ga_dpp_add<0x112, 0xf>(v);
+    v = ga_dpp_add<0x114, 0xf>(v);
+    v = ga_dpp_add<0x118, 0xf>(v);
+    v = ga_dpp_add<0x142, 0xa>(v);
+    v = ga_dpp_add<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float ga_readlane(float v, int l) {      // l must be wave-uniform (a constant after unrolling)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 // ---- hi / lo splits of two fp32 values at a time (packed results: element 0 in the low half-word)
 // f16: hi = rn_f16(x) (packed convert), lo = rn_f16(x - hi) by v_fma_mix{lo,hi}_f16 (f16 source * -1.0 + f32 source, ONE rounding
 // to f16; x - hi is exact in fp32, so this equals the convert / subtract / convert sequence bit for bit): 3 VALU instructions

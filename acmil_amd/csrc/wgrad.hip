@@ -171,11 +171,11 @@ __device__ __forceinline__ void wg_body(const WgProb& P, int K, int tile, int sp
     if (nsteps > 0) store(S0{}, 0);
     if (nsteps > 2) load(S0{}, 2);
     for (int s = 0; s < nsteps; s += 2) {
-        __syncthreads();                    // stage 0 holds step s; stage 1 (step s-1) has been consumed by every wave
+        ga_lds_barrier();                    // stage 0 holds step s; stage 1 (step s-1) has been consumed by every wave
         if (s + 1 < nsteps) { store(S1{}, 1); if (s + 3 < nsteps) load(S1{}, s + 3); }
         compute(0);
         if (s + 1 >= nsteps) break;
-        __syncthreads();
+        ga_lds_barrier();
         if (s + 2 < nsteps) { store(S0{}, 0); if (s + 4 < nsteps) load(S0{}, s + 4); }
         compute(1);
     }
