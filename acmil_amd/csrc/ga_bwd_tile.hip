@@ -183,12 +183,16 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
     {
         // every global value of the wave's 8 rows first: h rows (FPL floats per lane and row) and the K scores of each row
         // (lane 8 k + rr holds A[k][row rr]), then the arithmetic runs from registers / shuffles
+        // (unconditional loads from clamped addresses: as `cond ? load : 0` every one of them became its own exec-masked branch
+        // with a scalar-width load; rows past the bag and branches >= K end up multiplied by P = 0 / dA = 0 anyway)
+        typedef float bt_fv __attribute__((ext_vector_type(FPL)));
         float hv[8][FPL];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
             const int n = n0 + 8 * wave + rr;
+            const bt_fv v = *(const bt_fv*)(a.h + (size_t)(n < N ? n : N - 1) * DI + FPL * lane);
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) hv[rr][f] = n < N ? a.h[(size_t)n * DI + FPL * lane + f] : 0.0f;
+            for (int f = 0; f < FPL; ++f) hv[rr][f] = v[f];
         }
         float sA = -INFINITY;
         {
@@ -204,11 +208,13 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
         float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KP][KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const bool on = k < K;
+            const int kc = k < K ? k : 0;
+            const bt_fv dv = *(const bt_fv*)(a.d_afeat + (size_t)kc * DI + FPL * lane);
 #pragma unroll
-            for (int f = 0; f < FPL; ++f) daf[k][f] = on ? a.d_afeat[(size_t)k * DI + FPL * lane + f] : 0.0f;
-            ww[k][0] = on ? a.Ww[k * GA_DA + 2 * lane] : 0.0f;
-            ww[k][1] = on ? a.Ww[k * GA_DA + 2 * lane + 1] : 0.0f;
+            for (int f = 0; f < FPL; ++f) daf[k][f] = dv[f];
+            typedef float bt_f2 __attribute__((ext_vector_type(2)));
+            const bt_f2 wv = *(const bt_f2*)(a.Ww + kc * GA_DA + 2 * lane);
+            ww[k][0] = wv[0]; ww[k][1] = wv[1];
         }
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(BT_THREADS) void ga_bwd_tile_kernel(GbTileArgs a) {
             for (int j = 0; j < KP; ++j) cf[k][j] = ga_readlane(cfv, k * KP + j);
             ck[k] = ga_readlane(ckv, k);
             Mk[k] = ga_readlane(stv, (2 * k) & 63);
-            iL[k] = 1.0f / ga_readlane(stv, (2 * k + 1) & 63);
+            iL[k] = __builtin_amdgcn_rcpf(ga_readlane(stv, (2 * k + 1) & 63));
         }
         ga_lds_barrier();                                             // G tile complete (all waves' columns)
 #ifdef BT_PROF
