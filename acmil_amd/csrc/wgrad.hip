@@ -14,6 +14,7 @@
 //     the MFMAs of step s share one barrier per step (two LDS stages);
 //   * split-K over the patches, partials [split][M][N] finished by gemm_finish_kernel (fixed order, gemm_f32.hip); BOTH
 //     products are one launch (the grid is the concatenation of their (tile, split) lists).
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 
@@ -206,10 +207,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgArgs a) {
     else wg_body<ACMIL_DTYPE_BF16>(P, a.K, tile, split, smem);
 }
 
-// K split shared by both products: about one workgroup per CU over the two tile lists, at least 4 K steps per workgroup
+// K split shared by both products: about two workgroups per CU over the two tile lists, at least 4 K steps per workgroup
+static int wg_target_wgs() { static const int v = [] { const char* e = getenv("ACMIL_WGRAD_WGS"); return e ? atoi(e) : 512; }(); return v > 0 ? v : 512; }   // two workgroups per CU (measured 256..768: 512 is 24 us faster than 256 at N = 50 000)
 static int wg_pick_splits(int tiles_total, int K) {
     const int steps = (K + 31) / 32;
-    int s = (256 + tiles_total - 1) / tiles_total;
+    int s = (wg_target_wgs() + tiles_total - 1) / tiles_total;
     if (s > steps / 4) s = steps / 4;
     if (s > 128) s = 128;
     return s < 2 ? 0 : s;           // 0: not worth it (tiny bag) -> the caller keeps the generic path
