@@ -46,6 +46,17 @@ def test_size_queries_and_argument_validation(lib):
     assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 9, 2, 0, None, None, None, None, None, None, 1, None, None) == -2
     assert lib.acmil_stkim_select(None, 100, 5, 200, 0, None, None, None, None, None) == -1   # k > N
     assert lib.acmil_stkim_workspace_bytes(50000, 5, 10) >= 5 * 13 * 10 * 8
+    # the one-call training step: workspace covers the saved h, the scores' partials and the backward scratch; bad arguments
+    # come back as codes
+    ws = lib.acmil_ga_train_step_workspace_bytes(10000, 512, 256, 5, 7, 10)
+    assert ws >= 10000 * 256 * 4 * 2 + 10000 * 256 * 4 and ws % 256 == 0
+    assert lib.acmil_ga_train_step_workspace_bytes(0, 512, 256, 5, 7, 10) == 0
+    args = [None, 0, 100, None, 1] + [None] * 7 + [None, None, None, None] + [None] * 7 + [None, None, None, None]
+    assert lib.acmil_ga_train_step(*args, 512, 256, 128, 5, 7, 1, None, None, 10, 6, None, None, None, None, None, None, None, None, None) == -3
+    assert lib.acmil_ga_train_step(*args, 512, 256, 128, 5, 7, 1, None, None, 200, 6, None, None, None, None, None, None, None, None, None) == -1   # k_top > N
+    assert lib.acmil_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, None, None) == -3
+    assert lib.acmil_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, None) == -1          # step ordinals start at 1
+    assert lib.acmil_linear_packed_bytes(256, 1024) > 0 and lib.acmil_linear_packed_bytes(100, 1024) == 0                   # n_out % 128
 
 
 def test_modules_mirror_reference_surface():
