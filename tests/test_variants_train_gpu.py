@@ -96,7 +96,7 @@ def test_clam_sb_training_step_matches_reference(name, ncls, d, di, label):
     loss = 0.7 * F.cross_entropy(logits, y) + 0.3 * inst_loss
     loss.backward()
     np.testing.assert_allclose(logits.detach().cpu().numpy(), case["logits"], rtol=0, atol=1e-4)
-    assert abs(float(inst_loss) - float(case["inst_loss"])) < 1e-4 and abs(float(loss) - float(case["loss"])) < 1e-4
+    assert abs(float(inst_loss.detach()) - float(case["inst_loss"])) < 1e-4 and abs(float(loss.detach()) - float(case["loss"])) < 1e-4
     for pname, p in m.named_parameters():
         ref = case["grad." + pname]
         got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()       # unused instance classifiers: no gradient
@@ -122,3 +122,34 @@ def test_clam_sb_dropout_configuration_trains():
     with torch.no_grad():
         l1, l2 = m(x), m(x)
     assert torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("name,merge,learn", [("train_ibmil_conf_cat_learn_n700_d384_c3", "cat", True),
+                                              ("train_ibmil_conf_sub_fixed_n700_d384_c3", "sub", False)])
+def test_ibmil_confounder_branch_matches_reference(name, merge, learn, tmp_path):
+    """IBMIL with the deconfounding stage (ibmil.py:45-67, :93-107): eval outputs and one forward + backward against the
+    reference's fixture; the confounder dictionary is a learnable parameter (c_learn) or a buffer."""
+    from acmil_amd.architecture.ibmil import IBMIL
+    case, sd = load_golden(name)
+    cpath = str(tmp_path / "conf.npy")
+    np.save(cpath, sd["confounder_feat"].numpy())
+
+    class Conf:
+        D_feat, D_inner, n_class, c_path, c_learn = 384, 128, 3, [cpath], learn
+    m = IBMIL(Conf, confounder_merge=merge)
+    assert set(m.state_dict()) == set(sd)
+    m.load_state_dict(sd); m = m.cuda()
+    x = torch.from_numpy(case["x"]).cuda()
+    m.eval()
+    with torch.no_grad():
+        y, mm, da = m(x)
+    np.testing.assert_allclose(y.cpu().numpy(), case["Y_prob"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(mm.cpu().numpy(), case["M"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(da.cpu().numpy(), case["deconf_A"], rtol=0, atol=1e-6)
+    m.train()
+    y, mm, da = m(x)
+    loss = F.cross_entropy(y, torch.tensor([2]).cuda()) + 0.01 * mm.sum() + 3.0 * (da * da).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(case["loss"])) < 1e-4
+    assert ("confounder_feat" in dict(m.named_parameters())) == learn
+    _check_grads(m, case)
