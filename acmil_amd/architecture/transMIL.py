@@ -113,11 +113,14 @@ class TransMIL(nn.Module):
         return AG.linear(cls, self._fc2.weight, self._fc2.bias, precision="fp32")
 
     def forward(self, input, debug=False):
-        """input [B=1, N, D_feat] -> logits [1, C]  (transMIL.py:60-91)."""
-        if input.dim() != 3 or input.shape[0] != 1:
-            raise RuntimeError("acmil_amd: TransMIL expects input [1, N, D_feat]")
+        """input [B, N, D_feat] -> logits [B, C]  (transMIL.py:60-91).  Every stage of the reference acts per batch element
+        (token-wise Linear / LayerNorm, attention and PPEG per bag), so B > 1 is the B = 1 pipeline once per bag."""
+        if input.dim() != 3 or input.shape[0] < 1:
+            raise RuntimeError("acmil_amd: TransMIL expects input [B, N, D_feat]")
         if not input.is_cuda:
             raise RuntimeError("acmil_amd: TransMIL runs on an MI355X only (no CPU fallback)")
+        if input.shape[0] > 1:
+            return torch.cat([self.forward(input[b:b + 1], debug=debug) for b in range(input.shape[0])], dim=0)
         if torch.is_grad_enabled() and (self.training or any(p.requires_grad for p in self.parameters())):
             return self._forward_train(input[0])
         if self.training:

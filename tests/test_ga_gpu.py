@@ -253,3 +253,19 @@ def test_f16_range_guard_training_step():
         grads.append([p.grad.clone() for p in m.parameters()])
     for a, b in zip(*grads):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["ga_eval_n257_d512_k5_c2", "ga_eval_n1000_d384_k5_c7"])
+def test_single_pass_f16_throughput_mode_has_its_stated_tolerance(name):
+    """precision='f16' (one f16 MFMA product per fp32 product, fp32 accumulate) is a THROUGHPUT mode: documented tolerance
+    5e-4 on raw scores and 2e-3 on logits against the reference's fp32 outputs (measured ~1.6e-4 / ~3e-4) -- outside the 1e-4
+    parity bound, never the default, never used for a parity claim (bench.py --precision f16 labels its line accordingly)."""
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    case, sd = load_golden(name)
+    d, di, k, c = case_dims(sd)
+    m = _build(sd, k, c, d, di, "f16").eval()
+    with torch.no_grad():
+        sub, slide, a = m(torch.from_numpy(case["x"]).float().cuda())
+    assert (a.cpu().numpy() - case["A_out"]).__abs__().max() < 5e-4
+    assert (sub.cpu().numpy() - case["sub_preds"]).__abs__().max() < 2e-3 and (slide.cpu().numpy() - case["slide_pred"]).__abs__().max() < 2e-3
+    assert torch.isfinite(a).all()

@@ -92,3 +92,19 @@ def test_random_shapes_vs_oracle(n, d, di, c):
     assert (model._last["h1"].cpu() - ref["h1"][0]).abs().max() < 1e-4
     assert (model._last["h2"].cpu() - ref["h2"][0]).abs().max() < 1e-4
     assert (logits.cpu() - ref["logits"]).abs().max() < 1e-4
+
+
+def test_batch_of_bags_equals_per_bag_and_oracle():
+    """B > 1 (the reference accepts it, transMIL.py:60-91; every shipped config uses B = 1): logits [B, C], each row the
+    per-bag result, and equal to the oracle run on the batch."""
+    from oracle import transmil_oracle as TO
+    d, di, c = 384, 128, 3
+    sd = TO.default_state_dict(d, di, c, seed=5)
+    x = torch.randn(3, 500, d, generator=torch.Generator().manual_seed(11))
+    model = _model(sd, d, di, c)
+    with torch.no_grad():
+        lb = model(x.cuda())
+        l1 = torch.cat([model(x[b:b + 1].cuda()) for b in range(3)], 0)
+    assert lb.shape == (3, c) and torch.equal(lb, l1)
+    ref = torch.cat([TO.transmil_forward(x[b:b + 1], sd)["logits"] for b in range(3)], 0)
+    assert (lb.cpu() - ref).abs().max() < 1e-4
