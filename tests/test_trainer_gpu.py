@@ -227,3 +227,33 @@ def test_train_one_epoch_repeats_a_flagged_bag_in_fp32():
             opt2.step()
     for (n, pm), pt in zip(model.named_parameters(), twin.parameters()):
         assert (pm - pt).abs().max().item() <= 2e-5 * max(1.0, pt.abs().max().item()), n
+
+
+def test_rccl_single_rank_bucket_allreduce_and_broadcast():
+    """The collective calls of the data-parallel path on a real RCCL communicator (one rank: a multi-GPU node is not part of
+    the test hardware): `torch.distributed` backend nccl = RCCL, parameter broadcast, the flat gradient bucket INCLUDING its
+    range-flag slot through all_reduce, then the optimizer launch on the same buffer."""
+    import socket
+    import torch.distributed as dist
+    from acmil_amd import train as T
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this interpreter")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        T2, conf, dev, model, bucket, opt = _guard_setup(seed=5)
+        T.broadcast_parameters(model, world=2)                     # world > 1 takes the collective branch; the group has one rank
+        x = torch.randn(1, 600, 384, device=dev).half()
+        y = torch.tensor([2], device=dev)
+        model.train_step(x, y, guard_flag=opt.guard_flag)
+        bucket.sync_from_grads()
+        before = bucket.flat.clone()
+        dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)         # what GradBucket.allreduce_mean issues
+        torch.cuda.synchronize()
+        assert torch.equal(bucket.flat, before) and float(bucket.flag) == 0.0
+        p0 = opt.flat.clone()
+        opt.step(track_flag=True)
+        assert opt.poll_skipped(0) == [] and not torch.equal(opt.flat, p0)
+    finally:
+        dist.destroy_process_group()
