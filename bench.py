@@ -263,7 +263,7 @@ def other_workloads(args):
         "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
                                "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,
                    "sharding": "slide-level data parallel: one bag per rank, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)"},
-        "roofline": {"kernel": "whole step (~45 launches)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
+        "roofline": {"kernel": "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
                      "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
                      "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4), "traffic": None,
                      "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
