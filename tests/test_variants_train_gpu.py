@@ -153,3 +153,54 @@ def test_ibmil_confounder_branch_matches_reference(name, merge, learn, tmp_path)
     assert abs(float(loss.detach()) - float(case["loss"])) < 1e-4
     assert ("confounder_feat" in dict(m.named_parameters())) == learn
     _check_grads(m, case)
+
+
+def test_dtfd_double_tier_step_matches_reference():
+    """One slide through acmil_amd.dtfd.train_step against the REAL reference's train_one_epoch
+    (Step3_WSI_classification_DTFD.py:61-160): same patch permutation, both losses, every module's gradient as backward left
+    it (captured ahead of the reference's clip_grad_norm_), and the parameters after the two Adam steps."""
+    import torch.nn as nn
+    from acmil_amd import dtfd, train as T
+    z = np.load("tests/golden/train_dtfd_step_n900_d384_c3.npz")
+    conf = T.Struct(D_feat=384, D_inner=128, n_class=3, numGroup=4, total_instance=8, grad_clipping=5.0, lr=1e-3, wd=1e-5)
+    mods = dict(zip(("classifier", "attention", "dimReduction", "attCls"), dtfd.build_dtfd(conf)))
+    for name, m in mods.items():
+        m.load_state_dict({k[len("before." + name) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("before." + name + ".")})
+        m.cuda().train()
+    grads = {}
+    real_clip = nn.utils.clip_grad_norm_
+
+    def spy(params, max_norm, *a, **k):
+        params = list(params)
+        for name, m in mods.items():
+            own = list(m.parameters())
+            if len(own) == len(params) and all(p is q for p, q in zip(own, params)):
+                for (pn, _), p in zip(m.named_parameters(), params):
+                    grads["grad.%s.%s" % (name, pn)] = p.grad.detach().cpu().numpy().copy()
+        return real_clip(params, max_norm, *a, **k)
+    nn.utils.clip_grad_norm_ = spy
+    try:
+        opt0, opt1 = dtfd.make_optimizers(mods["classifier"], mods["attention"], mods["dimReduction"], mods["attCls"], conf)
+        l0, l1 = dtfd.train_step(mods["classifier"], mods["attention"], mods["dimReduction"], mods["attCls"],
+                                 torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["label"]).cuda(), opt0, opt1, conf,
+                                 perm=torch.from_numpy(z["perm"]).cuda())
+    finally:
+        nn.utils.clip_grad_norm_ = real_clip
+    assert abs(float(l0) - float(z["loss0"])) < 1e-4 and abs(float(l1) - float(z["loss1"])) < 1e-4
+    assert len(grads) == 17
+    for k, g in grads.items():
+        ref = z[k]
+        assert np.abs(g - ref).max() <= 3e-3 * max(1e-3, np.abs(ref).max()), k
+    # Adam's first step moves an element by lr * g / (|g| + 1e-8) ~ lr * sign(g): compare where |g| is well above that eps
+    for name, m in mods.items():
+        for pn, p in m.named_parameters():
+            ref, g = z["after.%s.%s" % (name, pn)], z["grad.%s.%s" % (name, pn)]
+            sure = np.abs(g) > 1e-6
+            if sure.any():
+                assert np.abs(p.detach().cpu().numpy() - ref)[sure].max() < 5e-5, (name, pn)
+
+
+def test_dtfd_trainer_main_runs_and_predicts():
+    from acmil_amd import dtfd
+    best = dtfd.main(["--synthetic_slides", "8", "--synthetic_patches", "400", "--train_epoch", "1", "--n_class", "2"])
+    assert set(best) == {"epoch", "val_auc", "val_f1"} and 0.0 <= best["val_auc"] <= 1.0
