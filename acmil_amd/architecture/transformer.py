@@ -280,8 +280,9 @@ class ACMIL_GA(_GatedBase):
     @torch.no_grad()
     def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None, guard_flag: Optional[torch.Tensor] = None,
                    precision: Optional[str] = None):
-        """One fused training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), fused ACMIL loss
-        (acmil_ga_loss) and HIP backward, writing the gradients into `p.grad` (allocated on first use, overwritten).
+        """One training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), the ACMIL loss and the HIP
+        backward, writing the gradients into `p.grad` (allocated on first use, overwritten) -- ONE library call
+        (acmil_ga_train_step) at the fused widths D_inner 128 / 256, the stand-alone kernels op by op at 384 / 512 / 768.
         Same mathematics as `loss = diff + loss0 + loss1; loss.backward()` of the reference's train_one_epoch
         (Step3_WSI_classification_ACMIL.py:200-219); the optimiser step stays with the caller.
         x [1,N,D_feat], label [1] int64 on the GPU.  Returns (losses [4] = loss0, loss1, diff_loss, total, on device; outputs dict).
