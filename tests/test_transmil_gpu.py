@@ -108,3 +108,27 @@ def test_batch_of_bags_equals_per_bag_and_oracle():
     assert lb.shape == (3, c) and torch.equal(lb, l1)
     ref = torch.cat([TO.transmil_forward(x[b:b + 1], sd)["logits"] for b in range(3)], 0)
     assert (lb.cpu() - ref).abs().max() < 1e-4
+
+
+def test_reference_parity_at_the_baseline_width():
+    """TransMIL at BASELINE configs[3]'s width (D = 768, D_inner = 384) and at D_inner = 256 against outputs of the REAL reference
+    (tests/golden/make_golden_transmil_wide.py).  Weights and bags are regenerated from the seeds the generator used, the
+    fixture holds the reference's logits, class-token rows and stage statistics."""
+    from oracle import transmil_oracle as TO
+    z = np.load("tests/golden/transmil_eval_wide.npz")
+    keys = sorted({k.split(".")[0] for k in z.files})
+    assert len(keys) == 3
+    for key in keys:
+        n, d, di, c, wseed, xseed = [int(v) for v in z[key + ".meta"]]
+        sd = TO.default_state_dict(d, di, c, seed=wseed)
+        x = torch.randn(1, n, d, generator=torch.Generator().manual_seed(xseed))
+        model = _model(sd, d, di, c)
+        with torch.no_grad():
+            logits = model(x.cuda(), debug=True)
+        np.testing.assert_allclose(logits.cpu().numpy(), z[key + ".logits"], rtol=0, atol=1e-4, err_msg=key)
+        for stage in ("h1", "hp", "h2"):
+            got = model._last[stage]
+            np.testing.assert_allclose(got[0].cpu().numpy(), z["%s.%s_cls" % (key, stage)], rtol=0, atol=1e-4, err_msg=key + stage)
+            ref_stat = z["%s.%s_stat" % (key, stage)]
+            stat = np.array([float(got.mean()), float(got.abs().mean()), float(got.abs().max())])
+            np.testing.assert_allclose(stat, ref_stat, rtol=1e-4, atol=1e-5, err_msg=key + stage)
