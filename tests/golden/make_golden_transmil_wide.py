@@ -30,7 +30,7 @@ class Conf:
 
 cases = {}
 torch.set_num_threads(8)
-for n, d, di, c, wseed, xseed in [(700, 768, 384, 2, 21, 701), (3000, 768, 384, 2, 21, 702), (900, 512, 256, 3, 22, 703)]:
+for n, d, di, c, wseed, xseed in [(700, 768, 384, 2, 21, 701), (3000, 768, 384, 2, 21, 702), (900, 512, 256, 3, 22, 703), (100000, 768, 384, 2, 21, 704)]:
     sd = TO.default_state_dict(d, di, c, seed=wseed)
     model = TransMIL(Conf(D_feat=d, D_inner=di, n_class=c)).eval()
     model.load_state_dict(sd)

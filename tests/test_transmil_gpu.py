@@ -117,7 +117,7 @@ def test_reference_parity_at_the_baseline_width():
     from oracle import transmil_oracle as TO
     z = np.load("tests/golden/transmil_eval_wide.npz")
     keys = sorted({k.split(".")[0] for k in z.files})
-    assert len(keys) == 3
+    assert len(keys) == 4       # incl. BASELINE configs[3] itself: N = 100 000
     for key in keys:
         n, d, di, c, wseed, xseed = [int(v) for v in z[key + ".meta"]]
         sd = TO.default_state_dict(d, di, c, seed=wseed)
