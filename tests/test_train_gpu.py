@@ -246,3 +246,27 @@ def test_fused_loss_matches_torch_autograd():
     assert (d_sub - sub.grad).abs().max() < 1e-6 and (d_slide - slide.grad[0]).abs().max() < 1e-6
     assert (d_A - attn.grad[0]).abs().max() <= 1e-4 * attn.grad.abs().max() + 1e-10
     assert d_A[1, 17] == 0 and d_A[3, 99] == 0
+
+
+@pytest.mark.parametrize("n,reps", [(130, 60), (3000, 60), (10000, 25)])
+def test_one_call_step_is_bitwise_reproducible(n, reps):
+    """The single-launch kernels of the training step hand data between workgroups inside a launch (arrival tickets,
+    write-through publishes, self-resetting counters).  Every reduction is fixed-order and atomics only count arrivals, so the
+    same step repeated must give bitwise identical losses, scores, indices and gradients -- a stale read or a lost reset shows
+    up here (tools/stress_train_step.py is the long version)."""
+    from acmil_amd import synthetic as S, train as T
+    conf = T.Struct(train_epoch=50, warmup_epoch=0, wd=1e-5, lr=1e-4, min_lr=0, n_class=7, n_token=5, n_masked_patch=10,
+                    mask_drop=0.6, arch="ga", precision="f16x3", seed=1, D_feat=512, D_inner=256)
+    torch.manual_seed(0)
+    model = T.build_model(conf).cuda().train()
+    x = S.synthetic_bag(n, 512, slide_idx=2)[0].half().cuda().unsqueeze(0)
+    y = torch.tensor([3]).cuda()
+    u = torch.rand(5, 10, generator=torch.Generator().manual_seed(n)).cuda()
+    ref = None
+    for r in range(reps):
+        losses, out = model.train_step(x, y, uniforms=u)
+        cur = [losses.clone(), out["A_out"].clone(), out["sub_preds"].clone(), out["masked_idx"].clone()] + [p.grad.clone() for p in model.parameters()]
+        if ref is None:
+            ref = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur)), "repeat %d differs" % r
