@@ -3,8 +3,8 @@ import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from acmil_amd import ops
-from oracle import ga_oracle as O
-sd = {k: v.cuda() for k, v in O.default_state_dict(512, 256, 2, 5).items()}
+from acmil_amd import synthetic as SY
+sd = {k: v.cuda() for k, v in SY.ga_state_dict(512, 256, 2, 5).items()}
 packed, dims = ops.ga_pack_weights(sd["dimreduction.fc1.weight"], sd["attention.attention_V.0.weight"], sd["attention.attention_V.0.bias"],
     sd["attention.attention_U.0.weight"], sd["attention.attention_U.0.bias"], sd["attention.attention_weights.weight"],
     sd["attention.attention_weights.bias"], [sd["classifier.%d.fc.weight" % i] for i in range(5)],

@@ -20,10 +20,10 @@ DEFAULT = ("v1w4:ACMIL_GA_KERNEL=1,ACMIL_GA_WAVES=4;v1w8:ACMIL_GA_KERNEL=1,ACMIL
 def child(args):
     import torch
     from acmil_amd import ops
-    from oracle import ga_oracle as O
+    from acmil_amd import synthetic as SY
     dev = "cuda"
     K, C = args.k, args.c
-    sd = {k: v.to(dev) for k, v in O.default_state_dict(args.d, args.di, C, K).items()}
+    sd = {k: v.to(dev) for k, v in SY.ga_state_dict(args.d, args.di, C, K).items()}
     packed, dims = ops.ga_pack_weights(
         sd["dimreduction.fc1.weight"], sd["attention.attention_V.0.weight"], sd["attention.attention_V.0.bias"],
         sd["attention.attention_U.0.weight"], sd["attention.attention_U.0.bias"], sd["attention.attention_weights.weight"],

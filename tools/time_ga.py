@@ -3,7 +3,7 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from acmil_amd import ops, _lib
-from oracle import ga_oracle as O
+from acmil_amd import synthetic as SY
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=50000)
@@ -15,7 +15,7 @@ ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--modes", default="fp32,f16x3,f16")
 ap.add_argument("--xdtype", default="float32")
 args = ap.parse_args()
-sd = {k: v.cuda() for k, v in O.default_state_dict(args.d, args.di, args.c, args.k).items()}
+sd = {k: v.cuda() for k, v in SY.ga_state_dict(args.d, args.di, args.c, args.k).items()}
 xs = [torch.randn(args.n, args.d, device="cuda").to(getattr(torch, args.xdtype)) for _ in range(8)]
 lib = _lib.load()
 for mode in args.modes.split(","):
