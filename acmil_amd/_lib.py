@@ -32,6 +32,8 @@ SIGNATURES = {
     "acmil_ga_batch_workspace_bytes": (_sz, [_i, C.POINTER(_i)] + [_i] * 5),
     "acmil_ga_forward_batch": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), _i, _vp] + [_i] * 6 + [C.POINTER(_vp)] + [_vp] * 4 +
                                [_i, _vp, _vp]),
+    "acmil_ga_forward_guarded": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp] + [_i] * 5 + [C.POINTER(_vp)] + [_vp] * 4 +
+                                 [_i, _vp, _vp, _vp]),
     "acmil_ga_pool": (_i, [_vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _i] + [_vp] * 4 + [_i, _vp, _vp]),
     "acmil_stkim_workspace_bytes": (_sz, [_i] * 3),
     "acmil_stkim_select": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

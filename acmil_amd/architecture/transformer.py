@@ -74,6 +74,29 @@ class _GaTrainFn(torch.autograd.Function):
         return (None, None, None, None, *grads)
 
 
+class RangeTicket:
+    """The split-f16 range word of ONE launch, on its way to the host: an asynchronous 4-byte copy into pinned memory issued
+    right behind the launch (stream-ordered after it and before whatever overwrites the word) plus an event.  `int(ticket)`
+    waits for THAT event only -- work enqueued after the launch keeps the GPU busy meanwhile (a plain `int(status)` is a
+    stream-ordered read-back: it would wait for everything enqueued since)."""
+    _pool: list = []
+
+    def __init__(self, status: torch.Tensor):
+        self.host = RangeTicket._pool.pop() if RangeTicket._pool else torch.empty(1, dtype=torch.int32).pin_memory()
+        self.host.copy_(status, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(status.device))
+        self._value: Optional[int] = None
+
+    def __int__(self) -> int:
+        if self._value is None:
+            self.event.synchronize()
+            self._value = int(self.host[0])
+            RangeTicket._pool.append(self.host)
+            self.host = None
+        return self._value
+
+
 class _GatedBase(nn.Module):
     """Shared plumbing: parameter gathering, the packed-weight cache, the two-pass training forward."""
 
@@ -88,8 +111,29 @@ class _GatedBase(nn.Module):
             return False
         bad = int(status) != 0
         if bad:
-            self.range_fallbacks = getattr(self, "range_fallbacks", 0) + 1
+            self._fb_host = getattr(self, "_fb_host", 0) + 1
         return bad
+
+    # Fallback counter = repeats decided on the host (paths that read the status word) + repeats decided ON THE DEVICE
+    # (acmil_ga_forward_guarded counts in a device word; reading the property synchronises, the forward never does).
+    def _fb_counter(self, device) -> torch.Tensor:
+        c = self.__dict__.get("_fb_dev")
+        if c is None or c.device != device:
+            c = torch.zeros(1, dtype=torch.int32, device=device)
+            self.__dict__["_fb_dev"] = c
+        return c
+
+    @property
+    def range_fallbacks(self) -> int:
+        c = self.__dict__.get("_fb_dev")
+        return getattr(self, "_fb_host", 0) + (int(c) if c is not None else 0)
+
+    @range_fallbacks.setter
+    def range_fallbacks(self, v: int) -> None:
+        c = self.__dict__.get("_fb_dev")
+        if c is not None:
+            c.zero_()
+        self._fb_host = int(v)
 
     def _heads(self):
         raise NotImplementedError
@@ -120,10 +164,25 @@ class _GatedBase(nn.Module):
             self._pack_cache = cache
         return cache[1], cache[2]
 
+    def _packed_cached(self, precision: str):
+        """As _packed(precision), but cached per mode (the fp32 repeats of the range guard: eval loops hit it per flagged batch)."""
+        if precision == self.precision:
+            return self._packed()
+        base, wc, bc, ws, bs = self._raw_params()
+        allp = base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
+        key = (precision,) + tuple((p.data_ptr(), p._version) for p in allp)
+        cache = self.__dict__.setdefault("_pack_cache_alt", {})
+        hit = cache.get(precision)
+        if hit is None or hit[0] != key:
+            packed, dims = self._packed(precision)
+            hit = cache[precision] = (key, packed, dims)
+        return hit[1], hit[2]
+
     def invalidate_packed(self):
         """Drop the packed-weight caches (for optimizers that update the parameters outside torch's version counters)."""
         self._pack_cache = None
         self._w1_cache = None
+        self.__dict__.pop("_pack_cache_alt", None)
 
     # D_inner with a fully fused forward kernel (csrc/ga_families.inc); the reference's other feature extractors
     # (Step3_WSI_classification_ACMIL.py:78-87: CLIP-L 768/384, UNI 1024/512, GigaPath 1536/768) take the composed path
@@ -172,6 +231,16 @@ class _GatedBase(nn.Module):
 
     def _eval_forward(self, xb, packed, dims, want_scores=True, want_preds=True, want_bag_feat=False):
         """Unmasked forward: the fully fused kernel where a family exists, else score pass + pooling pass."""
+        if self._is_fused() and self.precision == "f16x3" and self.range_guard:
+            # one library call, no host read-back: split-f16 launch, then its exact-fp32 repeat predicated ON THE DEVICE on the range
+            # status (it exits at once for an in-range bag), then merge + heads -- the loop `for x: model(x)` stays asynchronous
+            p32, _ = self._packed_cached("fp32")
+            out = ops.ga_forward_guarded([xb], packed, p32, dims, self._fb_counter(xb.device), want_scores=want_scores,
+                                         want_preds=want_preds, want_bag_feat=want_bag_feat)
+            for k in ("A_out", "sub_preds", "slide_pred", "bag_feat"):
+                if k in out:
+                    out[k] = out[k][0]
+            return out
         if self._is_fused():
             out = ops.ga_forward(xb, packed, dims, self.precision, want_scores=want_scores, want_preds=want_preds,
                                  want_bag_feat=want_bag_feat)
@@ -351,20 +420,33 @@ class ACMIL_GA(_GatedBase):
         return run()       # (the score pass handles the split-f16 range guard itself: fp32 re-run + fp32 backward)
 
     @torch.no_grad()
-    def forward_batch(self, bags):
+    def forward_batch(self, bags, defer_guard: bool = False, precision: Optional[str] = None):
         """Eval forward of up to 16 bags (list of [N_b, D_feat] CUDA tensors, ragged N allowed) in ONE fused launch
         (acmil_ga_forward_batch).  Returns a list of the reference's per-slide triples
-        (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N_b]).  Not in the reference (it is strictly B=1); same maths per bag."""
-        packed, dims = self._packed()
+        (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N_b]).  Not in the reference (it is strictly B=1); same maths per bag.
+        defer_guard=True: no host read-back here -- returns (triples, status) where `status` is a RangeTicket for this launch's
+        split-f16 range word (None when the arithmetic has none); the caller looks at it later (`int(status) != 0` = redo these
+        bags with precision="fp32"), e.g. after it has enqueued the next batch, so the GPU never idles on the check
+        (train.evaluate does that).  precision overrides the module's arithmetic for this call."""
+        prec = precision or self.precision
+        packed, dims = self._packed() if prec == self.precision else self._packed_cached(prec)
         bags = [b if b.is_contiguous() else b.contiguous() for b in bags]
+        if any(b.dtype != bags[0].dtype for b in bags):      # one launch reads one storage format: widen (exactly) to fp32
+            bags = [b.float() for b in bags]
         if not self._is_fused():
             outs = [self._eval_forward(b, packed, dims) for b in bags]
-            return [(o["sub_preds"], o["slide_pred"].unsqueeze(0), o["A_out"].unsqueeze(0)) for o in outs]
-        out = ops.ga_forward_batch(bags, packed, dims, self.precision)
-        if self.precision == "f16x3" and self._out_of_range(out["range_status"]):      # some bag left the f16 range: redo in fp32
-            p32, d32 = self._packed("fp32")
-            out = ops.ga_forward_batch(bags, p32, d32, "fp32")
-        return [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
+            triples = [(o["sub_preds"], o["slide_pred"].unsqueeze(0), o["A_out"].unsqueeze(0)) for o in outs]
+            return (triples, None) if defer_guard else triples
+        out = ops.ga_forward_batch(bags, packed, dims, prec)
+        status = None
+        if prec == "f16x3" and self.range_guard:
+            if defer_guard:
+                status = RangeTicket(out["range_status"])      # async copy now: the next launch on this workspace overwrites the word
+            elif self._out_of_range(out["range_status"]):      # some bag left the f16 range: redo in fp32
+                p32, d32 = self._packed_cached("fp32")
+                out = ops.ga_forward_batch(bags, p32, d32, "fp32")
+        triples = [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
+        return (triples, status) if defer_guard else triples
 
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> bag_feat [1,Di]  (transformer.py:332-352)."""

@@ -210,10 +210,13 @@ extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D
     return GA_CTRL_BYTES + bytes;
 }
 
-extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
-                                      int D, int Di, int Da, int K, int C, int mode, float* const* A_outs,
-                                      float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
-                                      int has_bag_head, void* workspace, void* stream) {
+// packed_fp32 != null (split-f16 mode only): the DEVICE-SIDE range guard -- right behind the split-f16 launch an exact-fp32 launch of
+// the same tiles is enqueued that every workgroup leaves at once unless the status word says a bag left the f16 range; it
+// then overwrites the scores and the partials, and merge + heads finish whichever result is there.  No host read-back.
+static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
+                                 int D, int Di, int Da, int K, int C, int mode, float* const* A_outs,
+                                 float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
+                                 int has_bag_head, void* workspace, void* stream, const void* packed_fp32, unsigned* fallback_count) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (nbags <= 0 || nbags > GA_MAX_BATCH) return ACMIL_ERR_SHAPE;
@@ -238,13 +241,21 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
         a.tile_start[b + 1] = a.tile_start[b] + (b < nbags ? (Ns[b] + 32 * a.waves - 1) / (32 * a.waves) : 0);
     }
     a.nbags = nbags; a.packed = (const char*)packed; a.part = (float*)((char*)workspace + GA_CTRL_BYTES); a.h_save = nullptr;
-    a.tile_counter = nullptr; a.status = nullptr;
+    a.tile_counter = nullptr; a.status = nullptr; a.cond = nullptr; a.cond_count = nullptr;
     if (ga_use_v2(mode)) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }   // control block, see ga_common.h
     a.self_reset = ga_memset_mode() ? 0 : 1;
     if (a.tile_counter && !a.self_reset && hipMemsetAsync(a.tile_counter, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     a.L = ga_layout(D, Di, K, C, mode);
     rc = ga_dispatch(a, mode, x_dtype, true, st);
     if (rc != ACMIL_OK) return rc;
+    if (packed_fp32) {
+        if (!a.status) return ACMIL_ERR_UNSUPPORTED;          // only the persistent split-f16 kernel publishes a status word
+        GaFwdArgs b = a;                                       // same bags, same 128-patch tiles, same partial slots
+        b.packed = (const char*)packed_fp32; b.L = ga_layout(D, Di, K, C, ACMIL_MODE_F32);
+        b.tile_counter = nullptr; b.status = nullptr; b.cond = a.status; b.cond_count = fallback_count;
+        rc = ga_dispatch(b, ACMIL_MODE_F32, x_dtype, true, st);
+        if (rc != ACMIL_OK) return rc;
+    }
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     // (measured: the single-launch finish of ga_step.hip -- ga_tail_eval -- costs 26 us against 12 us for these two launches at one
@@ -256,6 +267,24 @@ extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const in
                             bag_feat, has_bag_head, (unsigned*)workspace + 8, st);
     return ga_finish_batch(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head,
                            (float*)((char*)a.part + poff), st);
+}
+
+extern "C" int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
+                                      int D, int Di, int Da, int K, int C, int mode, float* const* A_outs,
+                                      float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
+                                      int has_bag_head, void* workspace, void* stream) {
+    return ga_forward_batch_impl(nbags, xs, Ns, x_dtype, packed, D, Di, Da, K, C, mode, A_outs, sub_preds, slide_pred, afeat, bag_feat,
+                                 has_bag_head, workspace, stream, nullptr, nullptr);
+}
+
+extern "C" int acmil_ga_forward_guarded(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed_f16x3,
+                                        const void* packed_fp32, int D, int Di, int Da, int K, int C, float* const* A_outs,
+                                        float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                                        unsigned* fallback_count, void* workspace, void* stream) {
+    if (!packed_fp32) return ACMIL_ERR_NULL;
+    if (!ga_use_v2(ACMIL_MODE_F16X3)) return ACMIL_ERR_UNSUPPORTED;
+    return ga_forward_batch_impl(nbags, xs, Ns, x_dtype, packed_f16x3, D, Di, Da, K, C, ACMIL_MODE_F16X3, A_outs, sub_preds, slide_pred,
+                                 afeat, bag_feat, has_bag_head, workspace, stream, packed_fp32, fallback_count);
 }
 
 extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,
@@ -285,7 +314,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);
     a.nbags = 1; a.packed = (const char*)packed; a.part = workspace ? (float*)((char*)workspace + GA_CTRL_BYTES) : nullptr; a.h_save = h_save;
-    a.tile_counter = nullptr; a.status = nullptr;
+    a.tile_counter = nullptr; a.status = nullptr; a.cond = nullptr; a.cond_count = nullptr;
     if (ga_use_v2(mode) && workspace) { a.tile_counter = (unsigned*)workspace; a.status = a.tile_counter + 1; }
     a.self_reset = ga_memset_mode() ? 0 : 1;
     if (a.tile_counter && !a.self_reset && hipMemsetAsync(a.tile_counter, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;

@@ -49,6 +49,9 @@ struct GaFwdArgs {
                               //     the split-f16 result is then NOT the fp32 result and the caller must redo the bag in fp32 mode
     int self_reset;  // v2: 1 = the last workgroup leaves the control block's counters at zero (default); 0 = the host memsets (A/B knob)
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
+    const unsigned* cond;     // v1 (fp32 repeat of the device-side range guard): run only if *cond != 0 (the status word the preceding
+                              //     split-f16 launch on this stream left); null = unconditional
+    unsigned* cond_count;     // v1: incremented once per launch that did run under `cond` (the module's fallback counter); may be null
     GaLayout L;
 };
 
@@ -126,6 +129,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void ga_fwd_kernel(GaFwdArgs a) {
 
     const GaLayout& L = a.L;
     const int tid = threadIdx.x, lane = tid & 63;
+    if (a.cond) {      // predicated repeat: the whole grid leaves at once unless the split-f16 launch before it flagged its bag(s)
+        if (__builtin_nontemporal_load(a.cond) == 0u) return;
+        if (blockIdx.x == 0 && tid == 0 && a.cond_count) atomicAdd(a.cond_count, 1u);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i31 = lane & 31, hi = lane >> 5;
     // batched launch: one grid covers the tiles of up to GA_MAX_BATCH bags (fills the CUs a single 50k-patch bag leaves idle)

@@ -84,7 +84,7 @@ _WS_CACHE: Dict[tuple, torch.Tensor] = {}
 def _ws_bytes(nbytes: int, device) -> torch.Tensor:
     """Grow-only GA workspace per (device, stream).  The library's contract (csrc/ga_common.h): the first 256 bytes are a
     control block that is zero when the workspace is first used and that every launch leaves zero again (apart from the
-    sticky range status), so the buffer is zero-filled once here and then reused -- no memset between launches.  Calls are
+    range status word of the most recent launch), so the buffer is zero-filled once here and then reused -- no memset between launches.  Calls are
     stream-ordered and a call's workspace contents are dead when it returns, so one buffer per stream is enough."""
     dev = torch.device(device)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
@@ -102,8 +102,10 @@ def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
 def _range_status(ws: torch.Tensor) -> torch.Tensor:
     """Device view of the split-f16 range status word of a GA workspace (control block, word 1).  Non-zero = a projected
     feature left the f16 range or was not finite (which is also what a bag value outside the range causes: its hi half
-    converts to inf): the f16x3 result is then not the fp32 result.  The word is STICKY (the kernels OR flags in); whoever acts on it clears it (`status.zero_()`).  Reading it
-    (`int(...)`) synchronises; the modules do that, the raw ops do not."""
+    converts to inf): the f16x3 result is then not the fp32 result.  The word holds the result of the MOST RECENT split-f16 launch
+    on this workspace (the last workgroup of a launch overwrites it; csrc/ga_common.h), so it must be read -- or copied with
+    `status.clone()` -- before the next launch on the same stream's workspace.  Reading it (`int(...)`) synchronises; the
+    modules do that (lagged, see architecture/transformer.py), the raw ops do not."""
     return ws[4:8].view(torch.int32)
 
 
@@ -167,6 +169,41 @@ def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaD
     _lib.check(rc, "acmil_ga_forward_batch")
     out: Dict[str, object] = {"sub_preds": sub, "range_status": _range_status(ws)}
     for k, v in (("A_out", A), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out
+
+
+def ga_forward_guarded(xs: Sequence[torch.Tensor], packed: torch.Tensor, packed_fp32: torch.Tensor, dims: GaDims,
+                       fallback_count: Optional[torch.Tensor] = None, want_scores: bool = True, want_preds: bool = True,
+                       want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, object]:
+    """acmil_ga_forward_guarded: the split-f16 fused forward of up to 16 bags followed, on the device, by its exact-fp32 repeat
+    if (and only if) a bag left the f16 range -- no host read-back, the outputs are the fp32-parity result either way.
+    Same returns as ga_forward_batch; fallback_count: device int32 [1] the library increments when the repeat ran."""
+    lib = _lib.load()
+    B = len(xs)
+    for x in xs:
+        _check_x(x, dims)
+        if x.dtype != xs[0].dtype:
+            raise RuntimeError("acmil_amd: all bags of a batch must share one dtype")
+    _need_cuda(packed, packed_fp32, fallback_count)
+    dev = xs[0].device
+    f32 = dict(dtype=torch.float32, device=dev)
+    Ns = (ctypes.c_int * B)(*[x.shape[0] for x in xs])
+    xp = (ctypes.c_void_p * B)(*[x.data_ptr() for x in xs])
+    A = [torch.empty(dims.K, x.shape[0], **f32) for x in xs] if want_scores else None
+    Ap = (ctypes.c_void_p * B)(*[t.data_ptr() for t in A]) if want_scores else None
+    sub = torch.empty(B, dims.K, dims.C, **f32) if want_preds else None
+    slide = torch.empty(B, dims.C, **f32) if (want_preds and dims.has_bag_head) else None
+    af = torch.empty(B, dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(B, dims.Di, **f32) if want_bag_feat else None
+    ws = _ws_bytes(lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, _lib.MODE_F16X3), dev)
+    rc = lib.acmil_ga_forward_guarded(B, xp, Ns, _DT[xs[0].dtype], packed.data_ptr(), packed_fp32.data_ptr(), *dims.args(), Ap,
+                                      _ptr(sub), _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), _ptr(fallback_count),
+                                      ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_forward_guarded")
+    out: Dict[str, object] = {"range_status": _range_status(ws)}
+    for k, v in (("A_out", A), ("sub_preds", sub), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
         if v is not None:
             out[k] = v
     return out
@@ -314,6 +351,28 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
     _check_x(x, dims)
     K, Cc = dims.K, dims.C
     N, dev = x.shape[0], x.device
+    # every pointer below is handed to the kernels raw: check what the op-by-op path checked in its wrappers
+    _need_cuda(label, guard_flag, *params, *grads)
+    n_par = 7 + 2 * K + (2 if dims.has_bag_head else 0)
+    if len(params) != n_par or len(grads) != n_par:
+        raise RuntimeError("acmil_amd.ga_train_step: expected %d parameters / gradients, got %d / %d" % (n_par, len(params), len(grads)))
+    for p, g in zip(params, grads):
+        if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous() or g.shape != p.shape \
+                or p.device != dev or g.device != dev:
+            raise RuntimeError("acmil_amd.ga_train_step: parameters and gradients must be contiguous fp32 on the bag's device, same shapes")
+    if label.device != dev or label.numel() < 1:
+        raise RuntimeError("acmil_amd.ga_train_step: label must be a [1] tensor on the bag's device")
+    if label.dtype != torch.int64 or not label.is_contiguous():
+        label = label.to(torch.int64).contiguous()
+    if not (0 <= k_top <= N) or not (0 <= m_mask <= k_top):
+        raise RuntimeError("acmil_amd.ga_train_step: need 0 <= m_mask <= k_top <= N (got k_top=%d m_mask=%d N=%d)" % (k_top, m_mask, N))
+    if m_mask > 0:
+        if uniforms is None or tuple(uniforms.shape) != (K, k_top):       # the kernel reads row k at stride k_top
+            raise RuntimeError("acmil_amd.ga_train_step: uniforms must be [K=%d, k_top=%d], got %s" % (
+                K, k_top, None if uniforms is None else tuple(uniforms.shape)))
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()      # as acmil_stkim_select's wrapper does
+    if guard_flag is not None and (guard_flag.dtype != torch.float32 or guard_flag.device != dev or guard_flag.numel() < 1):
+        raise RuntimeError("acmil_amd.ga_train_step: guard_flag must be a float32 device scalar")
     fbuf = torch.empty(4 + K * Cc + Cc + K * N, dtype=torch.float32, device=dev)
     losses, sub, slide, A = fbuf[:4], fbuf[4:4 + K * Cc].view(K, Cc), fbuf[4 + K * Cc:4 + K * Cc + Cc], fbuf[4 + K * Cc + Cc:].view(K, N)
     ibuf = torch.empty(K * (k_top + m_mask) + 1, dtype=torch.int64, device=dev)

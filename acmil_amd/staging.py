@@ -120,5 +120,47 @@ class BagPrefetcher:
             self.close()
 
 
+    def iter_groups(self, group: int) -> Iterator[list]:
+        """Yield LISTS of up to `group` items (same dicts as __iter__) whose ring slots all stay valid until the next list is
+        requested: what a batched launch over several bags needs (acmil_ga_forward_batch).  Needs depth >= 2 * group for the
+        copy of the next group to overlap the compute of this one (staged_groups sizes it)."""
+        compute = torch.cuda.current_stream(self.device) if self.cuda else None
+        held: list = []
+        done = False
+        try:
+            while not done:
+                if held:                                     # the previous group's kernels are enqueued: release its slots
+                    if self.cuda:
+                        ev = torch.cuda.Event()
+                        ev.record(compute)
+                        for sl in held:
+                            sl.consumed = ev
+                    for sl in held:
+                        self._free.put(sl)
+                    held = []
+                items = []
+                while len(items) < group:
+                    got = self._ready.get()
+                    if got is None:
+                        done = True
+                        break
+                    if got[0] == "error":
+                        raise got[1]
+                    slot, view, label, i = got
+                    if self.cuda:
+                        compute.wait_event(slot.copied)
+                    held.append(slot)
+                    items.append({"input": view, "label": label, "index": i})
+                if items:
+                    yield items
+        finally:
+            self.close()
+
+
 def staged(dataset, order: Iterable[int], device, depth: int = 3) -> BagPrefetcher:
     return BagPrefetcher(dataset, list(order), torch.device(device), depth=depth)
+
+
+def staged_groups(dataset, order: Iterable[int], device, group: int = 16) -> Iterator[list]:
+    """Groups of up to `group` staged bags (for one batched launch each); the ring holds two groups."""
+    return BagPrefetcher(dataset, list(order), torch.device(device), depth=2 * group).iter_groups(group)

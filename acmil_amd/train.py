@@ -28,7 +28,9 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .staging import staged
+from .staging import staged, staged_groups
+
+EVAL_BATCH = 16     # slides per fused eval launch (acmil_ga_forward_batch takes up to 16)
 
 PRETRAIN_DIMS = {  # Step3_WSI_classification_ACMIL.py:69-87
     "medical_ssl": (384, 128), "natural_supervised": (512, 256), "path-clip-B": (512, 256), "openai-clip-B": (512, 256),
@@ -288,27 +290,69 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
 
 
 @torch.no_grad()
-def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, world: int = 1):
-    """(auroc, acc, f1, loss) as Step3_WSI_classification_ACMIL.py:242-286; slides sharded over ranks, gathered on all."""
+def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, world: int = 1, batched: bool = True, detail: Optional[dict] = None):
+    """(auroc, acc, f1, loss) as Step3_WSI_classification_ACMIL.py:242-286; slides sharded over ranks, gathered on all.
+    batched=False keeps the reference's one-slide-per-call pattern (`model(x)` per slide); detail: a dict that receives this
+    rank's per-slide 'prob' [n,C], 'loss' [n] and 'div' [n] (tests)."""
     model.eval()
     order = epoch_order(len(data), 0, 0, False, rank, world, drop_last=False)
     probs, labels, losses, divs = [], [], [], []
     label_dev = torch.arange(conf.n_class, device=device)
-    for item in staged(data, order, device):
-        x = item["input"]
-        y = label_dev[item["label"]:item["label"] + 1]
-        out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
-        if isinstance(out, tuple):
-            sub_preds, slide_preds, attn = out
-            # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
-            divs.append(ops.attn_entropy_loss(attn))          # div_loss (:259) from one HIP pass over the raw scores
-        else:
-            slide_preds = out
-        losses.append(F.cross_entropy(slide_preds, y))
-        probs.append(torch.softmax(slide_preds, dim=-1))
-        labels.append(y)
+    if batched and device.type == "cuda" and hasattr(model, "forward_batch") and getattr(model, "_is_fused", lambda: False)():
+        # GA at the fused widths: up to 16 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times), and
+        # the split-f16 range word of a batch is looked at only after the NEXT batch has been enqueued, so the GPU never idles
+        # on the check; a flagged batch (never seen on real features) is re-read and repeated in fp32 arithmetic.
+        n_total = len(order)
+        probs, labels, losses, divs = [None] * n_total, [None] * n_total, [None] * n_total, [None] * n_total
+        pos = {idx: j for j, idx in enumerate(order)}
+
+        def record(item_idx, label, triple):
+            _, slide_preds, attn = triple
+            j = pos[item_idx]
+            y = label_dev[label:label + 1]
+            divs[j] = ops.attn_entropy_loss(attn)
+            losses[j] = F.cross_entropy(slide_preds, y)
+            probs[j] = torch.softmax(slide_preds, dim=-1)
+            labels[j] = y
+
+        def settle(pending):
+            status, members = pending
+            if status is None or int(status) == 0:
+                return
+            model._fb_host = getattr(model, "_fb_host", 0) + 1          # host-decided repeat (see _GatedBase.range_fallbacks)
+            xs = [torch.as_tensor(data[i]["input"]).to(device) for i, _ in members]     # the ring has recycled them: read again
+            for (i, lab), triple in zip(members, model.forward_batch(xs, precision="fp32")):
+                record(i, lab, triple)
+
+        pending = None
+        for group in staged_groups(data, order, device, group=EVAL_BATCH):
+            triples, status = model.forward_batch([it["input"] for it in group], defer_guard=True)
+            for it, triple in zip(group, triples):
+                record(it["index"], it["label"], triple)
+            if pending is not None:
+                settle(pending)
+            pending = (status, [(it["index"], it["label"]) for it in group])
+        if pending is not None:
+            settle(pending)
+    else:
+        for item in staged(data, order, device):
+            x = item["input"]
+            y = label_dev[item["label"]:item["label"] + 1]
+            out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
+            if isinstance(out, tuple):
+                sub_preds, slide_preds, attn = out
+                # per-slide scalars stay on the device (a float() here would serialise the H2D of the next bag with this forward)
+                divs.append(ops.attn_entropy_loss(attn))          # div_loss (:259) from one HIP pass over the raw scores
+            else:
+                slide_preds = out
+            losses.append(F.cross_entropy(slide_preds, y))
+            probs.append(torch.softmax(slide_preds, dim=-1))
+            labels.append(y)
     prob = torch.cat(probs) if probs else torch.zeros(0, conf.n_class, device=device)
     lab = torch.cat(labels) if labels else torch.zeros(0, dtype=torch.long, device=device)
+    if detail is not None:
+        detail.update(prob=prob.cpu(), loss=torch.stack(losses).cpu() if losses else torch.zeros(0),
+                      div=torch.stack([d.reshape(()) for d in divs]).cpu() if divs else torch.zeros(0))
     losses = torch.stack(losses).tolist() if losses else []
     if world > 1:
         import torch.distributed as dist

@@ -110,6 +110,20 @@ int acmil_ga_forward_batch(int nbags, const void* const* xs, const int* Ns, int 
                            float* afeat, float* bag_feat, int has_bag_head, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched eval forward with the DEVICE-SIDE range guard (no counterpart in the reference, whose fp32 arithmetic has no
+ * range to leave: architecture/transformer.py:305-330 is what both launches compute).  Enqueues, on one stream: the
+ * split-f16 fused launch (packed_f16x3 = acmil_ga_pack_weights(..., ACMIL_MODE_F16X3)), then an exact-fp32 launch over the
+ * same tiles (packed_fp32 = ... ACMIL_MODE_F32) that exits at once unless the first one's status word is non-zero and
+ * otherwise overwrites scores and partials, then merge + heads.  The caller never has to read the status word back:
+ * the outputs are the fp32-parity result either way.  fallback_count (device, may be NULL): incremented once per
+ * call whose fp32 launch ran.  Same arguments / workspace as acmil_ga_forward_batch otherwise.
+ * ------------------------------------------------------------------------------------------- */
+int acmil_ga_forward_guarded(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed_f16x3,
+                             const void* packed_fp32, int D, int Di, int Da, int K, int C, float* const* A_outs,
+                             float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                             unsigned* fallback_count, void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Masked pooling pass of a training step.  Replaces transformer.py:318-330 given the scores and h of the
  * score pass: A[k, masked_idx[k,:]] = -1e9 (written in place into A, which then IS the reference's A_out),
  * P = softmax_N(A), afeat = P h, heads as above.  masked_idx [K,n_masked] int64 (device) from

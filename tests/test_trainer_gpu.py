@@ -199,6 +199,34 @@ def test_lagged_range_guard_skips_on_device_and_reports_late():
     assert torch.equal(bucket.flat[:bucket.numel], bucket2.flat[:bucket2.numel])
 
 
+def test_evaluate_batched_matches_per_slide_and_guards_lagged():
+    """evaluate() groups staged bags into acmil_ga_forward_batch launches of up to 16 and reads the split-f16 range word one batch
+    late: per-slide probabilities / losses / div_loss equal the one-slide-per-call loop (Step3_WSI_classification_ACMIL.py:253-268),
+    also with ragged N, more bags than one batch and ONE bag outside the f16 range (its batch is repeated in fp32)."""
+    T, conf, dev, model, bucket, opt = _guard_setup(seed=3)
+    g = torch.Generator().manual_seed(4)
+    bags = [(torch.randn(300 + 53 * i, 384, generator=g).half(), i % 3) for i in range(37)]
+    bad = bags[20][0].float().clone(); bad[11, 5] = 2.0e5
+    bags[20] = (bad, bags[20][1])
+    data = _ListBags(bags)
+    d_b, d_s = {}, {}
+    model.range_fallbacks = 0
+    res_b = T.evaluate(model, data, dev, conf, "Val", batched=True, detail=d_b)
+    assert model.range_fallbacks == 1                      # exactly the batch that holds bag 20
+    res_s = T.evaluate(model, data, dev, conf, "Val", batched=False, detail=d_s)
+    assert model.range_fallbacks == 2                      # the per-slide loop repeats just that slide
+    assert torch.isfinite(d_b["prob"]).all() and torch.isfinite(d_b["div"]).all()
+    # batches of a flagged bag run in fp32 arithmetic, the per-slide loop only that bag: same results to the parity bound
+    assert (d_b["prob"] - d_s["prob"]).abs().max().item() < 1e-5
+    assert (d_b["loss"] - d_s["loss"]).abs().max().item() < 1e-5
+    assert (d_b["div"] - d_s["div"]).abs().max().item() < 1e-4 * max(1.0, d_s["div"].abs().max().item())
+    for a, b in zip(res_b, res_s):
+        assert abs(a - b) < 1e-5
+    # bags of batches without a flagged member are bit-identical to the per-slide launch (same kernel, same tile order per bag)
+    keep = [i for i in range(37) if i // 16 != 20 // 16]
+    assert torch.equal(d_b["prob"][keep], d_s["prob"][keep])
+
+
 def test_train_one_epoch_repeats_a_flagged_bag_in_fp32():
     """train_one_epoch with the lagged guard: the out-of-range bag is skipped by the device, found two steps later and trained
     in fp32.  The model ends where a run ends that sees the same bags with the flagged one moved to where its repeat happened
