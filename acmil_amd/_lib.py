@@ -17,7 +17,7 @@ ERRORS = {-1: "ACMIL_ERR_SHAPE", -2: "ACMIL_ERR_UNSUPPORTED", -3: "ACMIL_ERR_NUL
 MODE_F32, MODE_F16X3, MODE_F16 = 0, 1, 2
 MODES = {"fp32": MODE_F32, "f16x3": MODE_F16X3, "f16": MODE_F16}
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
-MAX_TOKENS, MAX_CLASSES = 5, 16
+MAX_TOKENS, MAX_TOKENS_FUSED, MAX_CLASSES = 16, 5, 16
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 

@@ -75,25 +75,37 @@ class _GaTrainFn(torch.autograd.Function):
 
 
 class RangeTicket:
-    """The split-f16 range word of ONE launch, on its way to the host: an asynchronous 4-byte copy into pinned memory issued
-    right behind the launch (stream-ordered after it and before whatever overwrites the word) plus an event.  `int(ticket)`
-    waits for THAT event only -- work enqueued after the launch keeps the GPU busy meanwhile (a plain `int(status)` is a
-    stream-ordered read-back: it would wait for everything enqueued since)."""
-    _pool: list = []
+    """The split-f16 range word of ONE launch, on its way to the host without touching the compute stream's flow: the word is
+    copied into a slot of a small device ring right behind the launch (a 4-byte device copy, stream-ordered before whatever
+    overwrites the word), and a SIDE stream -- ordered behind that copy by an event -- brings the slot to pinned host memory.
+    `int(ticket)` waits for the side stream's event only, so work enqueued after the launch keeps the GPU busy meanwhile.  (A
+    plain `int(status)`, and also an async D2H copy on the compute stream itself, order the compute queue behind the copy
+    engine: measured ~50 us per 16-bag launch.)"""
+    _state: dict = {}      # per device: (ring [64] int32, pinned host [64] int32, side stream, next slot)
 
     def __init__(self, status: torch.Tensor):
-        self.host = RangeTicket._pool.pop() if RangeTicket._pool else torch.empty(1, dtype=torch.int32).pin_memory()
-        self.host.copy_(status, non_blocking=True)
-        self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(status.device))
+        dev = status.device
+        st = RangeTicket._state.get(dev)
+        if st is None:
+            st = RangeTicket._state[dev] = [torch.zeros(64, dtype=torch.int32, device=dev), torch.zeros(64, dtype=torch.int32).pin_memory(),
+                                            torch.cuda.Stream(device=dev), 0]
+        ring, host, side, i = st
+        st[3] = (i + 1) % 64
+        self.slot, self.host = i, host
+        ring[i:i + 1].copy_(status)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            host[i:i + 1].copy_(ring[i:i + 1], non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(side)
         self._value: Optional[int] = None
 
     def __int__(self) -> int:
         if self._value is None:
             self.event.synchronize()
-            self._value = int(self.host[0])
-            RangeTicket._pool.append(self.host)
-            self.host = None
+            self._value = int(self.host[self.slot])
         return self._value
 
 
@@ -188,8 +200,11 @@ class _GatedBase(nn.Module):
     # (Step3_WSI_classification_ACMIL.py:78-87: CLIP-L 768/384, UNI 1024/512, GigaPath 1536/768) take the composed path
     FUSED_D_INNER = (128, 256)
 
+    FUSED_MAX_TOKENS = 5      # n_token above (Step3_WSI_classification_ACMIL.py:39 takes any) runs the composed kernels, K <= 16
+
     def _is_fused(self) -> bool:
-        return self.dimreduction.fc1.weight.shape[0] in self.FUSED_D_INNER
+        return (self.dimreduction.fc1.weight.shape[0] in self.FUSED_D_INNER
+                and self.attention.attention_weights.weight.shape[0] <= self.FUSED_MAX_TOKENS)
 
     def _score_pass(self, xb, packed, dims):
         """Raw scores A [K,N] and h [N,Di].  Fused widths: one kernel (GEMM chain in registers).  Other widths: the projection
@@ -206,16 +221,26 @@ class _GatedBase(nn.Module):
             return A, h
         base = self._raw_params()[0]
         prec = "fp32" if self.precision == "fp32" else "f16x3"
-        if prec == "f16x3" and self.range_guard and not bool(torch.isfinite(xb).all() and (xb.abs().max() < 65504.0)):
-            prec = "fp32"      # composed path: the GEMM has no status word; same rule, checked up front
-            self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
-        if prec == "f16x3" and xb.stride(0) * xb.element_size() % 16 == 0:
-            # packed-weight Linear kernel (csrc/linear_kernel.h): takes fp32 / fp16 / bf16 bags as they are; ~20 % faster than the
-            # generic split GEMM at these shapes (K >= 768, 256-wide output chunks)
-            h = ops.linear_f16x3(xb, self._packed_w1(), base[0].shape[0], relu=True)
-        else:
+
+        def project(prec):
+            if prec == "f16x3" and xb.stride(0) * xb.element_size() % 16 == 0:
+                # packed-weight Linear kernel (csrc/linear_kernel.h): takes fp32 / fp16 / bf16 bags as they are; ~20 % faster than the
+                # generic split GEMM at these shapes (K >= 768, 256-wide output chunks)
+                return ops.linear_f16x3(xb, self._packed_w1(), base[0].shape[0], relu=True)
             x32 = xb if xb.dtype == torch.float32 else xb.float()      # storage-format conversion of a 16-bit bag
-            h = ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
+            return ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
+
+        h = project(prec)
+        if prec == "f16x3" and self.range_guard:
+            # Same rule as the fused kernel's status word, on the same quantity: the projected features.  A bag value outside the
+            # f16 range has an inf hi half and makes its patch's features inf / NaN, so ONE pass over h [N, Di] covers both (the
+            # composed kernels carry no status word; this reduction is the guard's cost here).
+            hmax = h.max()
+            if not bool(torch.isfinite(hmax) & (hmax < 65504.0)):
+                self._fb_host = getattr(self, "_fb_host", 0) + 1
+                prec = "fp32"
+                self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
+                h = project(prec)
         A = ops.gated_scores(h, *[p.detach() for p in base[1:7]], precision=prec)
         return A, h
 

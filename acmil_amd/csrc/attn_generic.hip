@@ -95,6 +95,7 @@ extern "C" int acmil_gated_scores(const float* h, int N, int L, int Da, int K, c
     if (rc != ACMIL_OK) return rc;
     int blocks = (N + 3) / 4; if (blocks > 2048) blocks = 2048;
     if (K == 1) hipLaunchKernelGGL(ag_gate_scores_kernel<1>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A);
+    else if (K <= 5) hipLaunchKernelGGL(ag_gate_scores_kernel<5>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A);
     else hipLaunchKernelGGL(ag_gate_scores_kernel<ACMIL_MAX_TOKENS>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

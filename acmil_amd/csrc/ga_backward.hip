@@ -111,19 +111,24 @@ struct GaBwdGateArgs {
 };
 
 // one wave per row (grid-stride); lane l: features 4l..4l+3 of h / dh0 (Di = 64*FPL), units 2l, 2l+1 of the gate
-template <int KP, int FPL>
+// COEF: the instance can form the diversity-loss term itself (a.coef, the one-call step: K <= 5); the K > 5 instances take it
+// through dA_ext only and carry no [KP][KP] table
+template <int KP, int FPL, bool COEF = true>
 __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
     constexpr int Di = 64 * FPL;
     constexpr int PREC = KP * GA_DA + KP + 2 * GA_DA;   // floats per workgroup partial record
     __shared__ float sred[4][PREC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N, K = a.K;
-    float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KP][KP];
+    constexpr int KC = COEF ? KP : 1;
+    float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KC][KC];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         const bool on = k < K;
+        if constexpr (COEF) {
 #pragma unroll
-        for (int j = 0; j < KP; ++j) cf[k][j] = (a.coef && on && j < K) ? a.coef[k * KP + j] : 0.0f;
+            for (int j = 0; j < KP; ++j) cf[k][j] = (a.coef && on && j < K) ? a.coef[k * KP + j] : 0.0f;
+        }
 #pragma unroll
         for (int f = 0; f < FPL; ++f) daf[k][f] = on ? a.d_afeat[(size_t)k * Di + FPL * lane + f] : 0.0f;
         ww[k][0] = on ? a.Ww[k * GA_DA + 2 * lane] : 0.0f;
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(256) void ga_bwd_gate_kernel(GaBwdGateArgs a) {
             const float ext = (a.dA_ext && k < K) ? a.dA_ext[(size_t)k * N + n] : 0.0f;
             dA[k] = masked ? 0.0f : fmaf(P[k], dp - ck[k], ext);
         }
-        if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (ga_loss.hip; zero where masked: p = 0)
+        if constexpr (COEF) if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (ga_loss.hip; zero where masked: p = 0)
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 float sdiv = 0.0f;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(256) void gb_split_kernel(const float* __restrict__
 
 GbWs gb_layout(int N, int D, int Di, int K) {
     GbWs w; size_t off = 0;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int KP = ga_kp(K);
     w.G = off;       off += gb_align((size_t)N * 2 * GA_DA * 4);
     w.dpre = off;    off += gb_align((size_t)N * Di * 4);
     w.d_afeat = off; off += gb_align((size_t)K * Di * 4);
@@ -275,7 +280,8 @@ int gb_run(const GbRun& r) {
         hipLaunchKernelGGL(gb_concat_kernel, dim3(64), dim3(256), 0, st, r.Wv, r.Wu, r.bv, r.bu, GA_DA * Di, (float*)(ws + L.wcat), (float*)(ws + L.bcat));
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     }
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    const int KP = ga_kp(K);
+    if (KP > 5 && r.coef) return ACMIL_ERR_UNSUPPORTED;      // K > 5: the caller forms the diversity term (acmil_ga_loss -> d_A)
     int blocks = 0;
     // 3-5 as ONE kernel per 64-patch tile when the caller holds the pre-split operands (training step, split arithmetic)
     rc = ACMIL_ERR_UNSUPPORTED;
@@ -300,7 +306,11 @@ int gb_run(const GbRun& r) {
 #define GB_LAUNCH_GATE(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_>), dim3(blocks), dim3(256), 0, st, ga)
         if (KP == 1) { if (FPL == 2) GB_LAUNCH_GATE(1, 2); else if (FPL == 4) GB_LAUNCH_GATE(1, 4); else if (FPL == 6) GB_LAUNCH_GATE(1, 6); else if (FPL == 8) GB_LAUNCH_GATE(1, 8); else GB_LAUNCH_GATE(1, 12); }
         else if (KP == 5) { if (FPL == 2) GB_LAUNCH_GATE(5, 2); else if (FPL == 4) GB_LAUNCH_GATE(5, 4); else if (FPL == 6) GB_LAUNCH_GATE(5, 6); else if (FPL == 8) GB_LAUNCH_GATE(5, 8); else GB_LAUNCH_GATE(5, 12); }
+#define GB_LAUNCH_GATE_NC(KP_, FPL_) hipLaunchKernelGGL((ga_bwd_gate_kernel<KP_, FPL_, false>), dim3(blocks), dim3(256), 0, st, ga)
+        else if (KP == 8) { if (FPL == 2) GB_LAUNCH_GATE_NC(8, 2); else if (FPL == 4) GB_LAUNCH_GATE_NC(8, 4); else if (FPL == 6) GB_LAUNCH_GATE_NC(8, 6); else if (FPL == 8) GB_LAUNCH_GATE_NC(8, 8); else GB_LAUNCH_GATE_NC(8, 12); }
+        else if (KP == 16) { if (FPL == 2) GB_LAUNCH_GATE_NC(16, 2); else if (FPL == 4) GB_LAUNCH_GATE_NC(16, 4); else if (FPL == 6) GB_LAUNCH_GATE_NC(16, 6); else if (FPL == 8) GB_LAUNCH_GATE_NC(16, 8); else GB_LAUNCH_GATE_NC(16, 12); }
         else return ACMIL_ERR_UNSUPPORTED;
+#undef GB_LAUNCH_GATE_NC
 #undef GB_LAUNCH_GATE
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
         // 5 dpre = (dh0 + dS [Wv;Wu]) * [h > 0]   (dS = the gate pass' output in G, K = 2 Da)

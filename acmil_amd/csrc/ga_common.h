@@ -31,7 +31,7 @@ __host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3)
 //  g2 : GEMM2 operand stream, 2 unit-groups x ND x 16 fragment rows   (both: half as many rows in MODE_F16)
 //  tab: bv[128], bu[128], Ww[K][128]  raw fp32 (the C/D register quad (4rq..4rq+3) of tile pair p in lane
 //       half hi covers the 4 CONSECUTIVE units 32p + 8rq + 4hi + {0..3}, so the epilogue reads plain float4s)
-//  bw : 8 floats (bw[K], zero padded)
+//  bw : ACMIL_MAX_TOKENS floats (bw[K], zero padded)
 //  heads: Wc [K][C][Di], bc [K][C], Ws [C][Di], bs [C]   (raw copies, fp32)
 //  wcat : [Wv; Wu] [2 Da][Di], bcat [bv; bu] [2 Da], wcatT = [Wv; Wu]^T [Di][2 Da]  (raw fp32; read by the backward of a training step)
 // ---------------------------------------------------------------------------------------------------
@@ -49,7 +49,7 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
     L.g1_off = off; L.g1_rows = (size_t)(D / 64) * 8 * L.ND / half; off += L.g1_rows * GA_FRAG_ROW;
     L.g2_off = off; L.g2_rows = (size_t)L.ND * 32 / half;            off += L.g2_rows * GA_FRAG_ROW;
     L.tab_off = off; off += (size_t)(2 + K) * GA_DA * 4;
-    L.bw_off = off;  off += 8 * 4;
+    L.bw_off = off;  off += ACMIL_MAX_TOKENS * 4;
     L.wc_off = off;  off += (size_t)K * C * Di * 4;
     L.bc_off = off;  off += (size_t)((K * C + 3) / 4) * 16;
     L.ws_off = off;  off += (size_t)C * Di * 4;
@@ -69,6 +69,9 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
 __host__ __device__ static inline size_t ga_part_stride(int Di) { return (size_t)(2 + Di); }
 __host__ __device__ static inline int ga_num_tiles(int N) { return (N + GA_ROWS_PER_WG - 1) / GA_ROWS_PER_WG; }
 __host__ __device__ static inline int ga_pool_tiles(int N) { return (N + GA_POOL_ROWS - 1) / GA_POOL_ROWS; }
+
+// padded branch count the K-templated kernels are instantiated for
+__host__ __device__ static inline int ga_kp(int K) { return (K <= 1) ? 1 : (K <= 5) ? 5 : (K <= 8) ? 8 : 16; }
 
 static inline int ga_check_dims(int D, int Di, int Da, int K, int C) {
     if (Da != GA_DA) return ACMIL_ERR_UNSUPPORTED;

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void gl_gram_kernel(const float* __restrict__ 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int e = 0; e < KP * KP; ++e) {
+        if (e / KP > e % KP) { if (lane == 0) red[wave][e] = 0.0f; continue; }      // lower triangle: never accumulated
         float v = g[e];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
@@ -167,10 +168,12 @@ __global__ __launch_bounds__(256) void gl_dA_kernel(const float* __restrict__ A,
     }
 }
 
+// workspace: stats [2 K] (256 B) | coef [KP][KP] (1 KiB) | Gram partials [GL_BLOCKS][KP][KP]
 extern "C" size_t acmil_ga_loss_workspace_bytes(int N, int K) {
     (void)N;
     if (K <= 0 || K > GL_MAXK) return 0;
-    return 256 /*stats*/ + 256 /*coef*/ + (((size_t)GL_BLOCKS * 8 * 8 * 4 + 255) & ~(size_t)255);
+    const int KP = ga_kp(K);
+    return 256 + 1024 + (((size_t)GL_BLOCKS * KP * KP * 4 + 255) & ~(size_t)255);
 }
 
 extern "C" int acmil_ga_loss(const float* sub_preds, const float* slide_pred, const float* A_out, const int64_t* label, int N,
@@ -183,8 +186,8 @@ extern "C" int acmil_ga_loss(const float* sub_preds, const float* slide_pred, co
     hipStream_t st = (hipStream_t)stream;
     float* stats = (float*)workspace;
     float* coef = stats + 64;
-    float* part = coef + 64;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    float* part = coef + 256;
+    const int KP = ga_kp(K);
     int blocks = (N + 255) / 256; if (blocks > GL_BLOCKS) blocks = GL_BLOCKS;
     hipLaunchKernelGGL(gl_stats_kernel, dim3(K), dim3(1024), 0, st, A_out, N, stats);
     if (KP == 1) {
@@ -195,6 +198,14 @@ extern "C" int acmil_ga_loss(const float* sub_preds, const float* slide_pred, co
         hipLaunchKernelGGL(gl_gram_kernel<5>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, part);
         hipLaunchKernelGGL(gl_scalar_kernel<5>, dim3(1), dim3(1024), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
         hipLaunchKernelGGL(gl_dA_kernel<5>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, coef, d_A);
+    } else if (KP == 8) {
+        hipLaunchKernelGGL(gl_gram_kernel<8>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, part);
+        hipLaunchKernelGGL(gl_scalar_kernel<8>, dim3(1), dim3(1024), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
+        hipLaunchKernelGGL(gl_dA_kernel<8>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, coef, d_A);
+    } else if (KP == 16) {      // (register-heavy instances: a generality path, K = 9..16)
+        hipLaunchKernelGGL(gl_gram_kernel<16>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, part);
+        hipLaunchKernelGGL(gl_scalar_kernel<16>, dim3(1), dim3(1024), 0, st, part, blocks, K, C, sub_preds, slide_pred, label, losses, d_sub, d_slide, coef);
+        hipLaunchKernelGGL(gl_dA_kernel<16>, dim3(blocks), dim3(256), 0, st, A_out, N, K, stats, coef, d_A);
     } else return ACMIL_ERR_UNSUPPORTED;
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

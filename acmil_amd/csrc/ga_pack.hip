@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
         for (int k = 0; k < L.K; ++k) tab[(2 + k) * GA_DA + e] = a.Ww[(size_t)k * GA_DA + e];
     }
     float* bw = (float*)(a.out + L.bw_off);
-    if (tid < 8) bw[tid] = (tid < L.K) ? a.bw[tid] : 0.0f;
+    if (tid < ACMIL_MAX_TOKENS) bw[tid] = (tid < L.K) ? a.bw[tid] : 0.0f;
     float* bc = (float*)(a.out + L.bc_off);
     for (int k = 0; k < L.K; ++k)
         if (tid < L.C) bc[k * L.C + tid] = a.bc[k][tid];

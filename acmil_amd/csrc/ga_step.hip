@@ -18,7 +18,7 @@
 #include "ga_train_internal.h"
 
 #define GA_MERGE_GROUPS 16
-#define GS_MAXK ACMIL_MAX_TOKENS
+#define GS_MAXK ACMIL_MAX_TOKENS_FUSED
 
 extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
 extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K, int C);
@@ -382,7 +382,7 @@ static GsWs gs_layout(int N, int D, int Di, int K, int C, int k_top) {
 }
 
 extern "C" size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int K, int C, int k_top) {
-    if (N <= 0 || D <= 0 || Di <= 0 || K <= 0 || C <= 0 || k_top < 0) return 0;
+    if (N <= 0 || D <= 0 || Di <= 0 || K <= 0 || K > GS_MAXK || C <= 0 || k_top < 0) return 0;
     return gs_layout(N, D, Di, K, C, k_top).total;
 }
 
@@ -398,6 +398,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
                                    int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
+    if (K > GS_MAXK) return ACMIL_ERR_UNSUPPORTED;       // the one-call step exists for the fused families (K <= 5); K above: op by op
     if (N <= 0 || k_top < 0 || k_top > 64 || k_top > N || m_mask < 0 || m_mask > k_top) return ACMIL_ERR_SHAPE;
     if (mode != ACMIL_MODE_F32 && mode != ACMIL_MODE_F16X3 && mode != ACMIL_MODE_F16) return ACMIL_ERR_UNSUPPORTED;
     if (!x || !packed || !W1 || !Wv || !bv || !Wu || !bu || !Ww || !bw || !Wc || !bc || !label || !workspace) return ACMIL_ERR_NULL;

@@ -280,12 +280,13 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
 // one workgroup per 128-row tile; gram: see the kernel.  Shared by acmil_ga_pool, acmil_attn_pool and the fused step.
 int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st) {
     if (Di % 64 != 0 || Di / 4 > 256 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;
-    const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    if (K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
+    const int KP = ga_kp(K);
     const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
     const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
     if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
     void (*kern)(const float*, const float*, int, int, int, float*, float*) =
-        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : ga_pool_kernel<8>;
+        KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : KP == 8 ? ga_pool_kernel<8> : ga_pool_kernel<16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(ga_pool_tiles(N)), dim3(256), lds, st, h, A, N, K, Di, part, gram);
@@ -324,7 +325,7 @@ extern "C" size_t acmil_attn_pool_workspace_bytes(int N, int Di, int K) {
 
 extern "C" int acmil_attn_pool(const float* h, const float* A, int N, int Di, int K, float* afeat, void* workspace, void* stream) {
     if (N <= 0 || Di <= 0 || K <= 0) return ACMIL_ERR_SHAPE;
-    if (Di % 64 != 0 || Di > 1024 || K > 8) return ACMIL_ERR_UNSUPPORTED;
+    if (Di % 64 != 0 || Di > 1024 || K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
     if (!h || !A || !afeat || !workspace) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int tiles = ga_pool_tiles(N);

@@ -18,7 +18,7 @@
 #include "ga_common.h"
 
 #define MHA_HEADS 8
-#define MHA_MAXK ACMIL_MAX_TOKENS
+#define MHA_MAXK ACMIL_MAX_TOKENS_FUSED
 
 extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
 

@@ -117,12 +117,19 @@ class FlatAdamW:
     def state_dict(self):
         """torch.optim.AdamW's layout (what the reference's checkpoints hold under 'optimizer', utils/utils.py:415-422): per-parameter
         'state' entries {step, exp_avg, exp_avg_sq} and 'param_groups' with parameter indices -- loadable by torch.optim.AdamW."""
+        # tracked steps nobody has polled yet: wait for their flags and leave out the ones the device skipped (the entries stay
+        # queued for poll_skipped -- the trainer still has to repeat those bags)
+        step_count = self.step_count
+        for sid, ev, slot in self._pending:
+            ev.synchronize()
+            if float(self._host_flags[slot]) != 0.0:
+                step_count -= 1
         state, off = {}, 0
         frozen = {o for o, _ in self._frozen}
         for i, p in enumerate(self.params):
             n = p.numel()
-            if off not in frozen and self.step_count > 0:
-                state[i] = {"step": torch.tensor(float(self.step_count)),
+            if off not in frozen and step_count > 0:
+                state[i] = {"step": torch.tensor(float(step_count)),
                             "exp_avg": self.exp_avg[off:off + n].view_as(p).clone(),
                             "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).clone()}
             off += n
@@ -134,6 +141,8 @@ class FlatAdamW:
 
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW's layout (also one written by the reference) or this class's earlier flat layout."""
+        self._pending.clear()      # flags of steps taken before the load belong to the discarded state
+        self.skipped_steps = 0
         if "state" in sd:
             off, steps = 0, []
             for i, p in enumerate(self.params):

@@ -252,6 +252,23 @@ def other_workloads(args):
         if opt.poll_skipped(2):
             raise SystemExit("bench: a synthetic bag left the split-f16 range")
     dt = _timed(step, args, world, dev)
+    # the collective alone (what the step pays for data parallelism): the same flat-bucket all-reduce + mean, back to back, events on
+    # the launch stream; None on one GPU (GradBucket.allreduce_mean issues nothing there)
+    allreduce_us = None
+    if world > 1:
+        for _ in range(5):
+            bucket.allreduce_mean(world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _sync(world, dev)
+        e0.record()
+        for _ in range(50):
+            bucket.allreduce_mean(world)
+        e1.record()
+        torch.cuda.synchronize()
+        t_ar = torch.tensor([e0.elapsed_time(e1) * 1e3 / 50], dtype=torch.float64, device=dev)
+        import torch.distributed as dist
+        dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
+        allreduce_us = round(float(t_ar.item()), 2)
     _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
     flops = fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)
     t_step = dt / args.steps
@@ -259,6 +276,7 @@ def other_workloads(args):
         "metric": "slides/sec (ACMIL-ga training step: fwd + STKIM + losses + bwd + grad all-reduce + AdamW, N=%d D=512 C=7)" % N,
         "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "allreduce_us": allreduce_us, "allreduce_bytes": int(bucket.flat.numel() * 4),
         "dtype": "f32 (split-f16 / split-bf16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
         "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
                                "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,

@@ -41,7 +41,8 @@ extern "C" {
 #define ACMIL_DTYPE_F16 1
 #define ACMIL_DTYPE_BF16 2
 
-#define ACMIL_MAX_TOKENS 5  /* K = n_token supported by this build */
+#define ACMIL_MAX_TOKENS 16 /* K = n_token supported by this build (Step3_WSI_classification_ACMIL.py:39 --n_token; transformer.py:292-301) */
+#define ACMIL_MAX_TOKENS_FUSED 5 /* ... by the single-kernel forward families and the one-call training step; K above runs the composed kernels */
 #define ACMIL_MAX_CLASSES 16
 
 /* Library / build identification; returns a static string. */

@@ -43,7 +43,13 @@ def test_size_queries_and_argument_validation(lib):
     # error codes instead of crashes (no kernel is launched for invalid arguments)
     assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 5, 2, 0, None, None, None, None, None, None, 1, None, None) == -3
     assert lib.acmil_ga_forward(None, 0, 0, None, 512, 256, 128, 5, 2, 0, None, None, None, None, None, None, 1, None, None) == -1
-    assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 9, 2, 0, None, None, None, None, None, None, 1, None, None) == -2
+    # K above ACMIL_MAX_TOKENS (16) is refused up front; K = 6..16 passes the shape check (the fused families are K <= 5: their
+    # dispatch answers -2 once the pointers are there; the composed entry points take those K)
+    assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 17, 2, 0, None, None, None, None, None, None, 1, None, None) == -2
+    assert lib.acmil_ga_forward(None, 0, 10, None, 512, 256, 128, 9, 2, 0, None, None, None, None, None, None, 1, None, None) == -3
+    assert lib.acmil_ga_packed_bytes(512, 256, 128, 16, 2, 1) > 0 and lib.acmil_ga_packed_bytes(512, 256, 128, 17, 2, 1) == 0
+    assert lib.acmil_ga_train_step_workspace_bytes(1000, 512, 256, 8, 2, 10) == 0          # the one-call step: K <= 5
+    assert lib.acmil_ga_loss_workspace_bytes(1000, 16) > lib.acmil_ga_loss_workspace_bytes(1000, 5) > 0
     assert lib.acmil_stkim_select(None, 100, 5, 200, 0, None, None, None, None, None) == -1   # k > N
     assert lib.acmil_stkim_workspace_bytes(50000, 5, 10) >= 5 * 13 * 10 * 8
     # the one-call training step: workspace covers the saved h, the scores' partials and the backward scratch; bad arguments

@@ -12,6 +12,9 @@ from conftest import case_dims, load_golden
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 WIDE = ["d768_k5_c2", "d1024_k5_c7", "d1536_k5_c2"]
+# other branch counts (`--n_token` is free in the reference: Step3_WSI_classification_ACMIL.py:39, transformer.py:292-301), from the
+# real reference (tests/golden/make_golden_ntoken.py): K = 8 and 10 at the fused widths, K = 16 at the UNI width
+NTOK = ["d512_k8_c2", "d384_k10_c7", "d1024_k16_c2"]
 
 
 def _model(sd, precision, **kw):
@@ -27,7 +30,7 @@ def _model(sd, precision, **kw):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-@pytest.mark.parametrize("tag", WIDE)
+@pytest.mark.parametrize("tag", WIDE + NTOK)
 def test_wide_eval_forward_matches_reference(tag, precision):
     case, sd = load_golden("ga_eval_n300_" + tag)
     d, di, k, c = case_dims(sd)
@@ -52,7 +55,7 @@ def test_wide_eval_forward_matches_reference(tag, precision):
     assert torch.equal(outs[1][0], sub) and torch.equal(outs[0][2], a)
 
 
-@pytest.mark.parametrize("tag", WIDE + ["fused_d512"])
+@pytest.mark.parametrize("tag", WIDE + NTOK + ["d512_k5_c2m", "fused_d512"])
 def test_forward_feature_with_attention_mask_matches_reference(tag):
     """forward_feature(x, use_attention_mask=True): G1-G3 with the STKIM mask, then bag_feat (transformer.py:338-347)."""
     if tag == "fused_d512":
@@ -70,7 +73,7 @@ def test_forward_feature_with_attention_mask_matches_reference(tag):
         # masked positions = the reference's (fixture), so the masked bag feature is the reference's too: check via afeat mean
         assert np.array_equal(np.sort(out["masked_idx"].cpu().numpy(), axis=1), np.sort(case["masked_idx"], axis=1))
         return
-    case, sd = load_golden("ga_eval_n300_" + tag)
+    case, sd = load_golden("ga_eval_n300_" + tag)      # "d512_k5_c2m": the reference's masked feature at the FUSED width 512 / 256
     model = _model(sd, "f16x3").train()
     x = torch.from_numpy(case["x"]).cuda().float()
     with torch.no_grad():
@@ -80,7 +83,7 @@ def test_forward_feature_with_attention_mask_matches_reference(tag):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
-@pytest.mark.parametrize("tag", WIDE)
+@pytest.mark.parametrize("tag", WIDE + NTOK)
 def test_wide_train_step_matches_reference(tag, precision):
     """One training step (losses, every parameter gradient, AdamW update) against the reference's own train_one_epoch capture,
     through BOTH entries: torch.autograd over the HIP Function, and the autograd-free fused ACMIL_GA.train_step."""
@@ -137,3 +140,14 @@ def test_trainer_main_with_wide_family(tmp_path):
             "--out_dir", out, "--n_token", "5", "--n_masked_patch", "10", "--mask_drop", "0.6"])
     ck = torch.load(os.path.join(out, "checkpoint-last.pth"), weights_only=False)
     assert ck["model"]["dimreduction.fc1.weight"].shape == (512, 1024) and ck["epoch"] == 1
+
+
+def test_trainer_main_with_eight_branches(tmp_path):
+    """`--arch ga --n_token 8` trains end to end (Step3_WSI_classification_ACMIL.py:39: any branch count; K > 5 runs the composed
+    kernels at the fused width 512 / 256 as well)."""
+    from acmil_amd import train as T
+    out = str(tmp_path / "k8")
+    T.main(["--arch", "ga", "--pretrain", "plip", "--synthetic_slides", "12", "--synthetic_patches", "500", "--train_epoch", "2",
+            "--out_dir", out, "--n_token", "8", "--n_masked_patch", "10", "--mask_drop", "0.6"])
+    ck = torch.load(os.path.join(out, "checkpoint-last.pth"), weights_only=False)
+    assert ck["model"]["attention.attention_weights.weight"].shape == (8, 128) and len([k for k in ck["model"] if k.startswith("classifier.")]) == 16

@@ -33,6 +33,19 @@ def test_eval_forward_bit_exact(name):
     assert out["A_out"].shape == (1, k, x.shape[1]) and out["sub_preds"].shape == (k, c)
 
 
+@pytest.mark.parametrize("tag", ["d512_k8_c2", "d384_k10_c7", "d1024_k16_c2"])
+def test_eval_forward_bit_exact_other_branch_counts(tag):
+    """The oracle at n_token = 8 / 10 / 16 (the reference takes any: Step3_WSI_classification_ACMIL.py:39) against fixtures of the
+    real reference (tests/golden/make_golden_ntoken.py)."""
+    case, sd = load_golden("ga_eval_n300_" + tag)
+    d, di, k, c = case_dims(sd)
+    x = torch.from_numpy(case["x"]).float()
+    out = O.acmil_ga_forward(x, sd, n_token=k)
+    assert np.array_equal(out["A_out"].numpy(), case["A_out"]) and np.array_equal(out["sub_preds"].numpy(), case["sub_preds"])
+    assert np.array_equal(out["slide_pred"].numpy(), case["slide_pred"])
+    assert out["A_out"].shape == (1, k, 300) and out["sub_preds"].shape == (k, c)
+
+
 def test_abmil_bit_exact():
     case, sd = load_golden("abmil_eval_n1000_d512_c2")
     logits = O.abmil_forward(torch.from_numpy(case["x"]).float(), sd)

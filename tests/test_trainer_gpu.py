@@ -285,3 +285,19 @@ def test_rccl_single_rank_bucket_allreduce_and_broadcast():
         assert opt.poll_skipped(0) == [] and not torch.equal(opt.flat, p0)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs on one node (switches itself on where they exist)")
+def test_two_rank_rccl_training_steps():
+    """Two real ranks on RCCL: train_step -> GradBucket.allreduce_mean -> FlatAdamW.step for three steps incl. one range-flagged bag
+    on one rank; identical parameters on both ranks, equal to one process on the averaged gradients (tests/dist_worker_nccl.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker_nccl.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:]
