@@ -142,6 +142,19 @@ static int ga_dephase() {
 // kernel skips its end-of-kernel counter reset (the round-2 scheme before the self-resetting block)
 static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
 
+// tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
+// workgroup per CU: the weight stream is staged once per 256 patches).  ACMIL_GA2_WAVES=4|8 overrides; read once.
+static int ga_v2_waves() {
+    static const int v = [] { const char* e = getenv("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return v;
+}
+
+// wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
+static int ga_pair_split() {
+    static const int v = [] { const char* e = getenv("ACMIL_GA2_PAIR"); return e ? (atoi(e) != 0) : 0; }();
+    return v;
+}
+
 static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
     const int ND = a.L.ND, K = a.L.K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
@@ -231,8 +244,8 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     }
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
-    a.waves = ga_use_v2(mode) ? 4 : ga_pick_waves(maxN, total_patches);
-    a.dephase = ga_dephase();
+    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(maxN, total_patches);
+    a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
         a.xs[b] = b < nbags ? xs[b] : nullptr;
@@ -308,8 +321,8 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.waves = ga_use_v2(mode) ? 4 : ga_pick_waves(N);
-    a.dephase = ga_dephase();
+    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(N);
+    a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);

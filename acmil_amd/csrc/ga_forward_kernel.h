@@ -32,7 +32,7 @@
 #pragma once
 #include "ga_common.h"
 
-#define GA_MAX_BATCH 16
+#define GA_MAX_BATCH ACMIL_MAX_BATCH      // bags per launch (kernel-argument arrays); a launch of 64 x 50 000 patches is 48 rounds of tiles on 512 slots
 
 struct GaFwdArgs {
     const void* xs[GA_MAX_BATCH];     // bag matrices [N_b, D]
@@ -48,6 +48,7 @@ struct GaFwdArgs {
     unsigned* status;         // v2: zeroed word; bit 0 = a bag value, bit 1 = a projected feature h outside the f16 range (or NaN):
                               //     the split-f16 result is then NOT the fp32 result and the caller must redo the bag in fp32 mode
     int self_reset;  // v2: 1 = the last workgroup leaves the control block's counters at zero (default); 0 = the host memsets (A/B knob)
+    int pair_split;  // v2, D_inner = 256: GEMM1 with the feature tiles split over wave pairs (half the weight-fragment reads per MFMA)
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
     const unsigned* cond;     // v1 (fp32 repeat of the device-side range guard): run only if *cond != 0 (the status word the preceding
                               //     split-f16 launch on this stream left); null = unconditional

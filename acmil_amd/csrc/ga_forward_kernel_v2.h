@@ -47,9 +47,10 @@
 #define GA2_MFMA2(A, B, C) ((GA2_ABL & 8) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
 __device__ __forceinline__ f32x16 ga2_keep(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
 
-template <int ND, int KP, int XDT>
+template <int ND, int KP, int XDT, int WV = 4>
 struct Ga2Geom {
-    static constexpr int WAVES = 4;                                 // one wave per SIMD; two workgroups per CU
+    static constexpr int WAVES = WV;                                // 4: one wave per SIMD, two workgroups per CU; 8: ONE 256-patch workgroup
+    static constexpr int WGS = 8 / WV;                              //    per CU (the weight stream crosses L2 -> LDS once per 256 patches)
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;     // bytes per bag element
     static constexpr int WROWS = 2 * ND;                            // fragment rows per step ("hi" rows then "lo" rows)
     static_assert(WROWS % WAVES == 0, "every wave copies the same number of consecutive fragment rows");
@@ -75,14 +76,14 @@ struct Ga2Geom {
     static constexpr int ML_BYTES = WAVES * 8 * 2 * 4 + 16;         // (max, sum) [wave][8], then the drawn tile index
     // the epilogue scratch lives in the ring slot that is free between two tiles when a separate region would cost the
     // second workgroup of the CU (80 KiB each)
-    static constexpr bool SCRATCH_IN_RING = (RING + WAVES * PW + TAB_BYTES + PL_BYTES + ML_BYTES > 80 * 1024);
+    static constexpr bool SCRATCH_IN_RING = (WGS * (RING + WAVES * PW + TAB_BYTES + PL_BYTES + ML_BYTES) > 160 * 1024);
     static_assert(!SCRATCH_IN_RING || REGION >= PW, "free-slot scratch must hold a wave's pooling tile / combine record");
     static constexpr int SCR_OFF = RING;                            // separate scratch (when not in the ring)
     static constexpr int TAB_OFF = RING + (SCRATCH_IN_RING ? 0 : WAVES * PW);
     static constexpr int PL_OFF = TAB_OFF + TAB_BYTES;
     static constexpr int ML_OFF = PL_OFF + PL_BYTES;
     static constexpr int LDS = ML_OFF + ML_BYTES;
-    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static_assert(WGS * LDS <= 160 * 1024, "WGS workgroups per CU");
     static constexpr int frow(int r) { return (r / RW) * REGION + (r % RW) * 1024; }   // fragment row r inside a slot
 };
 
@@ -106,10 +107,11 @@ __device__ __forceinline__ float ga2_dpp(float v, float idv) {
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-template <int ND, int KP, int XDT, bool POOL, bool SAVEH>
-__global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
+template <int ND, int KP, int XDT, bool POOL, bool SAVEH, int WV = 4, bool PAIR = false>
+__global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
+    static_assert(!PAIR || ND == 8, "the wave-pair split is built for D_inner = 256 (two h tiles per GEMM2 step)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = Ga2Geom<ND, KP, XDT>;
+    using G = Ga2Geom<ND, KP, XDT, WV>;
     constexpr int WAVES = G::WAVES, NTHR = 64 * WAVES;
     constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
     constexpr int Di = G::Di, PD = G::PD, NB = G::NB;
@@ -135,8 +137,11 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     // ---- tile bookkeeping (wave-uniform, SGPRs)
     struct TileInfo { int N, m0, rmax; const char* xrow0; float* A_out; };
     auto tile_info = [&](int t) {
-        int bag = 0;
-        while (bag + 1 < a.nbags && t >= a.tile_start[bag + 1]) ++bag;
+        int bag = 0, top = a.nbags - 1;          // largest bag with tile_start[bag] <= t (binary search: up to 64 bags per launch)
+        while (bag < top) {
+            const int mid = (bag + top + 1) >> 1;
+            if (t >= a.tile_start[mid]) bag = mid; else top = mid - 1;
+        }
         TileInfo ti;
         ti.N = a.Ns[bag];
         ti.m0 = (t - a.tile_start[bag]) * G::ROWS + wave * 32;
@@ -286,154 +291,374 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         // range guard of the split-f16 arithmetic: largest |bag value| this lane converted (as a bit pattern, so that inf and
         // NaN rank above every finite value), largest feature it produced
         unsigned hmax = 0u;
-        // ======================================================= GEMM1: h^T = W1 * x^T
-        {
+#ifdef GA2_PROF
+        unsigned long long pf_t1 = 0, pf_vm1 = 0, pf_bar1 = 0;
+#endif
+        // wave-pair parity: own feature tiles are the actual tiles 2t + hp (PAIR), register order r <-> actual tile r ^ hp
+        const int hp = PAIR ? (wave & 1) : 0;
+        f16x8 hh[ND][2], hl[ND][2];
+        if constexpr (PAIR) {
+            // ==================================================== GEMM1 with D_inner split over a WAVE PAIR (ND = 8)
+            // Waves (w, w^1) share their 64 patches: each computes HALF of the feature tiles -- actual tiles a = 2t + hp, hp = w & 1 --
+            // for BOTH 32-patch groups (gamma = 0: its own group, gamma = 1: the partner's), so one weight fragment feeds two
+            // MFMAs: per K step a wave reads 4 hi + 4 lo fragment rows (8 KiB instead of 16) and two bag tiles (its own and its
+            // partner's DMA region, 4 KiB instead of 2) for the same 24 MFMAs and the same 128 accumulator registers.  Afterwards
+            // the partners exchange the halves they computed for each other through the ring slot that is free at that moment
+            // (8 rounds of 2 KiB per wave, double-buffered, one LDS barrier each), and every wave continues exactly as in the
+            // unsplit kernel with all of h for its own 32 patches -- in the register order r <-> actual tile r ^ hp (own tiles in
+            // the even slots, received tiles in the odd ones), which only shifts a few LDS / global ADDRESSES further down.
             const int ln = ga2_lane();
             const int i31 = ln & 31, hi = ln >> 5;
             const int lane16 = ln * 16;
             unsigned xoff[G::XG];
             tile_xoff(T, ln, xoff);
-            // x operand of a step: raw read from the wave's own tile, then f16 hi/lo split
-            const int xrd0 = wave * G::REGION + G::RW * 1024 +
-                             ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
-            const int xrd1 = wave * G::REGION + G::RW * 1024 + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
-            f32x4 xr0, xr1;      // raw fp32
-            u32x4 xrw;           // raw 16-bit (8 elements)
+            const int xl0 = (G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16));
+            const int xl1 = i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
+            const int xb[2] = {wave * G::REGION + G::RW * 1024, (wave ^ 1) * G::REGION + G::RW * 1024};
+            f32x4 xr0[2], xr1[2];
+            u32x4 xrw[2];
             auto read_x = [&](const char* slot) {
-                if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
-                else xrw = *(const u32x4*)(slot + xrd0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if constexpr (XDT == ACMIL_DTYPE_F32) { xr0[g] = *(const f32x4*)(slot + xb[g] + xl0); xr1[g] = *(const f32x4*)(slot + xb[g] + xl1); }
+                    else xrw[g] = *(const u32x4*)(slot + xb[g] + xl0);
+                }
             };
-            // split piece j (< NSP) of the raw tile into word j of the hi / lo operands (two K slots per piece)
-            constexpr int NSP = XLO ? 4 : 0;
-            u32x4 xhw, xlw;
-            auto split_piece = [&](int j) {
+            constexpr int NSP = XLO ? 8 : 0;      // split pieces per step: 2 groups x 4
+            u32x4 xhw[2], xlw[2];
+            auto split_piece = [&](int q) {
+                const int g = q >> 2, j = q & 3;
                 float v0, v1;
                 if constexpr (XDT == ACMIL_DTYPE_F32) {
-                    v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
-                    v1 = j < 2 ? xr0[2 * (j & 1) + 1] : xr1[2 * (j & 1) + 1];
+                    v0 = j < 2 ? xr0[g][2 * (j & 1)] : xr1[g][2 * (j & 1)];
+                    v1 = j < 2 ? xr0[g][2 * (j & 1) + 1] : xr1[g][2 * (j & 1) + 1];
                 } else {
-                    v0 = __builtin_bit_cast(float, xrw[j] << 16);
-                    v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
+                    v0 = __builtin_bit_cast(float, xrw[g][j] << 16);
+                    v1 = __builtin_bit_cast(float, xrw[g][j] & 0xffff0000u);
                 }
                 unsigned h, l;
                 ga2_split_pair(v0, v1, h, l);
-                xhw[j] = h; xlw[j] = l;
+                xhw[g][j] = h; xlw[g][j] = l;
             };
-            auto split_done = [&](f16x8& h8, f16x8& l8) {
-                if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
-                else h8 = __builtin_bit_cast(f16x8, xrw);
+            f16x8 xh[2], xl[2], xhp[2];
+            auto split_done = [&]() {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if constexpr (XLO) { xh[g] = __builtin_bit_cast(f16x8, xhw[g]); xl[g] = __builtin_bit_cast(f16x8, xlw[g]); }
+                    else xh[g] = __builtin_bit_cast(f16x8, xrw[g]);
+                }
             };
-            f16x8 WH[ND], WL[ND];
+            // fragment rows of this wave: hi row 2t + hp, lo row ND + 2t + hp (wave-uniform offsets)
+            int fro[4], frl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int rh = 2 * t + hp, rl = ND + 2 * t + hp;
+                fro[t] = (rh / G::RW) * G::REGION + (rh % G::RW) * 1024;
+                frl[t] = (rl / G::RW) * G::REGION + (rl % G::RW) * 1024;
+            }
+            f16x8 WH[4], WL[4];
             auto read_hi = [&](const char* slot) {
 #pragma unroll
-                for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
+                for (int t = 0; t < 4; ++t) WH[t] = *(const f16x8*)(slot + fro[t] + lane16);
             };
             auto read_lo = [&](const char* slot) {
 #pragma unroll
-                for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
+                for (int t = 0; t < 4; ++t) WL[t] = *(const f16x8*)(slot + frl[t] + lane16);
             };
             __builtin_amdgcn_s_setprio(GA2_PRIO_GEMM);
-            f16x8 xh, xl, xhp;
-            // defined values at loop entry: otherwise LLVM treats the fragments of the PREVIOUS tile's last step as the
-            // incoming values of the step loop and keeps 36 registers alive (spilled) through GEMM2 and the epilogue
 #pragma unroll
-            for (int d = 0; d < ND; ++d) WL[d] = (f16x8)(_Float16)0.0f;
-            xhp = (f16x8)(_Float16)0.0f;
+            for (int t = 0; t < 4; ++t) WL[t] = (f16x8)(_Float16)0.0f;
+            xhp[0] = xhp[1] = (f16x8)(_Float16)0.0f;
+            // accumulator of (tile t, group g): acc1[2 t + g]
             for (int s = 0; s < S1; ++s) {
                 step_sync(s + 1 < S1);
                 const char* slot = smem + rslot * G::SLOT;
-                read_x(slot);      // first: the LDS returns data in order, so the split can start under the hi-fragment reads
+                read_x(slot);
                 read_hi(slot);
                 __builtin_amdgcn_sched_barrier(0);
                 if (s > 0) {
-                    // P3(s-1) covers the reads above; the split of x(s) runs in its first MFMA gaps
+                    // P3(s-1) covers the reads above; the split of x(s) runs in its MFMA gaps
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) {
-                        acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
-                        if (d < NSP) {
+                    for (int m = 0; m < 8; ++m) {
+                        acc1[m] = GA2_MFMA1(WL[m >> 1], xhp[m & 1], acc1[m]);
+                        if (m < NSP) {
                             __builtin_amdgcn_sched_barrier(0);
-                            split_piece(d);
+                            split_piece(m);
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                } else {   // first step of the tile: nothing deferred yet
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NSP; ++j) split_piece(j);
+                    for (int q = 0; q < NSP; ++q) split_piece(q);
                 }
-                split_done(xh, xl);
+                split_done();
                 __builtin_amdgcn_sched_barrier(0);
                 read_lo(slot);
-                // P1(s), one LDS-DMA piece of step s+PD per MFMA gap (bag rows only while that step is still a GEMM1 step)
                 const bool wx = s + PD < S1;
 #pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
+                for (int m = 0; m < 8; ++m) {
+                    acc1[m] = GA2_MFMA1(WH[m >> 1], xh[m & 1], acc1[m]);
                     __builtin_amdgcn_sched_barrier(0);
-                    GA2_DMA_AT(d, s + PD, islot, (unsigned)lane16, wx, T.xrow0, xoff);
+                    GA2_DMA_AT(m, s + PD, islot, (unsigned)lane16, wx, T.xrow0, xoff);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 islot = (islot + 1 == NB) ? 0 : islot + 1;
                 if constexpr (XLO) {
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
+                    for (int m = 0; m < 8; ++m) acc1[m] = GA2_MFMA1(WH[m >> 1], xl[m & 1], acc1[m]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                xhp = xh;
+                xhp[0] = xh[0]; xhp[1] = xh[1];
                 rslot = (rslot + 1 == NB) ? 0 : rslot + 1;
             }
-            // P3 of the last GEMM1 step
 #pragma unroll
-            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+            for (int m = 0; m < 8; ++m) acc1[m] = GA2_MFMA1(WL[m >> 1], xhp[m & 1], acc1[m]);
             __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
-        }
 #ifdef GA2_PROF
-        const unsigned long long pf_t1 = __builtin_amdgcn_s_memtime();
-        const unsigned long long pf_vm1 = pf_vm, pf_bar1 = pf_bar;
+            pf_t1 = __builtin_amdgcn_s_memtime(); pf_vm1 = pf_vm; pf_bar1 = pf_bar;
 #endif
-
-        // ======================================================= relu + f16 split of h
-        // acc1[d][r] holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)].  The empty asm statements keep LLVM from
-        // sinking the relu / split into the GEMM2 steps (old and new values live together -> hundreds of spills).
-        // Range guard, once per tile and OUTSIDE the GEMM loop: the largest pre-activation as a bit pattern (orders finite < inf
-        // < NaN).  A bag value outside the f16 range converts to inf in its hi half and turns every feature of its patch into
-        // inf / NaN, so this one test covers the bag values too (checking them inside the loop cost ~9 % of the kernel).
+            // ---- relu, range guard, f16 split; exchange of the partner-group halves
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {     // sign shifted out: magnitudes order as unsigned integers, inf / NaN of either sign on top
-                const unsigned b0 = __builtin_bit_cast(unsigned, acc1[d][r]) << 1, b1 = __builtin_bit_cast(unsigned, acc1[d][r + 1]) << 1;
-                const unsigned m = b0 > b1 ? b0 : b1;
-                hmax = hmax > m ? hmax : m;
-            }
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
-#pragma unroll
-        for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
-        f16x8 hh[ND][2], hl[ND][2];
-#pragma unroll
-        for (int d = 0; d < ND; ++d)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                u32x4 hw, lw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned h, l;
-                    ga2_split_pair(acc1[d][8 * e + 2 * j], acc1[d][8 * e + 2 * j + 1], h, l);
-                    hw[j] = h; lw[j] = l;
+                for (int r = 0; r < 16; r += 2) {
+                    const unsigned b0 = __builtin_bit_cast(unsigned, acc1[d][r]) << 1, b1 = __builtin_bit_cast(unsigned, acc1[d][r + 1]) << 1;
+                    const unsigned m = b0 > b1 ? b0 : b1;
+                    hmax = hmax > m ? hmax : m;
                 }
-                hh[d][e] = __builtin_bit_cast(f16x8, hw);
-                hl[d][e] = __builtin_bit_cast(f16x8, lw);
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
+            // Exchange buffers (per wave, lane-linear 1-KiB pieces): the ring slot consumed last is free until GEMM2's second step
+            // issues into it -- its per-wave region holds pieces 0..REGION/1024-1 -- and the bag part of the NEXT slot (it carries
+            // GEMM2 step 0: weight rows only) two more.  fp32 bags: 8 pieces = two 4-piece buffers, ONE round per feature tile
+            // (hi + lo halves together, 5 barriers per tile of 128 patches); 16-bit bags (5 + 1 pieces): two rounds per feature tile.
+            const int xslot = (rslot == 0) ? NB - 1 : rslot - 1;
+            const int xoffs_mine = xslot * G::SLOT + wave * G::REGION, xoffs_part = xslot * G::SLOT + (wave ^ 1) * G::REGION;
+            const int nslot = rslot;      // slot of GEMM2 step 0
+            const int xlane16 = ga2_lane() * 16;
+            constexpr bool ONE_ROUND = (G::XE == 4);
+            auto piece = [&](int base_wave_off, int wv, int pc) -> int {      // byte offset of exchange piece pc (0..7) of wave wv
+                if (pc < G::REGION / 1024) return base_wave_off + pc * 1024;
+                return nslot * G::SLOT + wv * G::REGION + G::RW * 1024 + (pc - G::REGION / 1024) * 1024;
+            };
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                // own group: registers 2t of the final order
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    u32x4 hw, lw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned h, l;
+                        ga2_split_pair(acc1[2 * t][8 * e + 2 * j], acc1[2 * t][8 * e + 2 * j + 1], h, l);
+                        hw[j] = h; lw[j] = l;
+                    }
+                    hh[2 * t][e] = __builtin_bit_cast(f16x8, hw);
+                    hl[2 * t][e] = __builtin_bit_cast(f16x8, lw);
+                }
+                // partner's group: split, hand over
+                f16x8 sh[2], sl[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    u32x4 hw, lw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned h, l;
+                        ga2_split_pair(acc1[2 * t + 1][8 * e + 2 * j], acc1[2 * t + 1][8 * e + 2 * j + 1], h, l);
+                        hw[j] = h; lw[j] = l;
+                    }
+                    sh[e] = __builtin_bit_cast(f16x8, hw);
+                    sl[e] = __builtin_bit_cast(f16x8, lw);
+                }
+                if constexpr (ONE_ROUND) {
+                    const int b = 4 * (t & 1);
+                    *(f16x8*)(smem + piece(xoffs_mine, wave, b + 0) + xlane16) = sh[0];
+                    *(f16x8*)(smem + piece(xoffs_mine, wave, b + 1) + xlane16) = sh[1];
+                    *(f16x8*)(smem + piece(xoffs_mine, wave, b + 2) + xlane16) = sl[0];
+                    *(f16x8*)(smem + piece(xoffs_mine, wave, b + 3) + xlane16) = sl[1];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    hh[2 * t + 1][0] = *(const f16x8*)(smem + piece(xoffs_part, wave ^ 1, b + 0) + xlane16);
+                    hh[2 * t + 1][1] = *(const f16x8*)(smem + piece(xoffs_part, wave ^ 1, b + 1) + xlane16);
+                    hl[2 * t + 1][0] = *(const f16x8*)(smem + piece(xoffs_part, wave ^ 1, b + 2) + xlane16);
+                    hl[2 * t + 1][1] = *(const f16x8*)(smem + piece(xoffs_part, wave ^ 1, b + 3) + xlane16);
+                } else {
+                    *(f16x8*)(smem + xoffs_mine + xlane16) = sh[0];
+                    *(f16x8*)(smem + xoffs_mine + 1024 + xlane16) = sh[1];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    hh[2 * t + 1][0] = *(const f16x8*)(smem + xoffs_part + xlane16);
+                    hh[2 * t + 1][1] = *(const f16x8*)(smem + xoffs_part + 1024 + xlane16);
+                    *(f16x8*)(smem + xoffs_mine + 2048 + xlane16) = sl[0];
+                    *(f16x8*)(smem + xoffs_mine + 3072 + xlane16) = sl[1];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_s_barrier();
+                    hl[2 * t + 1][0] = *(const f16x8*)(smem + xoffs_part + 2048 + xlane16);
+                    hl[2 * t + 1][1] = *(const f16x8*)(smem + xoffs_part + 3072 + xlane16);
+                }
             }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
-        for (int d = 0; d < ND; ++d)
+            for (int d = 0; d < ND; ++d)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                asm volatile("" : "+v"(hh[d][e]));
-                asm volatile("" : "+v"(hl[d][e]));
+                for (int e = 0; e < 2; ++e) {
+                    asm volatile("" : "+v"(hh[d][e]));
+                    asm volatile("" : "+v"(hl[d][e]));
+                }
+        } else {
+            // ======================================================= GEMM1: h^T = W1 * x^T
+            {
+                const int ln = ga2_lane();
+                const int i31 = ln & 31, hi = ln >> 5;
+                const int lane16 = ln * 16;
+                unsigned xoff[G::XG];
+                tile_xoff(T, ln, xoff);
+                // x operand of a step: raw read from the wave's own tile, then f16 hi/lo split
+                const int xrd0 = wave * G::REGION + G::RW * 1024 +
+                                 ((G::XG == 2) ? (i31 * 64 + (((2 * hi) ^ ((i31 >> 2) & 3)) * 16)) : (i31 * 32 + ((hi ^ ((i31 >> 3) & 1)) * 16)));
+                const int xrd1 = wave * G::REGION + G::RW * 1024 + i31 * 64 + (((2 * hi + 1) ^ ((i31 >> 2) & 3)) * 16);   // fp32 only
+                f32x4 xr0, xr1;      // raw fp32
+                u32x4 xrw;           // raw 16-bit (8 elements)
+                auto read_x = [&](const char* slot) {
+                    if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
+                    else xrw = *(const u32x4*)(slot + xrd0);
+                };
+                // split piece j (< NSP) of the raw tile into word j of the hi / lo operands (two K slots per piece)
+                constexpr int NSP = XLO ? 4 : 0;
+                u32x4 xhw, xlw;
+                auto split_piece = [&](int j) {
+                    float v0, v1;
+                    if constexpr (XDT == ACMIL_DTYPE_F32) {
+                        v0 = j < 2 ? xr0[2 * (j & 1)] : xr1[2 * (j & 1)];
+                        v1 = j < 2 ? xr0[2 * (j & 1) + 1] : xr1[2 * (j & 1) + 1];
+                    } else {
+                        v0 = __builtin_bit_cast(float, xrw[j] << 16);
+                        v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
+                    }
+                    unsigned h, l;
+                    ga2_split_pair(v0, v1, h, l);
+                    xhw[j] = h; xlw[j] = l;
+                };
+                auto split_done = [&](f16x8& h8, f16x8& l8) {
+                    if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
+                    else h8 = __builtin_bit_cast(f16x8, xrw);
+                };
+                f16x8 WH[ND], WL[ND];
+                auto read_hi = [&](const char* slot) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) WH[d] = *(const f16x8*)(slot + G::frow(d) + lane16);
+                };
+                auto read_lo = [&](const char* slot) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
+                };
+                __builtin_amdgcn_s_setprio(GA2_PRIO_GEMM);
+                f16x8 xh, xl, xhp;
+                // defined values at loop entry: otherwise LLVM treats the fragments of the PREVIOUS tile's last step as the
+                // incoming values of the step loop and keeps 36 registers alive (spilled) through GEMM2 and the epilogue
+#pragma unroll
+                for (int d = 0; d < ND; ++d) WL[d] = (f16x8)(_Float16)0.0f;
+                xhp = (f16x8)(_Float16)0.0f;
+                for (int s = 0; s < S1; ++s) {
+                    step_sync(s + 1 < S1);
+                    const char* slot = smem + rslot * G::SLOT;
+                    read_x(slot);      // first: the LDS returns data in order, so the split can start under the hi-fragment reads
+                    read_hi(slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s > 0) {
+                        // P3(s-1) covers the reads above; the split of x(s) runs in its first MFMA gaps
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) {
+                            acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+                            if (d < NSP) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                split_piece(d);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    } else {   // first step of the tile: nothing deferred yet
+#pragma unroll
+                        for (int j = 0; j < NSP; ++j) split_piece(j);
+                    }
+                    split_done(xh, xl);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_lo(slot);
+                    // P1(s), one LDS-DMA piece of step s+PD per MFMA gap (bag rows only while that step is still a GEMM1 step)
+                    const bool wx = s + PD < S1;
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) {
+                        acc1[d] = GA2_MFMA1(WH[d], xh, acc1[d]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        GA2_DMA_AT(d, s + PD, islot, (unsigned)lane16, wx, T.xrow0, xoff);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    islot = (islot + 1 == NB) ? 0 : islot + 1;
+                    if constexpr (XLO) {
+#pragma unroll
+                        for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    xhp = xh;
+                    rslot = (rslot + 1 == NB) ? 0 : rslot + 1;
+                }
+                // P3 of the last GEMM1 step
+#pragma unroll
+                for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WL[d], xhp, acc1[d]);
+                __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
             }
 
+#ifdef GA2_PROF
+            pf_t1 = __builtin_amdgcn_s_memtime(); pf_vm1 = pf_vm; pf_bar1 = pf_bar;
+#endif
+            // ======================================================= relu + f16 split of h
+            // acc1[d][r] holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)].  The empty asm statements keep LLVM from
+            // sinking the relu / split into the GEMM2 steps (old and new values live together -> hundreds of spills).
+            // Range guard, once per tile and OUTSIDE the GEMM loop: the largest pre-activation as a bit pattern (orders finite < inf
+            // < NaN).  A bag value outside the f16 range converts to inf in its hi half and turns every feature of its patch into
+            // inf / NaN, so this one test covers the bag values too (checking them inside the loop cost ~9 % of the kernel).
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {     // sign shifted out: magnitudes order as unsigned integers, inf / NaN of either sign on top
+                    const unsigned b0 = __builtin_bit_cast(unsigned, acc1[d][r]) << 1, b1 = __builtin_bit_cast(unsigned, acc1[d][r + 1]) << 1;
+                    const unsigned m = b0 > b1 ? b0 : b1;
+                    hmax = hmax > m ? hmax : m;
+                }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[d][r] = fmaxf(acc1[d][r], 0.0f);
+#pragma unroll
+            for (int d = 0; d < ND; ++d) asm volatile("" : "+v"(acc1[d]));
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    u32x4 hw, lw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned h, l;
+                        ga2_split_pair(acc1[d][8 * e + 2 * j], acc1[d][8 * e + 2 * j + 1], h, l);
+                        hw[j] = h; lw[j] = l;
+                    }
+                    hh[d][e] = __builtin_bit_cast(f16x8, hw);
+                    hl[d][e] = __builtin_bit_cast(f16x8, lw);
+                }
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    asm volatile("" : "+v"(hh[d][e]));
+                    asm volatile("" : "+v"(hl[d][e]));
+                }
+
+        }
         // ======================================================= GEMM2 (four unit blocks) + gate + scores
         float sc[KP];
 #pragma unroll
@@ -450,9 +675,18 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             for (int g = 0; g < 4; ++g) {
                 const int ln = ga2_lane();
                 const int hi = ln >> 5, lane16 = ln * 16;
+                // (PAIR: register tile r holds the actual tile r ^ hp, i.e. the two h tiles of a step are swapped for odd waves)
+                int goff[4][4];
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = (PAIR ? (grp ^ (2 * hp)) : grp) * 4 + t;
+                        goff[grp][t] = (row / G::RW) * G::REGION + (row % G::RW) * 1024;
+                    }
                 auto readgrp = [&](const char* slot, int grp, f16x8 (&F)[4]) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) F[t] = *(const f16x8*)(slot + G::frow(grp * 4 + t) + lane16);
+                    for (int t = 0; t < 4; ++t) F[t] = *(const f16x8*)(slot + goff[grp][t] + lane16);
                 };
                 // unit block g = units 32g..32g+31: accumulator tile al = 0 tanh branch, 1 sigmoid branch; init = bias
                 f32x16 acc2[2];
@@ -691,7 +925,7 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 const int kk = 4 * hi + r;
                 if (kk < KP) {
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) comb[kk * Di + 32 * d + i31] = pk[d][r];
+                    for (int d = 0; d < ND; ++d) comb[kk * Di + 32 * (d ^ hp) + i31] = pk[d][r];
                 }
             }
             if (dynamic && has_next && wave == 0) draw_publish();
@@ -746,7 +980,7 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                     if constexpr (SAVEH) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * c + i31] = hv[e];
+                            if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * (c ^ hp) + i31] = hv[e];
                     }
                 }
             }
@@ -796,22 +1030,34 @@ __global__ __launch_bounds__(256, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     }
 }
 
-// persistent launch: two workgroups per CU (or one per tile when there are fewer tiles)
-template <int ND, int KP, int XDT>
-int ga_launch_fwd2(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    using G = Ga2Geom<ND, KP, XDT>;
-    static const int slots = [] {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
-        return 2 * prop.multiProcessorCount;
-    }();
-    static const hipError_t attr[2] = {
-        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS),
-        hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)};
-    if (attr[0] != hipSuccess || attr[1] != hipSuccess) return ACMIL_ERR_LAUNCH;
+// persistent launch: WGS workgroups per CU (or one per tile when there are fewer tiles).  The dynamic-LDS attribute and the CU
+// count are looked up per DEVICE (a process may drive several GPUs, or switch device after the first call)
+template <int ND, int KP, int XDT, int WV, bool PAIR>
+int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
+    using G = Ga2Geom<ND, KP, XDT, WV>;
+    static int slots_of[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
+    if (slots_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, true, false, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, false, true, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+            return ACMIL_ERR_LAUNCH;
+        slots_of[dev] = G::WGS * prop.multiProcessorCount;
+    }
+    const int slots = slots_of[dev];
     const int tiles = a.tile_start[a.nbags];
-    const dim3 grid(tiles < slots ? tiles : slots), block(256);
-    void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, true, false> : ga_fwd2_kernel<ND, KP, XDT, false, true>;
+    const dim3 grid(tiles < slots ? tiles : slots), block(64 * WV);
+    void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, true, false, WV, PAIR> : ga_fwd2_kernel<ND, KP, XDT, false, true, WV, PAIR>;
     hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+template <int ND, int KP, int XDT>
+int ga_launch_fwd2(const GaFwdArgs& a, bool pool, hipStream_t st) {
+    if constexpr (ND == 8) {
+        if (a.pair_split) return a.waves == 8 ? ga_launch_fwd2_w<ND, KP, XDT, 8, true>(a, pool, st) : ga_launch_fwd2_w<ND, KP, XDT, 4, true>(a, pool, st);
+    }
+    return a.waves == 8 ? ga_launch_fwd2_w<ND, KP, XDT, 8, false>(a, pool, st) : ga_launch_fwd2_w<ND, KP, XDT, 4, false>(a, pool, st);
 }

@@ -44,6 +44,7 @@ extern "C" {
 #define ACMIL_MAX_TOKENS 16 /* K = n_token supported by this build (Step3_WSI_classification_ACMIL.py:39 --n_token; transformer.py:292-301) */
 #define ACMIL_MAX_TOKENS_FUSED 5 /* ... by the single-kernel forward families and the one-call training step; K above runs the composed kernels */
 #define ACMIL_MAX_CLASSES 16
+#define ACMIL_MAX_BATCH 64   /* bags per acmil_ga_forward_batch / _guarded launch */
 
 /* Library / build identification; returns a static string. */
 const char* acmil_version(void);
@@ -98,7 +99,7 @@ int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int 
                      float* h_save, int has_bag_head, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Batched eval forward: up to 16 bags (different N allowed, same weights) in ONE launch of the fused kernel, one
+ * Batched eval forward: up to ACMIL_MAX_BATCH (64) bags (different N allowed, same weights) in ONE launch of the fused kernel, one
  * merge and one heads launch.  Same maths per bag as acmil_ga_forward; exists because a single 50 000-patch bag
  * only occupies 196 of the 256 CUs (tile quantisation) -- a batch keeps all of them busy.  xs / A_outs: HOST arrays
  * of nbags device pointers (A_outs or its entries may be NULL); Ns: HOST array; sub_preds [B,K,C],

@@ -172,6 +172,62 @@ def test_batched_forward_equals_per_bag_forward(precision):
     assert torch.equal(single["A_out"], out["A_out"][2])
 
 
+def test_large_batch_launch_of_64_ragged_bags():
+    """One launch takes up to 64 bags (binary search of the tile -> bag map): 64 ragged bags equal their single launches bit for
+    bit; a 65th is refused with ACMIL_ERR_SHAPE."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    sd = O.default_state_dict(512, 256, 2, 5)
+    model = _build(sd, 5, 2, 512, 256, "f16x3").eval()
+    packed, dims = model._packed()
+    ns = [1 + (97 * i * i) % 3000 for i in range(64)]
+    xs = [O.synthetic_bag(n, 512, 300 + i)[0].cuda() for i, n in enumerate(ns)]
+    out = ops.ga_forward_batch(xs, packed, dims, "f16x3")
+    for i in (0, 1, 17, 31, 32, 47, 63):
+        single = ops.ga_forward(xs[i], packed, dims, "f16x3")
+        assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
+        assert torch.equal(single["slide_pred"], out["slide_pred"][i])
+    with pytest.raises(RuntimeError, match="ACMIL_ERR_SHAPE"):
+        ops.ga_forward_batch(xs + [xs[0]], packed, dims, "f16x3")
+
+
+def test_wave_pair_split_variant_matches_default():
+    """ACMIL_GA2_PAIR=1 (GEMM1 with D_inner split over wave pairs + exchange, ga_forward_kernel_v2.h) and ACMIL_GA2_WAVES=8
+    (256-patch workgroups) are opt-in tile geometries of the same arithmetic: run in their own process (the library reads the
+    knobs once), their scores equal the default kernel's -- bit for bit at 8 waves, to fp32 round-off with the pair split (odd waves
+    accumulate the two h tiles of a GEMM2 step in swapped order)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from acmil_amd import ops; from oracle import ga_oracle as O\n"
+        "sd = {k: v.cuda() for k, v in O.default_state_dict(512, 256, 2, 5).items()}\n"
+        "packed, dims = ops.ga_pack_weights(sd['dimreduction.fc1.weight'], sd['attention.attention_V.0.weight'], sd['attention.attention_V.0.bias'],"
+        " sd['attention.attention_U.0.weight'], sd['attention.attention_U.0.bias'], sd['attention.attention_weights.weight'],"
+        " sd['attention.attention_weights.bias'], [sd['classifier.%%d.fc.weight' %% i] for i in range(5)],"
+        " [sd['classifier.%%d.fc.bias' %% i] for i in range(5)], sd['Slide_classifier.fc.weight'], sd['Slide_classifier.fc.bias'], 'f16x3')\n"
+        "xs = [O.synthetic_bag(n, 512, 500 + i)[0].cuda() for i, n in enumerate([3000, 129, 777])]\n"
+        "xs.append(xs[0].half())\n"
+        "outs = [ops.ga_forward(x, packed, dims, 'f16x3') for x in xs]\n"
+        "torch.save([(o['A_out'].cpu(), o['sub_preds'].cpu(), o['slide_pred'].cpu()) for o in outs], sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("base", {}), ("pair", {"ACMIL_GA2_PAIR": "1"}), ("w8", {"ACMIL_GA2_WAVES": "8"}), ("pair8", {"ACMIL_GA2_PAIR": "1", "ACMIL_GA2_WAVES": "8"})):
+            e = dict(os.environ); e.pop("ACMIL_GA2_PAIR", None); e.pop("ACMIL_GA2_WAVES", None); e.update(env)
+            path = os.path.join(d, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            res[tag] = torch.load(path)
+    for tag in ("pair", "w8", "pair8"):
+        for (a0, s0, b0), (a1, s1, b1) in zip(res["base"], res[tag]):
+            if tag == "w8":
+                assert torch.equal(a0, a1), tag                   # per-patch scores: identical arithmetic and accumulation order
+            assert (a0 - a1).abs().max() < 2e-6, tag              # pair split: odd waves add the two h tiles of a GEMM2 step in swapped order
+            assert (s0 - s1).abs().max() < 2e-6 and (b0 - b1).abs().max() < 2e-6, tag      # pooled over other tile shapes at most
+
+
 def test_repeated_launches_are_bitwise_reproducible():
     """Race screen for the LDS-DMA ring / counted vmcnt pipeline: 20 launches over rotating bags, identical outputs."""
     from acmil_amd import ops
