@@ -320,7 +320,11 @@ static TmGeom tm_geom(int N, int D, int Di, int C) {
 
 static size_t tm_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, GEMM, total; };
+struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, GEMM, total; };
+
+// transmil_pinv.hip: the whole Moore-Penrose iteration of one layer as ONE launch (one workgroup per head); opt-in, see tm_layer
+bool tm_pinv_fused_supported(int m);
+int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, float* ST, const unsigned* scal, int m, int iters, hipStream_t st);
 
 static TmWs tm_ws(const TmGeom& g) {
     TmWs w; size_t off = 0;
@@ -330,7 +334,7 @@ static TmWs tm_ws(const TmGeom& g) {
     w.S1 = off; off += tm_al((size_t)TM_HEADS * g.npad * g.m * 4);
     w.S3 = off; off += tm_al((size_t)TM_HEADS * g.m * g.npad * 4);
     w.QL = off; off += md; w.KL = off; off += md; w.AV = off; off += md; w.W2 = off; off += md;
-    w.S2 = off; off += mm; w.Z = off; off += mm; w.XZ = off; off += mm; w.T1 = off; off += mm; w.T2 = off; off += mm;
+    w.S2 = off; off += mm; w.Z = off; off += mm; w.ZT = off; off += mm; w.XZ = off; off += mm; w.T1 = off; off += mm; w.T2 = off; off += mm;
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
     w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
@@ -411,10 +415,23 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
     if (hipMemsetAsync(scal, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3((m + 3) / 4, H), dim3(256), 0, st, S2, m, scal);
-    hipLaunchKernelGGL(tm_pinv_init_kernel, dim3(256), dim3(256), 0, st, S2, m, scal, Z);
     TM_CHECK_LAUNCH();
     float* zc = Z; float* zn = T2;     // ping-pong z
-    for (int it = 0; it < 6; ++it) {
+    // ACMIL_TM_PINV_FUSED=1: ONE launch for the 24 products (transmil_pinv.hip: one 8-wave workgroup per head, operands staged
+    // through LDS, split-f16).  Correct (the TransMIL suite passes with it), but OPT-IN: 8 workgroups occupy 8 CUs and a 192^3
+    // product costs ~16 us there (MFMA floor 4.3 us on one CU + staging / store / barrier latency) against 12.6 us for the
+    // launch-per-product chain over 72 workgroups (exact fp32 MFMA) below: 3.70 vs 3.56 ms per N = 100 000 slide.  Also measured
+    // without gain: the chain on a second stream beside the fused attention leg (3.60 vs 3.62 ms).
+    static const bool pinv_one = getenv("ACMIL_TM_PINV_FUSED") != nullptr;
+    const bool pinv_fused = tm_pinv_fused_supported(m) && pinv_one;
+    if (pinv_fused) {
+        rc = tm_pinv_fused(S2, Z, (float*)(ws + W.ZT), XZ, T1, T2, scal, m, 6, st);
+        if (rc != ACMIL_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(tm_pinv_init_kernel, dim3(256), dim3(256), 0, st, S2, m, scal, Z);
+        TM_CHECK_LAUNCH();
+    }
+    for (int it = 0; it < (pinv_fused ? 0 : 6); ++it) {
         float* spare = (zc == Z) ? T2 : Z;
         // xz = x z ; t1 = 7I - xz ; t = 15I - xz t1 ; t1 = 13I - xz t ; z' = 0.25 z t1
         TM_PINV_GEMM(0, 0, m, m, m, 1.0f, S2, m, mm, zc, ACMIL_DTYPE_F32, m, mm, 7.0f, XZ, m, mm, nullptr, 4, T1, H, gws, st);   // + t1 = 7I - xz

@@ -1,0 +1,227 @@
+// transmil_pinv.hip -- the Moore-Penrose iteration of the Nystrom attention as ONE launch: one workgroup per head.
+//
+// Reference: moore_penrose_iter_pinv, architecture/nystrom_attention.py:12-27:
+//     z0 = x^T / (max_i sum_j |x_ij| * max_j sum_i |x_ij|)            (maxima over ALL heads: tm_pinv_maxsum_kernel, transmil.hip)
+//     6 x:  xz = x z ;  z <- 1/4 z (13 I - xz (15 I - xz (7 I - xz)))
+// The launch-per-product chain (24 batched [m x m x m] products + 2 per layer, acmil_gemm_f32) spent 12.6 us per product on
+// launch + fill latency for 14 MFLOP per head: 0.33 ms per layer, 18 % of the TransMIL forward.  Here the heads are
+// independent after the global maxima, so each head is ONE 8-wave workgroup that runs all 24 products back to back:
+//   * operands stay in global memory (5 matrices of m x m fp32 per head: L2-resident) and are staged per 32-wide K chunk
+//     into LDS as f16 hi / lo planes (double-buffered, one LDS barrier per chunk);
+//   * every product is C = A B with B given TRANSPOSED, so both operand chunks are K-contiguous rows: the epilogue of the
+//     producing product writes whichever layouts its consumers need (row-major for A operands, transposed -- one float4 per
+//     lane -- for B operands), so no product ever transposes anything;
+//   * arithmetic: split-f16, 3 MFMA products (v_mfma_f32_16x16x32_f16), fp32 accumulate, each operand matrix pre-scaled by a
+//     power of two taken from its own running max |.| (tracked by the epilogues), so the halves sit in the f16 normal range
+//     whatever the conditioning; the iteration is self-correcting, the fixtures bound the end result.
+#include "ga_common.h"
+
+#define TP_HEADS 8
+typedef float tp_f32x4 __attribute__((ext_vector_type(4)));
+
+enum { TP_EPI_XZ = 0, TP_EPI_C15 = 1, TP_EPI_C13 = 2, TP_EPI_Z = 3 };
+
+__device__ __forceinline__ float tp_scale_of(unsigned amax_bits) {      // 2^(14 - floor(log2 amax)): scaled max in [2^14, 2^15)
+    const int e = (int)((amax_bits >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    int se = 268 - e;
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+
+template <int M>
+struct TpGeom {
+    static constexpr int NTHR = 512;            // 8 waves (2 per SIMD, 256 VGPRs each) as 2 x 4 output blocks
+    static constexpr int WBR = M / 2, WBC = M / 4;      // rows / columns of a wave's output block
+    static constexpr int NTR = WBR / 16, NTC = WBC / 16; // 16 x 16 tiles per block side
+    static constexpr int PLANE = M * 64;        // one f16 plane of a chunk: M rows x 32 k
+    static constexpr int BUF = 4 * PLANE;       // A hi, A lo, B hi, B lo
+    static constexpr int LDS = 2 * BUF;
+    static constexpr int F4 = 16 * M / NTHR;    // float4 loads per thread per chunk (A and B together)
+    static_assert(M % 64 == 0 && M <= 192, "built for m = 64, 128, 192 (D_inner 128, 256, 384)");
+};
+
+// byte offset of (row, 16-byte K group kg) inside a plane; XOR swizzle: rows 4 apart share a bank group otherwise
+__device__ __forceinline__ int tp_off(int row, int kg) { return row * 64 + ((kg ^ ((row >> 2) & 3)) << 4); }
+
+// C = alpha * A * B with BT = B^T given; EPI selects the outputs (see the kernel).  amax slots: index of A's, B's and the outputs'.
+template <int M, int EPI>
+__device__ __forceinline__ void tp_gemm(const float* __restrict__ A, const float* __restrict__ BT, float* __restrict__ O0,
+                                        float* __restrict__ O1, unsigned* amax, int ia, int ib, int io0, int io1, char* smem) {
+    using G = TpGeom<M>;
+    // an OPAQUE copy of the thread id per product: without it LLVM hoists every address of all four products of an iteration
+    // (staging pointers, LDS offsets, 18 tiles x 5 epilogue addresses each) out of the iteration loop and spills hundreds of registers
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r0 = wr * G::WBR, c0 = wc * G::WBC;
+    const float sa = tp_scale_of(amax[ia]), sb = tp_scale_of(amax[ib]);
+    __syncthreads();                                    // everybody has read the operand maxima
+    if (tid == 0) { amax[io0] = 0u; if (io1 >= 0) amax[io1] = 0u; }
+    tp_f32x4 acc[G::NTR][G::NTC];
+#pragma unroll
+    for (int i = 0; i < G::NTR; ++i)
+#pragma unroll
+        for (int j = 0; j < G::NTC; ++j) acc[i][j] = tp_f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging map: float4 q of this thread: e = q * 1024 + tid -> matrix (e >= 8M: B), row (e % 8M) / 8, float4 k4 = e % 8
+    tp_f32x4 st[G::F4];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < G::F4; ++q) {
+            const int e = q * G::NTHR + tid;
+            const bool isb = e >= 8 * M;
+            const int r = (isb ? e - 8 * M : e) >> 3, k4 = e & 7;
+            st[q] = *(const tp_f32x4*)((isb ? BT : A) + (size_t)r * M + 32 * c + 4 * k4);
+        }
+    };
+    auto lstore = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < G::F4; ++q) {
+            const int e = q * G::NTHR + tid;
+            const bool isb = e >= 8 * M;
+            const int r = (isb ? e - 8 * M : e) >> 3, k4 = e & 7;
+            const float s = isb ? sb : sa;
+            unsigned h0, l0, h1, l1;
+            ga_split_pair_f16(st[q][0] * s, st[q][1] * s, h0, l0);
+            ga_split_pair_f16(st[q][2] * s, st[q][3] * s, h1, l1);
+            char* p = buf + (isb ? 2 * G::PLANE : 0) + tp_off(r, k4 >> 1) + (k4 & 1) * 8;
+            *(uint2*)p = make_uint2(h0, h1);
+            *(uint2*)(p + G::PLANE) = make_uint2(l0, l1);
+        }
+    };
+    constexpr int NC = M / 32;
+    gload(0);
+    lstore(smem);
+    ga_lds_barrier();
+    const int fr = lane & 15, kg = lane >> 4;
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) gload(c + 1);
+        const char* buf = smem + (c & 1) * G::BUF;
+        f16x8 bh[G::NTC], bl[G::NTC];
+#pragma unroll
+        for (int t = 0; t < G::NTC; ++t) {
+            const int ob = tp_off(c0 + 16 * t + fr, kg);
+            bh[t] = *(const f16x8*)(buf + 2 * G::PLANE + ob);
+            bl[t] = *(const f16x8*)(buf + 3 * G::PLANE + ob);
+        }
+#pragma unroll
+        for (int i = 0; i < G::NTR; ++i) {
+            const int oa = tp_off(r0 + 16 * i + fr, kg);
+            const f16x8 ah = *(const f16x8*)(buf + oa);
+            const f16x8 al = *(const f16x8*)(buf + G::PLANE + oa);
+#pragma unroll
+            for (int j = 0; j < G::NTC; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (c + 1 < NC) lstore(smem + ((c + 1) & 1) * G::BUF);
+        ga_lds_barrier();
+    }
+    // ---- epilogue.  Lane holds C[row0 + i][col], i < 4, row0 = r0 + 16 ti + 4 (lane >> 4), col = c0 + 16 tj + (lane & 15).
+    // (all global reads of A / BT are complete: the last chunk was staged before the last barrier -- in-place outputs are safe)
+    const float inv = 1.0f / (sa * sb);
+    float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+    for (int ti = 0; ti < G::NTR; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < G::NTC; ++tj) {
+            __builtin_amdgcn_sched_barrier(0);      // one tile at a time: otherwise every tile's addresses and temporaries are live together
+            const int row0 = r0 + 16 * ti + 4 * kg, col = c0 + 16 * tj + fr;
+            tp_f32x4 v = acc[ti][tj] * inv;
+            if constexpr (EPI == TP_EPI_XZ) {            // O0 = xz (row-major: the A operand of the next two products), O1 = (7 I - xz)^T
+                tp_f32x4 t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    O0[(size_t)(row0 + i) * M + col] = v[i];
+                    t[i] = ((row0 + i == col) ? 7.0f : 0.0f) - v[i];
+                    m0 = fmaxf(m0, fabsf(v[i])); m1 = fmaxf(m1, fabsf(t[i]));
+                }
+                *(tp_f32x4*)(O1 + (size_t)col * M + row0) = t;
+            } else if constexpr (EPI == TP_EPI_C15 || EPI == TP_EPI_C13) {      // O0 = (c I - P)^T only (consumed as a B operand)
+                constexpr float cI = (EPI == TP_EPI_C15) ? 15.0f : 13.0f;
+                tp_f32x4 t;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { t[i] = ((row0 + i == col) ? cI : 0.0f) - v[i]; m0 = fmaxf(m0, fabsf(t[i])); }
+                *(tp_f32x4*)(O0 + (size_t)col * M + row0) = t;
+            } else {                                      // z' = 1/4 z t: O0 = z' (row-major, in place over A), O1 = z'^T
+                v = v * 0.25f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { O0[(size_t)(row0 + i) * M + col] = v[i]; m0 = fmaxf(m0, fabsf(v[i])); }
+                *(tp_f32x4*)(O1 + (size_t)col * M + row0) = v;
+            }
+        }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o)); m1 = fmaxf(m1, __shfl_xor(m1, o)); }
+    if (lane == 0) {
+        atomicMax(&amax[io0], __float_as_uint(m0));
+        if (EPI == TP_EPI_XZ) atomicMax(&amax[io1], __float_as_uint(m1));
+        if (EPI == TP_EPI_Z) atomicMax(&amax[io1], __float_as_uint(m0));
+    }
+    __syncthreads();      // outputs (global) and maxima (LDS) visible to the whole workgroup
+}
+
+// grid = heads.  X = softmax(sim2) [H][m][m]; Z (row-major) receives the pseudo-inverse; ZT, XZ, T1T, ST: scratch of the same size.
+template <int M>
+__global__ __launch_bounds__(512) void tm_pinv_fused_kernel(const float* __restrict__ X_all, float* __restrict__ Z_all,
+                                                             float* __restrict__ ZT_all, float* __restrict__ XZ_all,
+                                                             float* __restrict__ T1T_all, float* __restrict__ ST_all,
+                                                             const unsigned* __restrict__ scal, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned amax[8];        // 0 x, 1 z (= z^T), 2 xz, 3 t1, 4 s
+    const size_t hoff = (size_t)blockIdx.x * M * M;
+    const float* X = X_all + hoff;
+    float *Z = Z_all + hoff, *ZT = ZT_all + hoff, *XZ = XZ_all + hoff, *T1T = T1T_all + hoff, *ST = ST_all + hoff;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 8) amax[tid] = 0u;
+    __syncthreads();
+    // z0 = x^T / (max row sum * max column sum), both layouts; max |x| on the way
+    const float inv = 1.0f / (__uint_as_float(scal[0]) * __uint_as_float(scal[1]));
+    float mx = 0.0f;
+    for (int e = tid; e < M * M; e += 512) {
+        const int i = e / M, j = e - i * M;
+        const float x = X[e];
+        mx = fmaxf(mx, fabsf(x));
+        ZT[e] = x * inv;
+        Z[(size_t)j * M + i] = x * inv;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) { atomicMax(&amax[0], __float_as_uint(mx)); atomicMax(&amax[1], __float_as_uint(mx * inv)); }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        tp_gemm<M, TP_EPI_XZ>(X, ZT, XZ, T1T, amax, 0, 1, 2, 3, smem);          // xz = x z ; t1 = 7 I - xz
+        tp_gemm<M, TP_EPI_C15>(XZ, T1T, ST, nullptr, amax, 2, 3, 4, -1, smem);  // s = 15 I - xz t1
+        tp_gemm<M, TP_EPI_C13>(XZ, ST, T1T, nullptr, amax, 2, 4, 3, -1, smem);  // t1 = 13 I - xz s
+        tp_gemm<M, TP_EPI_Z>(Z, T1T, Z, ZT, amax, 1, 3, 1, 1, smem);            // z = 1/4 z t1
+    }
+}
+
+// launcher (transmil.hip): false = this m has no fused instance (the caller keeps its product chain)
+bool tm_pinv_fused_supported(int m) { return m == 64 || m == 128 || m == 192; }
+
+template <int M>
+static int tm_pinv_launch(const float* X, float* Z, float* ZT, float* XZ, float* T1T, float* ST, const unsigned* scal, int iters, hipStream_t st) {
+    static bool attr_done[16] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
+    if (!attr_done[dev]) {
+        if (hipFuncSetAttribute((const void*)tm_pinv_fused_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, TpGeom<M>::LDS) != hipSuccess)
+            return ACMIL_ERR_LAUNCH;
+        attr_done[dev] = true;
+    }
+    hipLaunchKernelGGL(tm_pinv_fused_kernel<M>, dim3(TP_HEADS), dim3(512), TpGeom<M>::LDS, st, X, Z, ZT, XZ, T1T, ST, scal, iters);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, float* ST, const unsigned* scal, int m, int iters, hipStream_t st) {
+    switch (m) {
+        case 64: return tm_pinv_launch<64>(X, Z, ZT, XZ, T1T, ST, scal, iters, st);
+        case 128: return tm_pinv_launch<128>(X, Z, ZT, XZ, T1T, ST, scal, iters, st);
+        case 192: return tm_pinv_launch<192>(X, Z, ZT, XZ, T1T, ST, scal, iters, st);
+    }
+    return ACMIL_ERR_UNSUPPORTED;
+}

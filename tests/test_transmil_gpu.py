@@ -132,3 +132,32 @@ def test_reference_parity_at_the_baseline_width():
             ref_stat = z["%s.%s_stat" % (key, stage)]
             stat = np.array([float(got.mean()), float(got.abs().mean()), float(got.abs().max())])
             np.testing.assert_allclose(stat, ref_stat, rtol=1e-4, atol=1e-5, err_msg=key + stage)
+
+
+def test_one_launch_pinv_kernel_matches_the_product_chain():
+    """ACMIL_TM_PINV_FUSED=1 (csrc/transmil_pinv.hip: the 24 Moore-Penrose products of a layer as ONE launch, one workgroup per
+    head, split-f16) against the default launch-per-product chain (exact fp32 MFMA), nystrom_attention.py:12-27: logits of the
+    same bags agree to 1e-5 at m = 64 / 128 / 192 (D_inner 128 / 256 / 384).  Own process: the library reads the knob once."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from acmil_amd import ops; from acmil_amd import synthetic as S\n"
+        "res = []\n"
+        "for n, d, di in ((700, 384, 128), (1500, 512, 256), (3000, 768, 384)):\n"
+        "    sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=3).items()}\n"
+        "    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda()\n"
+        "    res.append(ops.transmil_forward(x, sd, 2)['logits'].cpu())\n"
+        "torch.save(res, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("chain", {}), ("one", {"ACMIL_TM_PINV_FUSED": "1"})):
+            e = dict(os.environ); e.pop("ACMIL_TM_PINV_FUSED", None); e.update(env)
+            path = os.path.join(d, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:]
+            out[tag] = torch.load(path)
+    for a, b in zip(out["chain"], out["one"]):
+        assert torch.isfinite(b).all() and (a - b).abs().max().item() < 1e-5, (a, b)
