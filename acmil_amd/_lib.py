@@ -47,6 +47,7 @@ SIGNATURES = {
     "acmil_linear_packed_bytes": (_sz, [_i, _i]),
     "acmil_linear_pack": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "acmil_linear_f16x3": (_i, [_vp, _i, _i, _i, C.c_longlong, _vp, _i, _vp, _i, C.c_float, _vp, C.c_longlong, _vp, _vp]),
+    "acmil_gated_scores_packed": (_i, [_vp, _i, _i, _i, C.c_longlong, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "acmil_mha_workspace_bytes": (_sz, [_i] * 5),
     "acmil_mha_forward": (_i, [_vp] + [_i] * 5 + [_vp, _vp] + [C.POINTER(_vp)] * 4 + [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "acmil_gated_scores_workspace_bytes": (_sz, [_i] * 4),

@@ -183,6 +183,7 @@ class _GatedBase(nn.Module):
         """Drop the packed-weight caches (for optimizers that update the parameters outside torch's version counters)."""
         self._pack_cache = None
         self._w1_cache = None
+        self._gate_cache = None
         self.__dict__.pop("_pack_cache_alt", None)
 
     # D_inner with a fully fused forward kernel (csrc/ga_families.inc); the reference's other feature extractors
@@ -211,27 +212,51 @@ class _GatedBase(nn.Module):
         base = self._raw_params()[0]
         prec = "fp32" if self.precision == "fp32" else "f16x3"
 
+        status = None
+
         def project(prec):
+            nonlocal status
             if prec == "f16x3" and xb.stride(0) * xb.element_size() % 16 == 0:
                 # packed-weight Linear kernel (csrc/linear_kernel.h): takes fp32 / fp16 / bf16 bags as they are; ~20 % faster than the
-                # generic split GEMM at these shapes (K >= 768, 256-wide output chunks)
-                return ops.linear_f16x3(xb, self._packed_w1(), base[0].shape[0], relu=True)
+                # generic split GEMM at these shapes (K >= 768, 256-wide output chunks); leaves the range word of the fused kernels
+                h, status = ops.linear_f16x3(xb, self._packed_w1(), base[0].shape[0], relu=True, want_status=True)
+                return h
             x32 = xb if xb.dtype == torch.float32 else xb.float()      # storage-format conversion of a 16-bit bag
             return ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
 
         h = project(prec)
         if prec == "f16x3" and self.range_guard:
-            # Same rule as the fused kernel's status word, on the same quantity: the projected features.  A bag value outside the
-            # f16 range has an inf hi half and makes its patch's features inf / NaN, so ONE pass over h [N, Di] covers both (the
-            # composed kernels carry no status word; this reduction is the guard's cost here).
-            hmax = h.max()
-            if not bool(torch.isfinite(hmax) & (hmax < 65504.0)):
+            # Same rule as the fused kernel's status word, on the same quantity: the projected features (a bag value outside the f16
+            # range has an inf hi half and makes its patch's features inf / NaN, so the one test covers both).  The projection kernel
+            # leaves the word; the generic-GEMM route (odd row strides) pays one reduction over h instead.
+            if status is not None:
+                bad = int(status) != 0
+            else:
+                hmax = h.max()
+                bad = not bool(torch.isfinite(hmax) & (hmax < 65504.0))
+            if bad:
                 self._fb_host = getattr(self, "_fb_host", 0) + 1
                 prec = "fp32"
                 self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
                 h = project(prec)
-        A = ops.gated_scores(h, *[p.detach() for p in base[1:7]], precision=prec)
+        if prec == "f16x3" and h.shape[1] % 16 == 0:
+            # one pass over h: [Wv; Wu] product with the gate formed in the accumulators (csrc/linear_kernel.h, act = 2)
+            pvu, bvu = self._packed_gate()
+            A = ops.gated_scores_packed(h, pvu, bvu, base[5], base[6])
+        else:
+            A = ops.gated_scores(h, *[p.detach() for p in base[1:7]], precision=prec)
         return A, h
+
+    def _packed_gate(self):
+        """Fragment stream + bias of the interleaved [Wv; Wu] matrix for acmil_gated_scores_packed, re-packed when a parameter changed."""
+        a = self.attention
+        ps = [a.attention_V[0].weight, a.attention_V[0].bias, a.attention_U[0].weight, a.attention_U[0].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_gate_cache", None)
+        if cache is None or cache[0] != key:
+            cache = (key,) + ops.pack_gate(*[p.detach() for p in ps])
+            self._gate_cache = cache
+        return cache[1], cache[2]
 
     def _packed_w1(self):
         """Fragment stream of dimreduction.fc1.weight for acmil_linear_f16x3, re-packed when the parameter changed."""

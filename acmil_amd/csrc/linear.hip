@@ -79,9 +79,11 @@ extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long
     if (((size_t)x & 15) != 0 || ((size_t)ldx * xe) % 16 != 0) return ACMIL_ERR_SHAPE;     // 16-byte LDS-DMA pieces
     hipStream_t st = (hipStream_t)stream;
     unsigned* ctr = (unsigned*)workspace;
-    if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
+    a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
+    a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
     const int nfull = n_out / 256;
     int rc = ACMIL_OK;
     if (nfull > 0) {
@@ -95,4 +97,27 @@ extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long
         rc = lin_launch_dt<4>(a, x_dtype, st);
     }
     return rc;
+}
+
+// Gated-attention scores of an already projected bag h [N, L] in ONE pass over h (Attention_Gated.forward,
+// architecture/transformer.py:259-267; attention width 128): the [Wv; Wu] product runs as the packed-weight Linear kernel above with
+// the gate formed in the accumulators -- h is read once, the [N, 256] pre-activations never exist in memory.
+// packed_vu = acmil_linear_pack of the [256, L] matrix whose rows are [Wv 0..31; Wu 0..31; Wv 32..63; Wu 32..63; ...], bias_vu [256]
+// in the same order.  Replaces the two GEMMs + gate pass of acmil_gated_scores at the widths it covers (K <= 16, L % 16 == 0).
+extern "C" int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int L, long long ldh, const void* packed_vu,
+                                         const float* bias_vu, const float* Ww, const float* bw, int K, float* A, void* workspace,
+                                         void* stream) {
+    if (N <= 0 || L <= 0 || L % 16 != 0 || ldh < L || K <= 0) return ACMIL_ERR_SHAPE;
+    if (K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
+    if (!h || !packed_vu || !bias_vu || !Ww || !bw || !A || !workspace) return ACMIL_ERR_NULL;
+    const int xe = (h_dtype == ACMIL_DTYPE_F32) ? 4 : 2;
+    if (((size_t)h & 15) != 0 || ((size_t)ldh * xe) % 16 != 0 || ((size_t)bias_vu & 15) != 0 || ((size_t)Ww & 15) != 0) return ACMIL_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* ctr = (unsigned*)workspace;
+    if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    LinArgs a;
+    a.x = h; a.ldx = ldh; a.M = N; a.K = L; a.bias = bias_vu; a.act = 2; a.beta = 0.0f; a.y = nullptr; a.ldy = 0;
+    a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr;
+    a.ww = Ww; a.bw = bw; a.scores = A; a.kb = K; a.status = nullptr;
+    return lin_launch_dt<8>(a, h_dtype, st);
 }

@@ -23,8 +23,18 @@ struct LinArgs {
     float* y;               // [M, ldy] fp32; this launch writes columns col0 .. col0 + nchunks * 32 ND
     unsigned* tile_counter; // zeroed word (dynamic tile drawing) or null
     long long ldx, ldy;
-    int M, K, nchunks, col0, act;   // act: 0 none, 1 relu
+    int M, K, nchunks, col0, act;   // act: 0 none, 1 relu, 2 gated-attention scores (below)
     float beta;                     // y = act(acc + bias) + beta * y_old   (residual adds)
+    // act == 2 (ND = 8, one chunk): the 256 output columns are the attention pre-activations in the order [Wv units 32p..32p+31 |
+    // Wu units 32p..32p+31], p = 0..3 (so accumulator tiles 2p / 2p+1 hold the tanh / sigmoid branch of the SAME units in the same
+    // registers); the epilogue forms gate = tanh(.) * sigmoid(.) in registers and writes only the K raw scores per row:
+    // scores[k][row] = sum_u gate[u] ww[k][u] + bw[k]   (Attention_Gated.forward, architecture/transformer.py:259-267) -- no y store
+    const float* ww;                // [kb][128]
+    const float* bw;                // [kb]
+    float* scores;                  // [kb][M]
+    int kb;
+    unsigned* status;               // or null: bit 1 is OR-ed in when an output of a VALID row is >= 65504 in magnitude, inf or NaN -- the
+                                    // range rule of the split-f16 arithmetic (ga_forward_kernel_v2.h) for consumers that split y again
 };
 
 template <int ND, int XDT>
@@ -236,6 +246,50 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
             __builtin_amdgcn_s_setprio(0);
         }
 
+        // ======================================================= epilogue (gated scores): gate in registers, K scores per row
+        bool gated = false;
+        if constexpr (ND == 8) gated = a.act == 2;
+        if (gated) {
+            if constexpr (ND == 8) {
+                const int lane = opaque_lane();
+                const int i31 = lane & 31, hi = lane >> 5;
+                constexpr int KPG = ACMIL_MAX_TOKENS;
+                float sc[KPG];
+#pragma unroll
+                for (int k = 0; k < KPG; ++k) sc[k] = 0.0f;
+                const int kb = a.kb;
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int ub = 8 * rq + 4 * hi;                        // registers 4rq..4rq+3 <-> units 32p + ub + {0..3}
+                        const f32x4 bv = *(const f32x4*)(a.bias + 64 * p + ub);
+                        const f32x4 bu = *(const f32x4*)(a.bias + 64 * p + 32 + ub);
+                        float gate[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) gate[q] = ga_tanh(acc[2 * p][4 * rq + q] + bv[q]) * ga_sigmoid(acc[2 * p + 1][4 * rq + q] + bu[q]);
+#pragma unroll
+                        for (int k = 0; k < KPG; ++k) {
+                            if (k < kb) {
+                                const f32x4 w = *(const f32x4*)(a.ww + k * GA_DA + 32 * p + ub);
+                                sc[k] = fmaf(gate[0], w[0], sc[k]); sc[k] = fmaf(gate[1], w[1], sc[k]);
+                                sc[k] = fmaf(gate[2], w[2], sc[k]); sc[k] = fmaf(gate[3], w[3], sc[k]);
+                            }
+                        }
+                    }
+                // the two lane halves cover complementary units of the same 32 rows: fold, add bw, one half stores the even branches
+                // and the other the odd ones (32 consecutive floats of a score row each)
+                const int row = T.m0 + i31;
+#pragma unroll
+                for (int k = 0; k < KPG; ++k) {
+                    if (k < kb) {
+                        const float tot = sc[k] + __shfl_xor(sc[k], 32) + a.bw[k];
+                        if ((k & 1) == hi && row < M) a.scores[(size_t)k * M + row] = tot;
+                    }
+                }
+            }
+        } else
         // ======================================================= epilogue: transpose 32 x 32 tiles through the free slot, store rows
         {
             const int lane = opaque_lane();
@@ -243,6 +297,18 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
             const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
             float* pool = (float*)(G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW);
             const int m0 = T.m0;
+            if (a.status) {      // largest |pre-activation| of this lane's row as a bit pattern (finite < inf < NaN), sign shifted out
+                unsigned hm = 0u;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned b = __builtin_bit_cast(unsigned, acc[d][r]) << 1;
+                        hm = hm > b ? hm : b;
+                    }
+                const bool bad = (m0 + i31 < M) && hm >= (0x477fe000u << 1);
+                if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, 2u);
+            }
 #pragma unroll
             for (int c = 0; c < ND; ++c) {
                 __builtin_amdgcn_sched_barrier(0);

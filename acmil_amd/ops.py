@@ -515,6 +515,36 @@ def gated_scores(h: torch.Tensor, Wv, bv, Wu, bu, Ww, bw, precision="f16x3") -> 
     return A
 
 
+def pack_gate(Wv: torch.Tensor, bv: torch.Tensor, Wu: torch.Tensor, bu: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Operands of gated_scores_packed: the fragment stream of the [256, L] matrix whose rows alternate 32 Wv / 32 Wu units (a
+    storage rearrangement of the two weight matrices, then acmil_linear_pack) and the bias vector in the same order."""
+    _need_cuda(Wv, bv, Wu, bu)
+    if Wv.shape[0] != GA_DA or Wu.shape != Wv.shape:
+        raise RuntimeError("acmil_amd.pack_gate: attention width must be 128")
+    L = Wv.shape[1]
+    wcat = torch.stack([Wv.detach().view(4, 32, L), Wu.detach().view(4, 32, L)], dim=1).reshape(2 * GA_DA, L).contiguous()
+    bcat = torch.stack([bv.detach().view(4, 32), bu.detach().view(4, 32)], dim=1).reshape(2 * GA_DA).contiguous()
+    return linear_pack(wcat), bcat
+
+
+def gated_scores_packed(h: torch.Tensor, packed_vu: torch.Tensor, bias_vu: torch.Tensor, Ww: torch.Tensor, bw: torch.Tensor) -> torch.Tensor:
+    """acmil_gated_scores_packed: raw gated-attention scores A [K, N] of a projected bag h [N, L] in ONE pass over h (split-f16 MFMA
+    product with the gate formed in the accumulators; the [N, 256] pre-activations never exist).  Attention width 128."""
+    lib = _lib.load()
+    _need_cuda(h, packed_vu, bias_vu, Ww, bw)
+    Ww, bw = Ww.detach(), bw.detach()
+    if h.dim() != 2 or h.stride(1) != 1 or h.dtype not in _DT or not Ww.is_contiguous() or Ww.dtype != torch.float32 or Ww.shape[1] != GA_DA:
+        raise RuntimeError("acmil_amd.gated_scores_packed: h [N, L] with unit inner stride, Ww contiguous fp32 [K, 128]")
+    N, L = h.shape
+    K = Ww.shape[0]
+    A = torch.empty(K, N, dtype=torch.float32, device=h.device)
+    ws = torch.empty(256, dtype=torch.uint8, device=h.device)
+    rc = lib.acmil_gated_scores_packed(h.data_ptr(), _DT[h.dtype], N, L, h.stride(0), packed_vu.data_ptr(), bias_vu.data_ptr(), Ww.data_ptr(),
+                                       bw.data_ptr(), K, A.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_gated_scores_packed")
+    return A
+
+
 def attn_pool(h: torch.Tensor, A: torch.Tensor) -> torch.Tensor:
     """acmil_attn_pool: softmax over N of the raw scores A [K,N], then the weighted sum afeat [K,Di] = P h."""
     lib = _lib.load()
@@ -590,8 +620,9 @@ def linear_pack(W: torch.Tensor) -> torch.Tensor:
 
 
 def linear_f16x3(x: torch.Tensor, packed: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None, relu: bool = False,
-                 out: Optional[torch.Tensor] = None, beta: float = 0.0) -> torch.Tensor:
-    """acmil_linear_f16x3: y = act(x W^T + bias) + beta * y for x [M, K] (fp32 / fp16 / bf16, unit inner stride)."""
+                 out: Optional[torch.Tensor] = None, beta: float = 0.0, want_status: bool = False):
+    """acmil_linear_f16x3: y = act(x W^T + bias) + beta * y for x [M, K] (fp32 / fp16 / bf16, unit inner stride).
+    want_status: also the device int32 range word of this call (non-zero: an output left the f16 range / was not finite)."""
     lib = _lib.load()
     _need_cuda(x, packed)
     if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in _DT:
@@ -603,5 +634,5 @@ def linear_f16x3(x: torch.Tensor, packed: torch.Tensor, n_out: int, bias: Option
     rc = lib.acmil_linear_f16x3(x.data_ptr(), _DT[x.dtype], M, K, x.stride(0), packed.data_ptr(), n_out, _ptr(bias), int(relu),
                                 float(beta), out.data_ptr(), out.stride(0), ws.data_ptr(), _stream())
     _lib.check(rc, "acmil_linear_f16x3")
-    return out
+    return (out, ws[8:12].view(torch.int32)) if want_status else out
 

@@ -313,6 +313,94 @@ def other_workloads(args):
         print(json.dumps(result))
 
 
+WIDE_SHAPES = {   # the reference's wider feature extractors (Step3_WSI_classification_ACMIL.py:78-87): no single-kernel family, composed path
+    "ga_uni": dict(N=50000, D=1024, Di=512, K=5, C=2, name="UNI (ViT-L/16, 1024 -> 512)"),
+    "ga_gigapath": dict(N=50000, D=1536, Di=768, K=5, C=2, name="GigaPath (ViT-g, 1536 -> 768)"),
+    "ga_clip_l": dict(N=50000, D=768, Di=384, K=5, C=2, name="CLIP-L-336 (768 -> 384)"),
+}
+
+
+def wide_workload(args):
+    """ACMIL-ga eval forward at the wide D_inner families, one slide per step through the product module (`model(x)`: packed-weight
+    projection kernel -> gated scores -> pooling -> merge + heads; h [N, D_inner] makes one HBM round trip).  Same JSON contract."""
+    world, rank, dev = _dist_setup(args)
+    from acmil_amd import _lib, ops
+    from acmil_amd import synthetic as S
+    from acmil_amd.architecture.transformer import ACMIL_GA
+    _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
+    sh = WIDE_SHAPES[args.workload]
+    N, D, Di, K, C = sh["N"], sh["D"], sh["Di"], sh["K"], sh["C"]
+
+    class _Conf:
+        D_feat, D_inner, n_class, n_token = D, Di, C, K
+    sd_cpu = S.ga_state_dict(D, Di, C, K, seed=0)
+    model = ACMIL_GA(_Conf, n_token=K, n_masked_patch=10, mask_drop=0.6, precision=args.precision)
+    model.load_state_dict(sd_cpu)
+    model = model.to(dev).eval()
+    nb = 8
+    bags = [S.synthetic_bag(N, D, slide_idx=rank * nb + i)[0].to(dev) for i in range(nb)]       # 8 x 205 / 307 MB: beyond the 256 MB MALL
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        # the projection kernel alone (events on the launch stream), first: it also brings the device to operating clocks
+        w1 = model._packed_w1()
+        hbuf = torch.empty(N, Di, dtype=torch.float32, device=dev)
+        for i in range(5):
+            ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        n_k = 40
+        for i in range(n_k):
+            ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
+        e1.record()
+        torch.cuda.synchronize()
+        t_lin = e0.elapsed_time(e1) * 1e-3 / n_k
+        dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
+    t_slide = dt / args.steps
+    nbytes, flops = algorithmic_work(N, D, Di, K, C)
+    g1 = 2.0 * N * D * Di
+    executed = 3.0 * flops if args.precision == "f16x3" else flops
+    peak = 2500.0 if args.precision == "f16x3" else 157.3
+    result = {
+        "metric": "slides/sec (ACMIL-ga eval forward, N=%d D=%d D_inner=%d: %s)" % (N, D, Di, sh["name"]),
+        "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_slide * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (projections as split-f16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
+        "config": {"workload": "ACMIL-ga eval forward, one slide per step through the module: N=%d patches, D=%d, D_inner=%d, n_token=%d, "
+                               "n_class=%d, fp32 bags resident in HBM, %d bags rotated; composed kernels (projection -> gated scores -> pooling)"
+                               % (N, D, Di, K, C, nb), "precision": args.precision, "sharding": "independent slides per GPU, no collective"},
+        "roofline": {"kernel": "whole composed forward (lin_kernel projection + gated scores + pooling + merge + heads)", "bound": "mfma",
+                     "achieved": round(flops / t_slide / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / t_slide / 1e12 / peak, 4),
+                     "traffic": None, "executed_tflops": round(executed / t_slide / 1e12, 1), "executed_frac": round(executed / t_slide / 1e12 / peak, 4),
+                     "projection_kernel": {"us_per_launch": round(t_lin * 1e6, 1), "achieved_tflops": round(g1 / t_lin / 1e12, 1),
+                                           "executed_frac": round((3.0 if args.precision == "f16x3" else 1.0) * g1 / t_lin / 1e12 / peak, 4),
+                                           "hbm_gbs": round((N * D * 4 + N * Di * 4) / t_lin / 1e9, 1)},
+                     "hbm": {"achieved": round((nbytes + 2.0 * N * Di * 4) / t_slide / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round((nbytes + 2.0 * N * Di * 4) / t_slide / 1e9 / 8000.0, 4),
+                             "note": "algorithmic bytes + the h [N, D_inner] round trip of the composed path"},
+                     "note": "flops = algorithmic (SURVEY 8d: %.2f GFLOP/slide); executed = x3 for the split products" % (flops / 1e9)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ga_oracle as O                     # the oracle is only ever the CPU baseline / checker
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        x0 = bags[0].cpu().unsqueeze(0)
+        with torch.no_grad():
+            O.acmil_ga_forward(x0, sd_cpu, n_token=K)
+            t0 = time.perf_counter(); n = 0
+            while time.perf_counter() - t0 < 8.0:
+                ref = O.acmil_ga_forward(x0, sd_cpu, n_token=K); n += 1
+            el = time.perf_counter() - t0
+            got = model(bags[0].unsqueeze(0))
+        result["cpu_baseline"] = {"value": round(n / el, 2), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": "%d forwards of one N=%d D=%d bag (%.1f s), torch-CPU oracle" % (n, N, D, el)}
+        result["max_abs_err_vs_oracle"] = max((got[2].cpu() - ref["A_out"]).abs().max().item(), (got[0].cpu() - ref["sub_preds"]).abs().max().item())
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 # GA eval-forward workloads: the BASELINE.json headline and configs[2]
 GA_SHAPES = {
     "ga_eval": dict(N=50000, D=512, Di=256, K=5, C=2, xdtype="float32",
@@ -336,7 +424,7 @@ def main(argv=None):
                          "reference's strictly per-slide call pattern.  A launch of 64 bags is 48 rounds of tiles on the 512 "
                          "persistent workgroups: the ragged last round and merge + heads weigh 2 % instead of 9 % at 16 bags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "ga_cfg3", "transmil", "train"],
+    ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "ga_cfg3", "transmil", "train", "ga_uni", "ga_gigapath", "ga_clip_l"],
                     help="ga_eval = the BASELINE.json headline (default); ga_cfg3 = configs[2] (N=50000, D=384, D_inner=128, bf16 "
                          "bags); transmil = configs[3] (N=100000, D=768 TransMIL eval forward); train = configs[4] (ACMIL "
                          "training step, slide-level DP, gradient all-reduce)")
@@ -351,6 +439,8 @@ def main(argv=None):
         return dry_run(args)
     if args.workload in ("transmil", "train"):
         return other_workloads(args)
+    if args.workload in WIDE_SHAPES:
+        return wide_workload(args)
 
     shape = GA_SHAPES[args.workload]
     N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS = shape["N"], shape["D"], shape["Di"], shape["K"], shape["C"]

@@ -296,6 +296,17 @@ int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, v
 
 int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
                        const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream);
+/* (acmil_linear_f16x3 also leaves a range word in workspace word 2 -- byte offset 8 -- of ITS call: non-zero = an output of a valid
+ *  row was >= 65504 in magnitude, inf or NaN, i.e. a consumer that splits y into f16 halves again must take the fp32 path; an input
+ *  value outside the f16 range poisons its row's outputs and is flagged by the same test.) */
+
+/* Gated-attention scores of a projected bag h [N, L] in ONE pass over h (Attention_Gated.forward, architecture/transformer.py:259-267,
+ * attention width 128, K <= ACMIL_MAX_TOKENS, L % 16 == 0): the [Wv; Wu] product with the gate tanh(.) * sigmoid(.) formed in the
+ * accumulators and only A [K, N] written -- the [N, 256] pre-activations of acmil_gated_scores never exist.  packed_vu =
+ * acmil_linear_pack of the [256, L] matrix with rows [Wv 0..31; Wu 0..31; Wv 32..63; Wu 32..63; ...]; bias_vu [256] in that order.
+ * h fp32 / fp16 / bf16 (h_dtype), 16-byte aligned rows.  workspace: 256 bytes. */
+int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int L, long long ldh, const void* packed_vu, const float* bias_vu,
+                              const float* Ww, const float* bw, int K, float* A, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Gated attention on an already projected bag (the other gated-attention consumers).

@@ -151,3 +151,21 @@ def test_trainer_main_with_eight_branches(tmp_path):
             "--out_dir", out, "--n_token", "8", "--n_masked_patch", "10", "--mask_drop", "0.6"])
     ck = torch.load(os.path.join(out, "checkpoint-last.pth"), weights_only=False)
     assert ck["model"]["attention.attention_weights.weight"].shape == (8, 128) and len([k for k in ck["model"] if k.startswith("classifier.")]) == 16
+
+
+def test_range_guard_on_the_composed_path_uses_the_projection_kernels_status_word():
+    """D_inner 512 (no fused family): a bag value outside the f16 range is flagged by the range word the projection kernel leaves
+    (csrc/linear_kernel.h) -- no extra pass over h -- and the bag is redone in fp32 arithmetic: outputs equal the fp32-mode module's."""
+    case, sd = load_golden("ga_eval_n300_d1024_k5_c7")
+    guarded, exact = _model(sd, "f16x3").eval(), _model(sd, "fp32").eval()
+    x = torch.from_numpy(case["x"]).float().clone()
+    x[0, 17, 5] = 2.0e5
+    with torch.no_grad():
+        before = guarded.range_fallbacks
+        sub_g, slide_g, a_g = guarded(x.cuda())
+        sub_e, slide_e, a_e = exact(x.cuda())
+        assert guarded.range_fallbacks == before + 1
+        assert torch.isfinite(a_g).all() and torch.equal(a_g, a_e) and torch.equal(sub_g, sub_e) and torch.equal(slide_g, slide_e)
+        ok = torch.from_numpy(case["x"]).float().cuda()
+        guarded(ok)
+        assert guarded.range_fallbacks == before + 1          # an in-range bag stays on the split-f16 path
