@@ -37,6 +37,7 @@ SIGNATURES = {
     "acmil_ga_pool": (_i, [_vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _i] + [_vp] * 4 + [_i, _vp, _vp]),
     "acmil_stkim_workspace_bytes": (_sz, [_i] * 3),
     "acmil_stkim_select": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "acmil_stkim_select_rng": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_ulonglong, C.c_ulonglong, _vp, _vp, _vp, _vp]),
     "acmil_gemm_workspace_bytes": (_sz, [_i] * 4),
     "acmil_gemm_f32": (_i, [_i, _i, _i, _i, _i, C.c_float, _vp, _i, C.c_longlong, _vp, _i, _i, C.c_longlong, C.c_float,
                             _vp, _i, C.c_longlong, _vp, _i, _vp, _i, _vp, _vp]),
@@ -89,6 +90,9 @@ SIGNATURES = {
     # D Di Da K C mode | label uniforms k_top m_mask | losses sub slide A_out topk midx guard_flag | workspace stream
     "acmil_ga_train_step": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
                             [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp]),
+    "acmil_ga_train_step_rng": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
+                            [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
+                                [C.c_ulonglong, C.c_ulonglong]),
 }
 
 _lib = None

@@ -302,14 +302,22 @@ class _GatedBase(nn.Module):
         m = int(k * self.mask_drop)
         topk = midx = None
         if k > 0:
-            if uniforms is None:
-                uniforms = torch.rand(dims.K, k, device=xb.device)
-            topk, midx = ops.stkim_select(A, k, m, uniforms)
+            # no injected draw: the STKIM kernel draws its uniforms itself (Philox keyed on this module's seed and forward count)
+            topk, midx = ops.stkim_select(A, k, m, uniforms, rng=None if uniforms is not None else self._next_rng())
         out = ops.ga_pool(h, A, packed, dims, self.precision, midx if m > 0 else None, want_bag_feat=want_bag_feat,
                           want_afeat=want_afeat)
         out["topk_idx"], out["masked_idx"], out["h"] = topk, midx, h
         out["dims_bwd"] = self._bwd_dims
         return out
+
+    def _next_rng(self):
+        """(seed, offset) of the next device-side STKIM draw: the seed is torch's at first use (so torch.manual_seed governs it), the
+        offset counts this module's masked forwards.  Replaces the `torch.rand(K, k)` launch of transformer.py:316."""
+        if getattr(self, "_rng_seed", None) is None:
+            self._rng_seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+            self._rng_count = 0
+        self._rng_count += 1
+        return (self._rng_seed, self._rng_count)
 
     def _all_params(self):
         base, wc, bc, ws, bs = self._raw_params()
@@ -403,8 +411,8 @@ class ACMIL_GA(_GatedBase):
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
         k_top = min(self.n_masked_patch, xb.shape[0]) if masking else 0
-        if masking and uniforms is None:      # drawn here so that an fp32 re-run of the step masks the same patches
-            uniforms = torch.rand(self.attention.attention_weights.weight.shape[0], k_top, device=xb.device)
+        # no injected draw: the kernel draws on the device; ONE (seed, offset) per step, so an fp32 re-run masks the same patches
+        self._step_rng = self._next_rng() if (masking and uniforms is None) else None
         for p in params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
@@ -436,7 +444,7 @@ class ACMIL_GA(_GatedBase):
                 packed, dims = self._packed(precision) if precision != self.precision else self._packed()
                 st = cache[(precision, dev)] = (packed.clone(), dims)      # a private buffer: the call rewrites it every step
             return ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=True,
-                                     guard_flag=guard_flag)
+                                     guard_flag=guard_flag, rng=self._step_rng)
 
         prec = precision or self.precision
         out = run(prec)

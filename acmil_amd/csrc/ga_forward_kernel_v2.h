@@ -110,6 +110,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int ND, int KP, int XDT, bool POOL, bool SAVEH, int WV = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     static_assert(!PAIR || ND == 8, "the wave-pair split is built for D_inner = 256 (two h tiles per GEMM2 step)");
+    static_assert(!PAIR || WV == 4, "exchange buffers: 4 KiB of the free slot's per-wave region (5 - 6 KiB at 4 waves)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Ga2Geom<ND, KP, XDT, WV>;
     constexpr int WAVES = G::WAVES, NTHR = 64 * WAVES;
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             const int xoffs_mine = xslot * G::SLOT + wave * G::REGION, xoffs_part = xslot * G::SLOT + (wave ^ 1) * G::REGION;
             const int nslot = rslot;      // slot of GEMM2 step 0
             const int xlane16 = ga2_lane() * 16;
-            constexpr bool ONE_ROUND = (G::XE == 4);
+            constexpr bool ONE_ROUND = (G::REGION / 1024 + G::XG >= 8);      // fp32 bags at 4 waves (6 + 2 pieces); else two rounds in 4 KiB
             auto piece = [&](int base_wave_off, int wv, int pc) -> int {      // byte offset of exchange piece pc (0..7) of wave wv
                 if (pc < G::REGION / 1024) return base_wave_off + pc * 1024;
                 return nslot * G::SLOT + wv * G::REGION + G::RW * 1024 + (pc - G::REGION / 1024) * 1024;
@@ -1057,7 +1058,7 @@ int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
 template <int ND, int KP, int XDT>
 int ga_launch_fwd2(const GaFwdArgs& a, bool pool, hipStream_t st) {
     if constexpr (ND == 8) {
-        if (a.pair_split) return a.waves == 8 ? ga_launch_fwd2_w<ND, KP, XDT, 8, true>(a, pool, st) : ga_launch_fwd2_w<ND, KP, XDT, 4, true>(a, pool, st);
+        if (a.pair_split && a.waves != 8) return ga_launch_fwd2_w<ND, KP, XDT, 4, true>(a, pool, st);
     }
     return a.waves == 8 ? ga_launch_fwd2_w<ND, KP, XDT, 8, false>(a, pool, st) : ga_launch_fwd2_w<ND, KP, XDT, 4, false>(a, pool, st);
 }

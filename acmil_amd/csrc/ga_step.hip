@@ -386,7 +386,7 @@ extern "C" size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int 
     return gs_layout(N, D, Di, K, C, k_top).total;
 }
 
-extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int repack,
+extern "C" int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* packed, int repack,
                                    const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
                                    const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
                                    const float* Ws, const float* bs,
@@ -395,7 +395,8 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
                                    int D, int Di, int Da, int K, int C, int mode,
                                    const int64_t* label, const float* uniforms, int k_top, int m_mask,
                                    float* losses, float* sub_preds, float* slide_pred, float* A_out,
-                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream) {
+                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                                       unsigned long long rng_seed, unsigned long long rng_offset) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (K > GS_MAXK) return ACMIL_ERR_UNSUPPORTED;       // the one-call step exists for the fused families (K <= 5); K above: op by op
@@ -405,7 +406,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc || !losses || !sub_preds || !A_out) return ACMIL_ERR_NULL;
     const int has_bag_head = Ws != nullptr;
     if (has_bag_head && (!bs || !dWs || !dbs || !slide_pred)) return ACMIL_ERR_NULL;
-    if (k_top > 0 && (!topk_idx || (m_mask > 0 && (!uniforms || !masked_idx)))) return ACMIL_ERR_NULL;
+    if (k_top > 0 && (!topk_idx || (m_mask > 0 && !masked_idx))) return ACMIL_ERR_NULL;      // uniforms null: drawn on the device
     for (int k = 0; k < K; ++k)
         if (!Wc[k] || !bc[k] || !dWc[k] || !dbc[k]) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
@@ -432,7 +433,7 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     // 3 STKIM + mask
     if (k_top > 0) {
         rc = stkim_launch(A_out, m_mask > 0 ? A_out : nullptr, N, K, k_top, m_mask, uniforms, topk_idx, masked_idx,
-                          (unsigned long long*)(ws + W.cand), ctrl + 4, st);
+                          (unsigned long long*)(ws + W.cand), ctrl + 4, st, rng_seed, rng_offset);
         if (rc != ACMIL_OK) return rc;
     }
     // 4 pooling tiles + Gram partials
@@ -464,4 +465,20 @@ extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* pack
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = bws; r.st = st;
     return gb_run(r);
+}
+
+extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int repack,
+                                   const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                   const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                                   const float* Ws, const float* bs,
+                                   float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                                   float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                                   int D, int Di, int Da, int K, int C, int mode,
+                                   const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                                   float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream) {
+    // this entry takes the draw from the caller (_rng draws on the device); shape errors keep their precedence over the null check
+    const bool shape_ok = ga_check_dims(D, Di, Da, K, C) == ACMIL_OK && N > 0 && k_top >= 0 && k_top <= 64 && k_top <= N && m_mask >= 0 && m_mask <= k_top;
+    if (shape_ok && m_mask > 0 && !uniforms) return ACMIL_ERR_NULL;
+    return acmil_ga_train_step_rng(x, x_dtype, N, packed, repack, W1, Wv, bv, Wu, bu, Ww, bw, Wc, bc, Ws, bs, dW1, dWv, dbv, dWu, dbu, dWw, dbw, dWc, dbc, dWs, dbs, D, Di, Da, K, C, mode, label, uniforms, k_top, m_mask, losses, sub_preds, slide_pred, A_out, topk_idx, masked_idx, guard_flag, workspace, stream, 0ull, 0ull);
 }

@@ -86,9 +86,30 @@ __device__ static inline void stkim_merge_wave(const unsigned long long* __restr
 //   one wave per branch: merge the candidates into the sorted top-k, pick the masked subset (the columns with the m smallest
 //   uniforms, argsort ascending, first m, in that order) and -- when A_mask is given -- write the -1e9 mask into the scores
 //   (architecture/transformer.py:311-320).  `arrive` is left at zero for the next launch.
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> 4 x 32 random bits.  The production draw of the STKIM
+// uniforms (`torch.rand(K, k)` of the reference, architecture/transformer.py:316): any iid U[0,1) stream is the same distribution,
+// so the step draws its own on the device -- keyed on (seed, offset = the caller's step number, branch, column) -- instead of paying
+// a torch.rand launch per step; injected uniforms remain for the parity tests.
+__device__ static inline void stkim_philox(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ static inline float stkim_uniform(unsigned long long seed, unsigned long long offset, unsigned branch, unsigned col) {
+    unsigned r[4];
+    stkim_philox(col, branch, (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
+    return (float)(r[0] >> 8) * (1.0f / 16777216.0f);      // 24 random bits: [0, 1)
+}
+
 #define STKIM_MERGE_E 32      // candidates per lane in the merge: nchunks * k <= 64 * 32
 __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, int N, int K,
                                                           int k, int m, const float* __restrict__ uniforms,
+                                                          unsigned long long rng_seed, unsigned long long rng_offset,
                                                           unsigned long long* __restrict__ cand, unsigned* __restrict__ arrive,
                                                           int64_t* __restrict__ topk_idx, int64_t* __restrict__ masked_idx) {
     __shared__ unsigned long long red[2][4];
@@ -138,12 +159,15 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
         else stkim_merge_wave<STKIM_MERGE_E>(c, ncand, k, lane, sel[wave], trow);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // sel[] written by lane 0 is visible to the wave
-        if (lane < k && m > 0) {
-            const float* u = uniforms + (size_t)b * k;
-            const float mine = u[lane];
+        if (m > 0) {
+            // this lane's uniform: injected (parity tests) or drawn here (uniforms == null); rank = position in argsort ascending
+            const float mine = lane < k ? (uniforms ? uniforms[(size_t)b * k + lane] : stkim_uniform(rng_seed, rng_offset, (unsigned)b, (unsigned)lane)) : 2.0f;
             int rank = 0;
-            for (int j = 0; j < k; ++j) rank += (u[j] < mine || (u[j] == mine && j < lane)) ? 1 : 0;
-            if (rank < m) {
+            for (int j = 0; j < k; ++j) {
+                const float uj = __shfl(mine, j);
+                rank += (uj < mine || (uj == mine && j < lane)) ? 1 : 0;
+            }
+            if (lane < k && rank < m) {
                 const unsigned n = sel[wave][lane];
                 masked_idx[(size_t)b * m + rank] = (int64_t)n;
                 if (A_mask && n < (unsigned)N) A_mask[(size_t)b * N + n] = -1e9f;
@@ -161,25 +185,33 @@ extern "C" size_t acmil_stkim_workspace_bytes(int N, int K, int k) {
 
 // shared by acmil_stkim_select and the fused training step (ga_step.hip): one launch; `arrive` must be zero and is left zero
 int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
-                 int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st) {
+                 int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st, unsigned long long rng_seed,
+                 unsigned long long rng_offset) {
     if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
-    if (!scores || !topk_idx || !cand || !arrive || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
+    if (!scores || !topk_idx || !cand || !arrive || (m > 0 && !masked_idx)) return ACMIL_ERR_NULL;      // uniforms null = device draw
     const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
     if ((size_t)nch * k > 64 * STKIM_MERGE_E) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
-    hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, N, K, k, m, uniforms, cand, arrive,
-                       topk_idx, masked_idx);
+    hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, N, K, k, m, uniforms, rng_seed, rng_offset,
+                       cand, arrive, topk_idx, masked_idx);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
-extern "C" int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
-                                  int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
+extern "C" int acmil_stkim_select_rng(const float* scores, int N, int K, int k, int m, const float* uniforms,
+                                      unsigned long long seed, unsigned long long offset, int64_t* topk_idx, int64_t* masked_idx,
+                                      void* workspace, void* stream) {
     if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
-    if (!scores || !topk_idx || !workspace || (m > 0 && (!uniforms || !masked_idx))) return ACMIL_ERR_NULL;
+    if (!scores || !topk_idx || !workspace || (m > 0 && !masked_idx)) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     // stand-alone call on a caller-provided scratch buffer: the arrival counter is zeroed here (the fused step keeps its own)
     if (hipMemsetAsync(workspace, 0, 4, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     return stkim_launch(scores, nullptr, N, K, k, m, uniforms, topk_idx, masked_idx,
-                        (unsigned long long*)((char*)workspace + 256), (unsigned*)workspace, st);
+                        (unsigned long long*)((char*)workspace + 256), (unsigned*)workspace, st, seed, offset);
+}
+
+extern "C" int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
+                                  int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream) {
+    if (m > 0 && !uniforms) return ACMIL_ERR_NULL;      // this entry takes the draw from the caller; _rng draws on the device
+    return acmil_stkim_select_rng(scores, N, K, k, m, uniforms, 0ull, 0ull, topk_idx, masked_idx, workspace, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,8 +12,10 @@ int ga_tail_eval(const float* part, const int* tile_start, int nbags, const void
                  float* slide_pred, float* afeat, float* bag_feat, int has_bag_head, unsigned* arrive, hipStream_t st);
 
 // ga_train.hip
+// uniforms == null: the kernel draws them itself, Philox4x32-10 keyed on (rng_seed, rng_offset, branch, column)
 int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
-                 int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st);
+                 int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st, unsigned long long rng_seed = 0,
+                 unsigned long long rng_offset = 0);
 int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st);
 
 // ga_backward.hip

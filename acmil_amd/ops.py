@@ -225,22 +225,26 @@ def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, with_st
     return (A, h, _range_status(ws)) if with_status else (A, h)
 
 
-def stkim_select(scores: torch.Tensor, k: int, m: int, uniforms: Optional[torch.Tensor]):
-    """acmil_stkim_select: (topk_idx [K,k] int64 sorted by descending score, masked_idx [K,m] int64)."""
+def stkim_select(scores: torch.Tensor, k: int, m: int, uniforms: Optional[torch.Tensor], rng: Optional[Tuple[int, int]] = None):
+    """acmil_stkim_select(_rng): (topk_idx [K,k] int64 sorted by descending score, masked_idx [K,m] int64).
+    uniforms [K,k]: the injected `torch.rand(K, k)` draw (parity tests); None + rng = (seed, offset): drawn on the device (Philox)."""
     lib = _lib.load()
     _need_cuda(scores)
     K, N = scores.shape
     dev = scores.device
     topk = torch.empty(K, k, dtype=torch.int64, device=dev)
     midx = torch.empty(K, m, dtype=torch.int64, device=dev)
-    if m > 0:
-        if uniforms is None or tuple(uniforms.shape) != (K, k):
+    if m > 0 and uniforms is not None:
+        if tuple(uniforms.shape) != (K, k):
             raise RuntimeError("acmil_amd: uniforms must be [K,k]")
         uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+    if m > 0 and uniforms is None and rng is None:
+        raise RuntimeError("acmil_amd: STKIM needs either the uniforms [K,k] or rng = (seed, offset) for the device draw")
+    seed, offset = rng if rng is not None else (0, 0)
     ws = torch.empty(lib.acmil_stkim_workspace_bytes(N, K, k), dtype=torch.uint8, device=dev)
-    rc = lib.acmil_stkim_select(scores.data_ptr(), N, K, k, m, _ptr(uniforms) if m > 0 else None, topk.data_ptr(),
-                                midx.data_ptr() if m > 0 else None, ws.data_ptr(), _stream())
-    _lib.check(rc, "acmil_stkim_select")
+    rc = lib.acmil_stkim_select_rng(scores.data_ptr(), N, K, k, m, _ptr(uniforms) if m > 0 else None, seed & (2 ** 64 - 1), offset & (2 ** 64 - 1),
+                                    topk.data_ptr(), midx.data_ptr() if m > 0 else None, ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_stkim_select_rng")
     return topk, midx
 
 
@@ -340,7 +344,7 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
 
 def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
                   grads: Sequence[torch.Tensor], label: torch.Tensor, uniforms: Optional[torch.Tensor], k_top: int, m_mask: int,
-                  repack: bool = True, guard_flag: Optional[torch.Tensor] = None):
+                  repack: bool = True, guard_flag: Optional[torch.Tensor] = None, rng: Optional[Tuple[int, int]] = None):
     """acmil_ga_train_step: forward with STKIM masking + ACMIL loss + backward of one slide, enqueued by ONE library call.
     params / grads = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0.., bc_0.., (Ws, bs)] (gradients are overwritten).
     Returns a dict: losses [4] (loss0, loss1, diff, total), sub_preds [K,C], slide_pred [C] or None, A_out [K,N] (masked raw
@@ -366,11 +370,13 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
         label = label.to(torch.int64).contiguous()
     if not (0 <= k_top <= N) or not (0 <= m_mask <= k_top):
         raise RuntimeError("acmil_amd.ga_train_step: need 0 <= m_mask <= k_top <= N (got k_top=%d m_mask=%d N=%d)" % (k_top, m_mask, N))
-    if m_mask > 0:
-        if uniforms is None or tuple(uniforms.shape) != (K, k_top):       # the kernel reads row k at stride k_top
-            raise RuntimeError("acmil_amd.ga_train_step: uniforms must be [K=%d, k_top=%d], got %s" % (
-                K, k_top, None if uniforms is None else tuple(uniforms.shape)))
+    if m_mask > 0 and uniforms is None and rng is None:
+        raise RuntimeError("acmil_amd.ga_train_step: masking needs either the uniforms [K, k_top] or rng = (seed, offset) for the device draw")
+    if m_mask > 0 and uniforms is not None:
+        if tuple(uniforms.shape) != (K, k_top):       # the kernel reads row k at stride k_top
+            raise RuntimeError("acmil_amd.ga_train_step: uniforms must be [K=%d, k_top=%d], got %s" % (K, k_top, tuple(uniforms.shape)))
         uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()      # as acmil_stkim_select's wrapper does
+    seed, offset = rng if rng is not None else (0, 0)
     if guard_flag is not None and (guard_flag.dtype != torch.float32 or guard_flag.device != dev or guard_flag.numel() < 1):
         raise RuntimeError("acmil_amd.ga_train_step: guard_flag must be a float32 device scalar")
     fbuf = torch.empty(4 + K * Cc + Cc + K * N, dtype=torch.float32, device=dev)
@@ -382,14 +388,15 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
     gp = [g.data_ptr() for g in grads]
     vpK = ctypes.c_void_p * K
     has_bag = dims.has_bag_head
-    rc = lib.acmil_ga_train_step(
+    rc = lib.acmil_ga_train_step_rng(
         x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), int(repack),
         *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
         *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
         *dims.args(), mode, label.data_ptr(), _ptr(uniforms) if m_mask > 0 else None, k_top, m_mask,
         losses.data_ptr(), sub.data_ptr(), slide.data_ptr() if has_bag else None, A.data_ptr(),
-        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, _ptr(guard_flag), ws.data_ptr(), _stream())
-    _lib.check(rc, "acmil_ga_train_step")
+        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, _ptr(guard_flag), ws.data_ptr(), _stream(),
+        seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
+    _lib.check(rc, "acmil_ga_train_step_rng")
     return {"losses": losses, "sub_preds": sub, "slide_pred": slide if has_bag else None, "A_out": A,
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 

@@ -147,6 +147,12 @@ size_t acmil_stkim_workspace_bytes(int N, int K, int k);
 int acmil_stkim_select(const float* scores, int N, int K, int k, int m, const float* uniforms,
                        int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
 
+/* The same selection with the uniforms drawn ON THE DEVICE when `uniforms` is NULL: Philox4x32-10 keyed on (seed, offset, branch,
+ * column), 24 random bits per draw -- the production form of `torch.rand(K, k)` (architecture/transformer.py:316: any iid U[0,1)
+ * stream is the same distribution; the caller advances `offset` once per forward).  With `uniforms` given it is acmil_stkim_select. */
+int acmil_stkim_select_rng(const float* scores, int N, int K, int k, int m, const float* uniforms, unsigned long long seed,
+                           unsigned long long offset, int64_t* topk_idx, int64_t* masked_idx, void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Exact-fp32 matrix-core GEMM (v_mfma_f32_32x32x2_f32), row-major, optional batch and transpose:
  *   C[b] = act( alpha * op(A[b]) * op(B[b]) + bias[col] + beta * C[b] ),  op(A) M x K, op(B) K x N.
@@ -229,6 +235,21 @@ int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int rep
                         const int64_t* label, const float* uniforms, int k_top, int m_mask,
                         float* losses, float* sub_preds, float* slide_pred, float* A_out,
                         int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream);
+
+/* acmil_ga_train_step with the STKIM uniforms drawn on the device when `uniforms` is NULL (see acmil_stkim_select_rng): no
+ * torch.rand launch per step; a repeat of the step (the fp32 re-run of the range guard) with the same (seed, offset) masks the
+ * same patches. */
+int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* packed, int repack,
+                        const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                        const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                        const float* Ws, const float* bs,
+                        float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                        float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                        int D, int Di, int Da, int K, int C, int mode,
+                        const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                        float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                        int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                            unsigned long long rng_seed, unsigned long long rng_offset);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216

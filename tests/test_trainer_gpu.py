@@ -202,10 +202,10 @@ def test_lagged_range_guard_skips_on_device_and_reports_late():
 def test_evaluate_batched_matches_per_slide_and_guards_lagged():
     """evaluate() groups staged bags into acmil_ga_forward_batch launches of up to 16 and reads the split-f16 range word one batch
     late: per-slide probabilities / losses / div_loss equal the one-slide-per-call loop (Step3_WSI_classification_ACMIL.py:253-268),
-    also with ragged N, more bags than one batch and ONE bag outside the f16 range (its batch is repeated in fp32)."""
+    also with ragged N, more bags than one batch (EVAL_BATCH = 64) and ONE bag outside the f16 range (its batch is repeated in fp32)."""
     T, conf, dev, model, bucket, opt = _guard_setup(seed=3)
     g = torch.Generator().manual_seed(4)
-    bags = [(torch.randn(300 + 53 * i, 384, generator=g).half(), i % 3) for i in range(37)]
+    bags = [(torch.randn(300 + 23 * i, 384, generator=g).half(), i % 3) for i in range(T.EVAL_BATCH + 9)]
     bad = bags[20][0].float().clone(); bad[11, 5] = 2.0e5
     bags[20] = (bad, bags[20][1])
     data = _ListBags(bags)
@@ -223,8 +223,8 @@ def test_evaluate_batched_matches_per_slide_and_guards_lagged():
     for a, b in zip(res_b, res_s):
         assert abs(a - b) < 1e-5
     # bags of batches without a flagged member are bit-identical to the per-slide launch (same kernel, same tile order per bag)
-    keep = [i for i in range(37) if i // 16 != 20 // 16]
-    assert torch.equal(d_b["prob"][keep], d_s["prob"][keep])
+    keep = [i for i in range(len(bags)) if i // T.EVAL_BATCH != 20 // T.EVAL_BATCH]
+    assert len(keep) == 9 and torch.equal(d_b["prob"][keep], d_s["prob"][keep])
 
 
 def test_train_one_epoch_repeats_a_flagged_bag_in_fp32():
