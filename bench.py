@@ -35,11 +35,19 @@ N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, D_ATTN = 50000, 512, 256, 5, 2, 128
 N_BAGS = 16      # resident bags (grown to the batch size in main)
 
 
-def kernel_source_id():
-    """Fingerprint of the fused forward kernel's sources; tools/pmc_ga.py stamps it into every PMC summary it writes."""
+SOURCES_OF = {     # kernel sources whose change invalidates a workload's PMC summary
+    "ga": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"),
+    "transmil": ("transmil.hip", "transmil_attn.hip", "gemm_f32.hip", "gemm_internal.h"),
+    "train": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h", "ga_step.hip", "ga_train.hip", "ga_bwd_tile.hip", "ga_backward.hip",
+              "wgrad.hip", "optim.hip"),
+}
+
+
+def kernel_source_id(workload="ga_eval"):
+    """Fingerprint of a workload's kernel sources; tools/pmc_ga.py stamps it into every PMC summary it writes."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"):
+    for f in SOURCES_OF.get(workload, SOURCES_OF["ga"]):
         with open(os.path.join(ROOT, "acmil_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -62,7 +70,7 @@ def pmc_traffic(workload, precision, batch):
         try:
             with open(f) as fh:
                 js = json.load(fh)
-            if js.get("kernel_source_id") != kernel_source_id():
+            if js.get("kernel_source_id") != kernel_source_id(workload):
                 return None, "PMC summary %s was taken on a different kernel source (%s)" % (os.path.basename(f), js.get("kernel_source_id"))
             return int(js["traffic_bytes_per_launch"]), os.path.basename(f)
         except Exception:
@@ -207,7 +215,8 @@ def other_workloads(args):
                                    "n_class=2, fp32 bag resident in HBM, 4 bags rotated", "sharding": "independent slides per GPU, no collective"},
             "roofline": {"kernel": "whole forward (gemm_f16x3 / tm_attn1x / tm_attn3x / pinv / stencils)", "bound": "mfma",
                          "achieved": round(flops / t_slide / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                         "frac": round(flops / t_slide / 1e12 / 2500.0, 4), "traffic": None,
+                         "frac": round(flops / t_slide / 1e12 / 2500.0, 4), "traffic": pmc_traffic("transmil", "f16x3", 1)[0],
+                         "traffic_source": pmc_traffic("transmil", "f16x3", 1)[1],
                          "executed_tflops": round(executed / t_slide / 1e12, 1),
                          "executed_frac": round(executed / t_slide / 1e12 / 2500.0, 4),
                          "fp32_equivalent_frac": round(flops / t_slide / 1e12 / 157.3, 4),
@@ -283,7 +292,9 @@ def other_workloads(args):
                    "sharding": "slide-level data parallel: one bag per rank, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)"},
         "roofline": {"kernel": "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
                      "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
-                     "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4), "traffic": None,
+                     "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4),
+                     "traffic": pmc_traffic("train", args.precision, 1)[0] if N == 10000 else None,
+                     "traffic_source": pmc_traffic("train", args.precision, 1)[1] if N == 10000 else "no PMC summary at this bag size",
                      "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

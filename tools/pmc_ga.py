@@ -47,6 +47,16 @@ def pick(res, kernel_sub, counter):
     return None, 0
 
 
+def total(res, counter):
+    """sum over ALL kernels of the command: (counter total, dispatches)"""
+    t, n = 0.0, 0
+    for (kn, cn), (avg, cnt) in res.items():
+        if cn == counter:
+            t += avg * cnt
+            n += cnt
+    return t, n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="f16x3")
@@ -54,15 +64,18 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
+    ap.add_argument("--extra", default="", help="further bench.py arguments of the profiled command (e.g. '--train-n 50000')")
+    ap.add_argument("--whole-step", action="store_true",
+                    help="workloads without one dominant kernel (transmil, train): sum the counters over ALL kernels and divide by the steps")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     calib = [os.path.join(ROOT, "build", "exp", "hbm_calib"), "8"]
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--precision", args.precision, "--batch", str(args.batch),
-             "--steps", str(args.steps), "--warmup", "3", "--no-b1", "--no-cpu-baseline"]
+             "--steps", str(args.steps), "--warmup", "3", "--no-b1", "--no-cpu-baseline"] + args.extra.split()
     summary = {"command": " ".join(["python", "bench.py"] + bench[2:]), "kernel": "ga_fwd2_kernel / ga_fwd_kernel", "per_launch_avg": {}, "calibration": {}}
     sys.path.insert(0, ROOT)
     import bench as B
-    summary["kernel_source_id"] = B.kernel_source_id()      # bench.py reports `traffic` only for a matching fingerprint
+    summary["kernel_source_id"] = B.kernel_source_id(args.workload)      # bench.py reports `traffic` only for a matching fingerprint
 
     known_rd, known_wr = 50000 * 512 * 4, (16 << 20) * 4
     c_f = run_pass("cal_fetch", PASSES["fetch"], calib, args.out)
@@ -78,17 +91,44 @@ def main():
         "FETCH_SIZE_of_pure_write_kernel_KB": rd_on_wr_kb,
         "pattern": "LDS-DMA 16 B/lane, 16 rows x 64-B row segment per wave-instruction (ga_fwd_kernel bag tile); fp32 stores 256 B/wave-instruction",
     }
+    # the same command once unprofiled: the launch duration the cycle counters are divided by (profiled runs clock lower)
+    r = subprocess.run(bench, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    steps_total = args.steps + 3
     for tag, counters in PASSES.items():
         res = run_pass(tag, counters, bench, args.out)
         for c in counters:
+            if args.whole_step:
+                t, n = total(res, c)
+                summary["per_launch_avg"][c] = t / steps_total
+                summary["launches_seen"] = n
+                continue
             v, n = pick(res, "ga_fwd2_kernel", c)
             if v is None:
                 v, n = pick(res, "ga_fwd_kernel", c)
             summary["per_launch_avg"][c] = v
             summary["launches_seen"] = n
+    if args.whole_step:
+        summary["kernel"] = "ALL kernels of a step (counter totals / (steps + warm-up))"
+        us = line["ms_per_step"] * 1e3
+    else:
+        us = line["roofline"]["us_per_launch"]
     f_kb, w_kb = summary["per_launch_avg"]["FETCH_SIZE"], summary["per_launch_avg"]["WRITE_SIZE"]
     summary["traffic_bytes_per_launch"] = int(f_kb * 1024 * k_rd + w_kb * 1024 * k_wr)
     summary["traffic_note"] = "FETCH_SIZE x fetch_correction + WRITE_SIZE x write_correction, KB -> bytes, average over the launches of the bench command"
+    # effective shader clock under this kernel (the chip clocks to its 1 400 W budget): GRBM_GUI_ACTIVE counts per XCD, 8 XCDs;
+    # matrix-pipe busy fraction against the NOMINAL 2.4 GHz and against the cycles that actually elapsed
+    g = summary["per_launch_avg"].get("GRBM_GUI_ACTIVE")
+    mf = summary["per_launch_avg"].get("SQ_VALU_MFMA_BUSY_CYCLES")
+    summary["us_per_launch_unprofiled"] = us
+    if g and us:
+        clk = g / 8.0 / us / 1e3          # GHz
+        summary["effective_clock_ghz"] = round(clk, 3)
+        if mf:
+            summary["mfma_busy_frac_of_nominal_2p4ghz"] = round(mf / 1024.0 / (us * 2400.0), 4)
+            summary["mfma_busy_frac_of_elapsed_cycles"] = round(mf / 1024.0 / (us * clk * 1e3), 4)
+    summary["clock_note"] = ("effective clock = GRBM_GUI_ACTIVE / 8 XCDs / unprofiled launch duration (the profiled pass itself runs 5-7 % slower, "
+                             "so this is a lower bound by that margin); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs")
     summary["precision"], summary["batch"] = args.precision, args.batch
     summary["workload"] = args.workload
     with open(os.path.join(args.out, "pmc_%s_%s_b%d.json" % (args.workload, args.precision, args.batch)), "w") as fh:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the round's bench lines + rocprofv3 evidence on the GPU box (run through gpurun):  tools/profile_round.sh r02
+# Collect the round's bench lines + rocprofv3 evidence on the GPU box (run through gpurun):  tools/profile_round.sh r03
 # Writes gpurun_out/<tag>/: bench JSON lines, kernel-trace stats CSVs, PMC summaries (tools/pmc_ga.py).  Copy what is to be
 # judged into profiles/.
 TAG=${1:-rXX}
@@ -8,6 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 export TMPDIR=/tmp
+[ -x build/exp/hbm_calib ] || { mkdir -p build/exp; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o build/exp/hbm_calib tools/hbm_calib.hip; }
 run_stats() {   # name, bench args...
   name=$1; shift
   d=/tmp/prof_$name; rm -rf $d
@@ -15,20 +16,32 @@ run_stats() {   # name, bench args...
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
 }
-python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.log
-python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cfg3.log
+# PMC first (their summaries stamp the kernel source; the bench lines below then carry `traffic`)
+python tools/pmc_ga.py --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_b64.log 2>&1
+python tools/pmc_ga.py --batch 1 --steps 100 --out $OUT/pmc > $OUT/pmc_ga_eval_b1.log 2>&1
+python tools/pmc_ga.py --precision fp32 --batch 16 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_fp32.log 2>&1
+python tools/pmc_ga.py --workload ga_cfg3 --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_cfg3.log 2>&1
+python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
+python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
+cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
+for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
+python bench.py > $OUT/bench_default.json 2>> $OUT/bench_default.log
+python bench.py --batch 16 --no-cpu-baseline > $OUT/bench_b16.json 2>> $OUT/bench_default.log
 python bench.py --batch 1 --no-cpu-baseline > $OUT/bench_b1.json 2>> $OUT/bench_default.log
-run_stats bench_f16x3_b16 --steps 50 --warmup 5 --no-b1 --no-cpu-baseline
-run_stats bench_ga_cfg3 --workload ga_cfg3 --steps 50 --warmup 5 --no-b1 --no-cpu-baseline
-run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
-run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
-run_stats bench_train_n50k --workload train --train-n 50000 --steps 200 --warmup 20 --no-cpu-baseline
+python bench.py --precision fp32 --batch 16 --no-cpu-baseline --no-b1 > $OUT/bench_fp32.json 2>> $OUT/bench_default.log
+python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cfg3.log
+for w in ga_uni ga_gigapath ga_clip_l; do python bench.py --workload $w --steps 50 > $OUT/bench_$w.json 2> $OUT/bench_$w.log; done
 python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
 python bench.py --workload train > $OUT/bench_train_n10k.json 2> $OUT/bench_train.log
 python bench.py --workload train --train-n 50000 > $OUT/bench_train_n50k.json 2>> $OUT/bench_train.log
-python tools/pmc_ga.py --batch 16 --out $OUT/pmc > $OUT/pmc_ga_eval.log 2>&1
-python tools/pmc_ga.py --workload ga_cfg3 --batch 16 --out $OUT/pmc > $OUT/pmc_ga_cfg3.log 2>&1
-cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
-tail -c 1500 $OUT/bench_default.json; echo; tail -c 1200 $OUT/bench_ga_cfg3.json; echo
-head -5 $OUT/bench_f16x3_b16_kernel_stats.csv
+run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
+run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
+run_stats bench_ga_uni --workload ga_uni --steps 50 --warmup 5 --no-cpu-baseline
+run_stats bench_ga_gigapath --workload ga_gigapath --steps 50 --warmup 5 --no-cpu-baseline
+run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
+run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
+run_stats bench_train_n50k --workload train --train-n 50000 --steps 200 --warmup 20 --no-cpu-baseline
+tail -c 1500 $OUT/bench_driver_args.json; echo
+for f in $OUT/bench_*_kernel_stats.csv; do echo == $f; head -12 $f | cut -c1-150; done
 ls $OUT
