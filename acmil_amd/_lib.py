@@ -28,6 +28,7 @@ SIGNATURES = {
     "acmil_ga_packed_bytes": (_sz, [_i] * 6),
     "acmil_ga_pack_weights": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp)] + [_vp] * 2 + [_i] * 6 + [_vp, _vp]),
     "acmil_ga_workspace_bytes": (_sz, [_i] * 6),
+    "acmil_ga_workspace_init": (_i, [_vp, _vp]),
     "acmil_ga_forward": (_i, [_vp, _i, _i, _vp] + [_i] * 6 + [_vp] * 6 + [_i, _vp, _vp]),
     "acmil_ga_batch_workspace_bytes": (_sz, [_i, C.POINTER(_i)] + [_i] * 5),
     "acmil_ga_forward_batch": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), _i, _vp] + [_i] * 6 + [C.POINTER(_vp)] + [_vp] * 4 +

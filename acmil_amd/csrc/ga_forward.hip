@@ -165,6 +165,14 @@ static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hip
     return ACMIL_ERR_UNSUPPORTED;
 }
 
+// One-off initialisation of a freshly allocated GA workspace: zeroes the 256-byte control block (tile counter, arrival counters,
+// range words).  Every launch leaves the counters at zero again, so this is needed ONCE per allocation, not per call; a workspace
+// that was never initialised starts with garbage counters and the persistent kernels would skip or repeat tiles.
+extern "C" int acmil_ga_workspace_init(void* workspace, void* stream) {
+    if (!workspace) return ACMIL_ERR_NULL;
+    return hipMemsetAsync(workspace, 0, GA_CTRL_BYTES, (hipStream_t)stream) == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
 extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode) {
     (void)D; (void)C; (void)mode;
     if (N <= 0 || Di <= 0 || K <= 0) return 0;

@@ -29,12 +29,9 @@
 #pragma once
 #include "ga_forward_kernel.h"
 
-// Timing-only build knobs for tools/build_variants.sh (never set in the product build; results are WRONG with GA2_ABL):
-//   GA2_ABL bits: 1 no x DMA, 2 no W DMA, 4 no GEMM1 MFMAs, 8 no GEMM2 MFMAs.
-//   GA2_PROF: s_memtime accounting; per-wave cycle totals REPLACE the first 8 scores of each 32-patch group of A_out[0].
-#ifndef GA2_ABL
-#define GA2_ABL 0
-#endif
+// Measurement hooks.  The product build compiles them to nothing: Ga2Probe below is empty and the MFMA / DMA macros are the plain
+// instructions.  tools/build_variants.sh builds timing variants with -DGA2_TOOLS, which swaps in tools/ga2_probe.h (s_memtime cycle
+// account per phase, ablation of the MFMAs or the DMA streams -- results are WRONG there by construction, never shipped).
 // wave priority inside the GEMM step loops / outside (gate, softmax, pooling): the wave that feeds the matrix pipe wins the
 // issue arbitration against a co-resident wave that is in a VALU / LDS phase
 #ifndef GA2_PRIO_GEMM
@@ -43,9 +40,24 @@
 #ifndef GA2_PRIO_REST
 #define GA2_PRIO_REST 0
 #endif
-#define GA2_MFMA1(A, B, C) ((GA2_ABL & 4) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
-#define GA2_MFMA2(A, B, C) ((GA2_ABL & 8) ? ga2_keep(A, B, C) : __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0))
-__device__ __forceinline__ f32x16 ga2_keep(f16x8 a, f16x8 b, f32x16 c) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+#ifdef GA2_TOOLS
+#include "ga2_probe.h"
+#else
+#define GA2_MFMA1(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#define GA2_MFMA2(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+struct Ga2Probe {
+    static constexpr bool DMA_X = true, DMA_W = true;
+    __device__ __forceinline__ void sync_begin() {}
+    __device__ __forceinline__ void sync_loaded() {}
+    __device__ __forceinline__ void sync_released() {}
+    __device__ __forceinline__ void tile_begin() {}
+    __device__ __forceinline__ void gemm1_end() {}
+    __device__ __forceinline__ void gemm2_end() {}
+    __device__ __forceinline__ void softmax_end() {}
+    __device__ __forceinline__ void pool_end() {}
+    __device__ __forceinline__ void tile_end(float*, int, int, int, int) {}
+};
+#endif
 
 template <int ND, int KP, int XDT, int WV = 4>
 struct Ga2Geom {
@@ -65,7 +77,7 @@ struct Ga2Geom {
     static constexpr int NB = 3;                                    // ring slots
     static constexpr int PD = 2;                                    // prefetch distance in steps
     static constexpr int ROWS = 32 * WAVES;                         // patches per tile
-    static_assert(ND % 4 == 0, "Di must be a multiple of 128");
+    static_assert(ND % 2 == 0, "whole 64-column pairs");        // (the fused GA kernel further needs ND % 4 == 0: asserted there)
     static constexpr int Di = 32 * ND;
     static constexpr int RING = NB * SLOT;
     static constexpr int PTILE = 4608;                              // wave-private transposition image: 2 x 4 planes x 576 B (f16) or [32][36] fp32
@@ -109,6 +121,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 template <int ND, int KP, int XDT, bool POOL, bool SAVEH, int WV = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
+    static_assert(ND % 4 == 0, "D_inner must be a multiple of 128");
     static_assert(!PAIR || ND == 8, "the wave-pair split is built for D_inner = 256 (two h tiles per GEMM2 step)");
     static_assert(!PAIR || WV == 4, "exchange buffers: 4 KiB of the free slot's per-wave region (5 - 6 KiB at 4 waves)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,10 +188,10 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         constexpr int m = decltype(mc)::value;
         const unsigned m0v = m0w + slot * G::SLOT;
         if constexpr (m < G::RW) {
-            if constexpr (!(GA2_ABL & 2)) ga2_dma<-(G::RW - m) * 1024>(woff, wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v);
+            if constexpr (Ga2Probe::DMA_W) ga2_dma<-(G::RW - m) * 1024>(woff, wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v);
         } else if constexpr (m < G::NVX) {
             constexpr int q = m - G::RW;
-            if constexpr (!(GA2_ABL & 1)) { if (with_x) ga2_dma<q * 1024>(xo[q], xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
+            if constexpr (Ga2Probe::DMA_X) { if (with_x) ga2_dma<q * 1024>(xo[q], xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
         }
     };
     // piece d (a loop index the unroller resolves) -> dma_piece<d>
@@ -245,36 +258,23 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
     }
     int rslot = 0;   // ring slot of the step being consumed
 
-#ifdef GA2_PROF
-    unsigned long long pf_vm = 0, pf_bar = 0;
-#endif
+    Ga2Probe probe;      // empty unless built with -DGA2_TOOLS (tools/ga2_probe.h)
     // Before reading slot s: this wave's pieces of step s have landed (at most the NEXT step's pieces stay in flight: they
     // were issued one step ago, step s's two steps ago), every read of the slot about to be recycled has returned, barrier.
     auto step_sync = [&](bool next_has_x) {
-#ifdef GA2_PROF
-        const unsigned long long ta = __builtin_amdgcn_s_memtime();
-#endif
+        probe.sync_begin();
         if (next_has_x) ga_wait_vm<G::NVX>(); else ga_wait_vm<G::NVW>();
-#ifdef GA2_PROF
-        const unsigned long long tb = __builtin_amdgcn_s_memtime();
-#endif
+        probe.sync_loaded();
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
-#ifdef GA2_PROF
-        const unsigned long long tc = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        pf_vm += tb - ta; pf_bar += tc - tb;
-#endif
+        probe.sync_released();
     };
     const float* tabf = (const float*)(smem + G::TAB_OFF);
     const float* bwp = tabf + (2 + KP) * GA_DA;      // bw[8] (LDS copy: no global load inside the tile loop)
 
     // =============================================================================================== tile loop
     for (;;) {
-#ifdef GA2_PROF
-        const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long pf_vm0 = pf_vm, pf_bar0 = pf_bar;
-#endif
+        probe.tile_begin();
         // the tile after this one (its first steps are prefetched by this tile's last steps); none -> refetch this tile's rows
         const bool has_next = ntile < ntiles;
         const TileInfo TN = tile_info(has_next ? ntile : tile);
@@ -292,9 +292,6 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
         // range guard of the split-f16 arithmetic: largest |bag value| this lane converted (as a bit pattern, so that inf and
         // NaN rank above every finite value), largest feature it produced
         unsigned hmax = 0u;
-#ifdef GA2_PROF
-        unsigned long long pf_t1 = 0, pf_vm1 = 0, pf_bar1 = 0;
-#endif
         // wave-pair parity: own feature tiles are the actual tiles 2t + hp (PAIR), register order r <-> actual tile r ^ hp
         const int hp = PAIR ? (wave & 1) : 0;
         f16x8 hh[ND][2], hl[ND][2];
@@ -415,9 +412,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) acc1[m] = GA2_MFMA1(WL[m >> 1], xhp[m & 1], acc1[m]);
             __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
-#ifdef GA2_PROF
-            pf_t1 = __builtin_amdgcn_s_memtime(); pf_vm1 = pf_vm; pf_bar1 = pf_bar;
-#endif
+            probe.gemm1_end();
             // ---- relu, range guard, f16 split; exchange of the partner-group halves
 #pragma unroll
             for (int d = 0; d < ND; ++d)
@@ -614,9 +609,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 __builtin_amdgcn_s_setprio(GA2_PRIO_REST);
             }
 
-#ifdef GA2_PROF
-            pf_t1 = __builtin_amdgcn_s_memtime(); pf_vm1 = pf_vm; pf_bar1 = pf_bar;
-#endif
+            probe.gemm1_end();
             // ======================================================= relu + f16 split of h
             // acc1[d][r] holds h[patch = lane&31][feature = 32d + mfma32_row(r, hi)].  The empty asm statements keep LLVM from
             // sinking the relu / split into the GEMM2 steps (old and new values live together -> hundreds of spills).
@@ -778,10 +771,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 }
             }
         }
-#ifdef GA2_PROF
-        const unsigned long long pf_t2 = __builtin_amdgcn_s_memtime();
-        unsigned long long pf_tb = pf_t2;
-#endif
+        probe.gemm2_end();
 
         // ======================================================= scores, wave-level softmax statistics
         // Everything cross-lane here is DPP / permlane (VALU): no ds_bpermute round trips, no LDS traffic beside the GEMM
@@ -831,9 +821,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
             }
             pe[sl] = p;
         }
-#ifdef GA2_PROF
-        const unsigned long long pf_t2a = __builtin_amdgcn_s_memtime();
-#endif
+        probe.softmax_end();
 
         // ======================================================= attention-weighted sum  sum_n p[k][n] h[n][:]
         // Scratch: the ring slot consumed last (the two others hold the next tile's first steps, in flight) or the separate
@@ -911,9 +899,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 __builtin_amdgcn_wave_barrier();
             }
             __builtin_amdgcn_sched_barrier(0);
-#ifdef GA2_PROF
-            const unsigned long long pf_t2b = __builtin_amdgcn_s_memtime();
-#endif
+            probe.pool_end();
             // =================================================== combine the 4 waves, publish the tile's partial
             float* comb = (float*)scr;   // [KP][Di], overlays this wave's (now dead) transposition image
             float* ml = (float*)(smem + G::ML_OFF);
@@ -956,9 +942,6 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                     out[k * PS + 0] = M; out[k * PS + 1] = lt;
                 }
             }
-#ifdef GA2_PROF
-            pf_tb = pf_t2b;
-#endif
         } else {
             // score pass of the training step (SAVEH): h goes to HBM as fp32 rows.  Transposed through a wave-private padded tile,
             // 32 features at a time, so that a half-wave stores 128 contiguous bytes of a row.
@@ -986,19 +969,7 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 }
             }
         }
-#ifdef GA2_PROF
-        {
-            const unsigned long long pf_t3 = __builtin_amdgcn_s_memtime();
-            const float pv[8] = {(float)(pf_t3 - pf_t0), (float)(pf_vm1 - pf_vm0), (float)(pf_bar1 - pf_bar0), (float)(pf_t2a - pf_t2),
-                                 (float)(pf_tb - pf_t2a), (float)(pf_t1 - pf_t0), (float)(pf_t2 - pf_t1), (float)(pf_t3 - pf_tb)};
-            if (A_out && lane < 8 && m0 + 8 <= N) A_out[m0 + lane] = pv[lane];
-            // start time (two 24-bit halves), CU identity (HW_ID, XCC_ID), second-workgroup flag, workgroup id
-            const float pw[8] = {(float)(unsigned)(pf_t0 & 0xffffff), (float)(unsigned)((pf_t0 >> 24) & 0xffffff),
-                                 (float)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)), (float)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)),
-                                 (float)__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)), (float)blockIdx.x, (float)tile, 0.0f};
-            if (A_out && lane >= 8 && lane < 16 && m0 + 16 <= N) A_out[m0 + lane] = pw[lane - 8];
-        }
-#endif
+        probe.tile_end(A_out, lane, m0, N, tile);
         if (!has_next) break;
         if constexpr (!POOL) {
             if (dynamic) {

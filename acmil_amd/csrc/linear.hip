@@ -1,21 +1,30 @@
 // linear.hip -- host side of the packed-weight Linear kernel (linear_kernel.h): weight packing and the C entry points.
 #include "linear_kernel.h"
 
-// Packed stream of W [n_out, K] (row-major, leading dimension ldw): n_out / 256 chunks of ND = 8 (256 output columns), then
-// one ND = 4 chunk when n_out % 256 == 128.  Chunk = K/16 steps; step = ND "hi" fragment rows then ND "lo" rows; fragment
-// row (step s, tile d): lane (i = lane & 31, hi = lane >> 5) holds the 8 f16 halves of W[col0 + 32 d + i][16 s + 8 hi .. + 7].
+// Packed stream of W [n_out, K] (row-major, leading dimension ldw) as output-column chunks (lin_plan): n_out / 256 chunks of ND = 8
+// (256 columns) then one ND = 4 chunk when n_out % 256 == 128 -- except n_out = 384, which runs as 2 chunks of ND = 6
+// (192 columns: no half-rate remainder launch; the TransMIL width and CLIP-L's D_inner: 272 vs 323 us at M = 100 000, K = 768).  Chunk = K/16 steps; step = ND "hi"
+// fragment rows then ND "lo" rows; fragment row (step s, tile d): lane (i = lane & 31, hi = lane >> 5) holds the 8 f16 halves of
+// W[col0 + 32 d + i][16 s + 8 hi .. + 7].
 struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; };
+struct LinPlan { int nd, nmain, nd_rem; };      // nmain chunks of 32 * nd columns, then one chunk of 32 * nd_rem columns (0 = none)
+__host__ __device__ static inline LinPlan lin_plan(int n_out) {
+    if (n_out == 384) return LinPlan{6, 2, 0};
+    return LinPlan{8, n_out / 256, (n_out % 256) ? 4 : 0};
+}
 
 __global__ __launch_bounds__(256) void lin_pack_kernel(LinPackArgs a) {
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int S1 = a.K / 16, nfull = a.n_out / 256;
-    const size_t rows_full = (size_t)nfull * S1 * 16;
-    const size_t rows_all = rows_full + ((a.n_out % 256) ? (size_t)S1 * 8 : 0);
+    const int S1 = a.K / 16;
+    const LinPlan P = lin_plan(a.n_out);
+    const size_t per = (size_t)S1 * 2 * P.nd;                 // fragment rows of one main chunk
+    const size_t rows_full = (size_t)P.nmain * per;
+    const size_t rows_all = rows_full + (size_t)S1 * 2 * P.nd_rem;
     if (row >= rows_all) return;
     int ND, col0; size_t r;
-    if (row < rows_full) { ND = 8; const size_t c = row / ((size_t)S1 * 16); col0 = (int)c * 256; r = row - c * (size_t)S1 * 16; }
-    else { ND = 4; col0 = nfull * 256; r = row - rows_full; }
+    if (row < rows_full) { ND = P.nd; const size_t c = row / per; col0 = (int)c * 32 * P.nd; r = row - c * per; }
+    else { ND = P.nd_rem; col0 = P.nmain * 32 * P.nd; r = row - rows_full; }
     const int d = r % ND; r /= ND;
     const int part = r & 1; const int s = (int)(r >> 1);
     const float* src = a.W + (size_t)(col0 + 32 * d + i) * a.ldw + 16 * s + 8 * hi;
@@ -32,7 +41,8 @@ static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K > 0 && n_out %
 
 extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
     if (!lin_dims_ok(n_out, K)) return 0;
-    return (size_t)(K / 16) * GA_FRAG_ROW * (16 * (size_t)(n_out / 256) + ((n_out % 256) ? 8 : 0));
+    const LinPlan P = lin_plan(n_out);
+    return (size_t)(K / 16) * GA_FRAG_ROW * ((size_t)2 * P.nd * P.nmain + 2 * P.nd_rem);
 }
 
 extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream) {
@@ -77,6 +87,7 @@ extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long
     if (!x || !packed || !y || !workspace) return ACMIL_ERR_NULL;
     const int xe = (x_dtype == ACMIL_DTYPE_F32) ? 4 : 2;
     if (((size_t)x & 15) != 0 || ((size_t)ldx * xe) % 16 != 0) return ACMIL_ERR_SHAPE;     // 16-byte LDS-DMA pieces
+    if (((size_t)y & 15) != 0 || ldy % 4 != 0) return ACMIL_ERR_SHAPE;                     // 16-byte row stores
     hipStream_t st = (hipStream_t)stream;
     unsigned* ctr = (unsigned*)workspace;
     if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
@@ -84,16 +95,17 @@ extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
     a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
-    const int nfull = n_out / 256;
+    const LinPlan P = lin_plan(n_out);
     int rc = ACMIL_OK;
-    if (nfull > 0) {
-        a.packed = (const char*)packed; a.nchunks = nfull; a.col0 = 0; a.tile_counter = ctr;
-        rc = lin_launch_dt<8>(a, x_dtype, st);
+    if (P.nmain > 0) {
+        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr;
+        rc = P.nd == 6 ? lin_launch_dt<6>(a, x_dtype, st) : lin_launch_dt<8>(a, x_dtype, st);
         if (rc != ACMIL_OK) return rc;
     }
-    if (n_out % 256) {
-        a.packed = (const char*)packed + (size_t)nfull * (K / 16) * 16 * GA_FRAG_ROW; a.nchunks = 1; a.col0 = nfull * 256;
-        a.bias = bias ? bias + nfull * 256 : nullptr; a.tile_counter = ctr + 1;
+    if (P.nd_rem) {
+        const int c0 = P.nmain * 32 * P.nd;
+        a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
+        a.bias = bias ? bias + c0 : nullptr; a.tile_counter = ctr + 1;
         rc = lin_launch_dt<4>(a, x_dtype, st);
     }
     return rc;

@@ -309,32 +309,37 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                 const bool bad = (m0 + i31 < M) && hm >= (0x477fe000u << 1);
                 if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, 2u);
             }
+            // Per 32-column tile: accumulators -> wave-private tile [32 rows (patches)][36] (lane = row, register = column), read back
+            // as float4 = 4 consecutive output columns of one row: 8 lanes store 128 contiguous bytes of an output row with ONE 16-byte
+            // store each (4 stores per lane and tile; the first version stored 16 scalars per lane: the epilogue was store-issue-bound)
+            const int rsub = lane >> 3, cq = lane & 7;               // row within a group of 8, column quad
 #pragma unroll
             for (int c = 0; c < ND; ++c) {
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pool[mfma32_row(r, hi) * 36 + i31] = acc[c][r];
+                for (int r = 0; r < 16; ++r) pool[i31 * 36 + mfma32_row(r, hi)] = acc[c][r];
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);     // column T.col + 32c + i31, rows 16hi ..
-                const int col = T.col + 32 * c + i31;
-                const float b = a.bias ? a.bias[col] : 0.0f;
+                const int col = T.col + 32 * c + 4 * cq;
+                f32x4 b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (a.bias) b4 = f32x4{a.bias[col], a.bias[col + 1], a.bias[col + 2], a.bias[col + 3]};      // (no alignment demand on the bias)
                 float* yc = a.y + (size_t)(a.col0 + col);
+                f32x4 old[4];
+                if (a.beta != 0.0f) {      // residual form: all old values first (unconditional loads from clamped rows), then the stores
 #pragma unroll
-                for (int mq = 0; mq < 4; ++mq) {
-                    const f32x4 hv = prow[mq];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = m0 + 16 * hi + 4 * mq + e;
-                        if (row < M) {
-                            float v = hv[e] + b;
-                            if (a.act == 1) v = fmaxf(v, 0.0f);
-                            float* dst = yc + (size_t)row * a.ldy;
-                            if (a.beta != 0.0f) v = fmaf(a.beta, *dst, v);
-                            *dst = v;
-                        }
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = m0 + 8 * it + rsub;
+                        old[it] = *(const f32x4*)(yc + (size_t)(row < M ? row : M - 1) * a.ldy);
                     }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = m0 + 8 * it + rsub;
+                    f32x4 v = *(const f32x4*)(pool + (8 * it + rsub) * 36 + 4 * cq) + b4;
+                    if (a.act == 1) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
+                    if (a.beta != 0.0f) v = v + old[it] * a.beta;
+                    if (row < M) *(f32x4*)(yc + (size_t)row * a.ldy) = v;
                 }
             }
         }

@@ -154,15 +154,34 @@ __global__ __launch_bounds__(1024) void tm_softmax_long_kernel(float* __restrict
 
 // pinv init, pass 1: global max over heads of the row sums and of the column sums of |x| (x >= 0 after softmax).
 // scal[0] = max_i sum_j |x_ij| ("col" in the reference), scal[1] = max_j sum_i |x_ij| ("row"); uint-ordered atomics.
-__global__ __launch_bounds__(256) void tm_pinv_maxsum_kernel(const float* __restrict__ x, int m, unsigned* __restrict__ scal) {
-    const int h = blockIdx.y, i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (i >= m) return;
+// One workgroup per head: column sums with one thread per column (coalesced row reads), row sums with one wave per row; the
+// first version walked columns with a stride of m floats per lane and took 37 us for 1.2 MB.
+__global__ __launch_bounds__(1024) void tm_pinv_maxsum_kernel(const float* __restrict__ x, int m, unsigned* __restrict__ scal) {
+    __shared__ float red[2][16];
+    const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* X = x + (size_t)h * m * m;
-    float rs = 0.0f, cs = 0.0f;
-    for (int j = lane; j < m; j += 64) { rs += fabsf(X[(size_t)i * m + j]); cs += fabsf(X[(size_t)j * m + i]); }
+    float cs = 0.0f;                                   // column tid
+    if (tid < m) {
+#pragma unroll 8
+        for (int i = 0; i < m; ++i) cs += fabsf(X[(size_t)i * m + tid]);
+    }
+    float rmax = 0.0f;                                 // rows wave, wave + 16, ...
+    for (int i = wave; i < m; i += 16) {
+        float rs = 0.0f;
+        for (int j = lane; j < m; j += 64) rs += fabsf(X[(size_t)i * m + j]);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { rs += __shfl_xor(rs, o); cs += __shfl_xor(cs, o); }
-    if (lane == 0) { atomicMax(scal + 0, __float_as_uint(rs)); atomicMax(scal + 1, __float_as_uint(cs)); }
+        for (int o = 32; o >= 1; o >>= 1) rs += __shfl_xor(rs, o);
+        rmax = fmaxf(rmax, rs);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o));
+    if (lane == 0) { red[0][wave] = rmax; red[1][wave] = cs; }
+    __syncthreads();
+    if (tid == 0) {
+        float r = 0.0f, c = 0.0f;
+        for (int w = 0; w < 16; ++w) { r = fmaxf(r, red[0][w]); c = fmaxf(c, red[1][w]); }
+        atomicMax(scal + 0, __float_as_uint(r)); atomicMax(scal + 1, __float_as_uint(c));
+    }
 }
 
 // pass 2: z = x^T / (scal0 * scal1)
@@ -320,7 +339,7 @@ static TmGeom tm_geom(int N, int D, int Di, int C) {
 
 static size_t tm_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, GEMM, total; };
+struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, PKW, LINWS, GEMM, total; };
 
 // transmil_pinv.hip: the whole Moore-Penrose iteration of one layer as ONE launch (one workgroup per head); opt-in, see tm_layer
 bool tm_pinv_fused_supported(int m);
@@ -338,6 +357,12 @@ static TmWs tm_ws(const TmGeom& g) {
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
     w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
+    // packed-weight Linear kernel (linear.hip): one fragment stream at a time (the largest of fc1 / to_qkv / to_out) + its counters
+    {
+        size_t pk = (size_t)g.Di * g.D * 4, q = (size_t)3 * g.Di * g.Di * 4;
+        w.PKW = off; off += tm_al(pk > q ? pk : q);
+        w.LINWS = off; off += 256;
+    }
     // split-K scratch: the largest need over EVERY product of the forward (a small bag with a wide feature vector splits
     // products that never split at slide scale, e.g. fc1 at N = 400, D = 1536)
     const int H = TM_HEADS, m = g.m, d = g.d, np_ = g.npad, Di = g.Di;
@@ -367,6 +392,29 @@ static bool tm_pinv_x3() { static const bool v = getenv("ACMIL_TM_PINV_X3") != n
 #define TM_PINV_GEMM(...) do { int rc_ = tm_pinv_x3() ? acmil_gemm_f16x3(__VA_ARGS__) : acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 #define TM_LINEAR(...) do { int rc_ = tm_linear_exact() ? acmil_gemm_f32(__VA_ARGS__) : acmil_gemm_f16x3(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
+extern "C" size_t acmil_linear_packed_bytes(int n_out, int K);
+extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream);
+extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
+                                  const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream);
+
+// y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
+// Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
+// launch, ~4 us) where its shape rules hold -- 216 / 216 / 197 TF on the three cfg4 shapes against 199 / 201 / 186 for the generic
+// split GEMM; otherwise, and for ACMIL_TM_FP32_GEMM=1 (exact fp32 MFMA), the generic GEMMs.  ACMIL_TM_GENERIC_GEMM=1: A/B knob.
+static int tm_linear(const float* x, int M, int K, long long ldx, const float* W, int n_out, const float* bias, int act, float beta,
+                     float* y, long long ldy, char* pkw, void* linws, void* gws, hipStream_t st) {
+    static const bool generic = getenv("ACMIL_TM_GENERIC_GEMM") != nullptr;
+    const bool lin_ok = !tm_linear_exact() && !generic && acmil_linear_packed_bytes(n_out, K) != 0 && ((size_t)x & 15) == 0 &&
+                        ((size_t)ldx * 4) % 16 == 0 && ldy >= n_out && ((size_t)y & 15) == 0 && ldy % 4 == 0;
+    if (lin_ok) {
+        int rc = acmil_linear_pack(W, K, n_out, K, pkw, st);
+        if (rc != ACMIL_OK) return rc;
+        return acmil_linear_f16x3(x, ACMIL_DTYPE_F32, M, K, ldx, pkw, n_out, bias, act, beta, y, ldy, linws, st);
+    }
+    TM_LINEAR(0, 1, M, n_out, K, 1.0f, x, (int)ldx, 0, W, ACMIL_DTYPE_F32, K, 0, beta, y, (int)ldy, 0, bias, act, nullptr, 1, gws, st);
+    return ACMIL_OK;
+}
+
 static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) {
     const unsigned blocks = (unsigned)((rows + 3) / 4);
     if (cols <= 64) hipLaunchKernelGGL(tm_softmax_short_kernel<1>, dim3(blocks), dim3(256), 0, st, x, rows, cols);
@@ -393,7 +441,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_layernorm_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, LN, g.n, Di, p.norm_w, p.norm_b, g.pad);
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
-    TM_LINEAR(0, 1, npad, 3 * Di, Di, 1.0f, LN, Di, 0, p.qkv_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, QKV, 3 * Di, 0, nullptr, 0, nullptr, 1, gws, st);
+    { const int rq = tm_linear(LN, npad, Di, Di, p.qkv_w, 3 * Di, nullptr, 0, 0.0f, QKV, 3 * Di, ws + W.PKW, ws + W.LINWS, gws, st); if (rq != ACMIL_OK) return rq; }
     {
         int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
         const int threads = ((Di / 4) * phases + 63) / 64 * 64;
@@ -414,7 +462,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
     rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
     if (hipMemsetAsync(scal, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3((m + 3) / 4, H), dim3(256), 0, st, S2, m, scal);
+    hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
     TM_CHECK_LAUNCH();
     float* zc = Z; float* zn = T2;     // ping-pong z
     // ACMIL_TM_PINV_FUSED=1: ONE launch for the 24 products (transmil_pinv.hip: one 8-wave workgroup per head, operands staged
@@ -459,8 +507,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
     TM_CHECK_LAUNCH();
     // X[pad:] += OUT[pad:] Wout^T + b   (only the last n rows are kept by the reference)
-    TM_LINEAR(0, 1, g.n, Di, Di, 1.0f, OUT + (size_t)g.pad * Di, Di, 0, p.out_w, ACMIL_DTYPE_F32, Di, 0, 1.0f, X + (size_t)g.pad * Di, Di, 0, p.out_b, 0, nullptr, 1, gws, st);
-    return ACMIL_OK;
+    return tm_linear(OUT + (size_t)g.pad * Di, g.n, Di, Di, p.out_w, Di, p.out_b, 0, 1.0f, X + (size_t)g.pad * Di, Di, ws + W.PKW, ws + W.LINWS, gws, st);
 }
 
 extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
@@ -483,7 +530,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     void* gws = ws + W.GEMM;
     const size_t tokbytes = (size_t)g.n * Di;
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
-    TM_LINEAR(0, 1, N, Di, D, 1.0f, x, D, 0, fc1_w, ACMIL_DTYPE_F32, D, 0, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, 0, fc1_b, 1, nullptr, 1, gws, st);
+    { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, ws + W.PKW, ws + W.LINWS, gws, st); if (r1 != ACMIL_OK) return r1; }
     hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
     TM_CHECK_LAUNCH();
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};

@@ -90,7 +90,8 @@ def _ws_bytes(nbytes: int, device) -> torch.Tensor:
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
     ws = _WS_CACHE.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().acmil_ga_workspace_init(ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "acmil_ga_workspace_init")
         _WS_CACHE[key] = ws
     return ws
 

@@ -94,6 +94,11 @@ int acmil_ga_pack_weights(const float* W1, const float* Wv, const float* bv, con
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, int mode);
 
+/* Zero the control block of a freshly allocated GA workspace (enqueued on `stream`): call ONCE per allocation, before the first
+ * acmil_ga_forward / _forward_batch / _guarded / _pool / _train_step on it.  (Equivalent to hipMemsetAsync(workspace, 0, 256, stream);
+ * provided so that the one-off initialisation the contract above asks for is an explicit call of this library.) */
+int acmil_ga_workspace_init(void* workspace, void* stream);
+
 int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K, int C,
                      int mode, float* A_out, float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
                      float* h_save, int has_bag_head, void* workspace, void* stream);

@@ -5,7 +5,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 16, 128)])
+@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 16, 128), (2000, 384, 384)])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.float16, torch.bfloat16])
 def test_linear_matches_fp64(m, k, n_out, xdt):
     from acmil_amd import ops
