@@ -943,9 +943,11 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
                 }
             }
         } else {
-            // score pass of the training step (SAVEH): h goes to HBM as fp32 rows.  Transposed through a wave-private padded tile,
-            // 32 features at a time, so that a half-wave stores 128 contiguous bytes of a row.
+            // score pass of the training step (SAVEH): h goes to HBM as fp32 rows.  Through a wave-private padded tile [32 patches][36], 32
+            // features at a time: written lane = patch / register = feature, read back as float4 = 4 consecutive features of one patch,
+            // so 8 lanes store 128 contiguous bytes of an h row with one 16-byte store each (4 per lane and tile, not 16 scalars).
             float* pool = (float*)scr;
+            const int rsub = lane >> 3, cq = lane & 7;
 #pragma unroll
             for (int c = 0; c < ND; ++c) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -953,18 +955,16 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float hv = (float)hh[c][r >> 3][r & 7] + (float)hl[c][r >> 3][r & 7];
-                    pool[mfma32_row(r, hi) * 36 + i31] = hv;
+                    pool[i31 * 36 + mfma32_row(r, hi)] = hv;
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                const f32x4* prow = (const f32x4*)(pool + i31 * 36 + 16 * hi);    // feature 32c + (lane&31), patches 16hi..
+                if constexpr (SAVEH) {
 #pragma unroll
-                for (int mq = 0; mq < 4; ++mq) {
-                    const f32x4 hv = prow[mq];
-                    if constexpr (SAVEH) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (m0 + 16 * hi + 4 * mq + e < N) a.h_save[(size_t)(m0 + 16 * hi + 4 * mq + e) * Di + 32 * (c ^ hp) + i31] = hv[e];
+                    for (int it = 0; it < 4; ++it) {
+                        const int prow = 8 * it + rsub;
+                        const f32x4 hv = *(const f32x4*)(pool + prow * 36 + 4 * cq);
+                        if (m0 + prow < N) *(f32x4*)(a.h_save + (size_t)(m0 + prow) * Di + 32 * (c ^ hp) + 4 * cq) = hv;
                     }
                 }
             }

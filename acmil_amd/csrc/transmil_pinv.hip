@@ -225,3 +225,135 @@ int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, fl
     }
     return ACMIL_ERR_UNSUPPORTED;
 }
+
+
+// =====================================================================================================================
+// The default form of the chain: ONE WAVE PER 16 x 16 OUTPUT TILE, the whole K extent in registers.
+// A product of the chain is 14 MFLOP per head; what it costs is latency.  The generic GEMM (gemm_f32.hip: 64 x 64 tiles, K loop of
+// 32-wide steps, two __syncthreads per step each waiting for the prefetched loads) took 12.4 us per product.  Here a wave loads
+// its 16 rows of A and its 16 rows of B^T -- both K-contiguous, 2 x M/16 float4 per lane, ALL in flight at once -- and runs
+// M/4 exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32: lane (r = lane & 15, kq = lane >> 4) supplies A[r][k], so with float4 loads at
+// k = 16 j + 4 kq the four elements feed four consecutive MFMAs -- a permutation of the K order that A and B share).  No LDS,
+// no barrier: one L2 round trip + 0.7 us of MFMA per product, 1152 waves at m = 192.  The epilogues write the layouts the next
+// products read (row-major for A operands, transposed -- one float4 per lane -- for B operands), as in the one-launch kernel above.
+// Arithmetic: exact fp32 products, fp32 accumulate (the class of the chain it replaces; reference nystrom_attention.py:12-27).
+// (Measured floor: a dispatch of ANY kernel reports >= 4.6 us here; a product launch takes 8.2 us, the generic GEMM took 12.4.)
+// The iteration in THREE dependent launches instead of four.  With y = x z:
+//     z' = 1/4 z (13 I - y (15 I - y (7 I - y))) = 1/4 (13 z - 15 a + (7 z - a) b),   a = z y,  b = y y
+// (the same polynomial, re-associated): a and b depend on y only, so they share ONE launch (twice the blocks), and with
+// l = 7 z - a the last product is z' = w + 1/4 l b, w = 1/4 (15 l - 92 z) formed by the second launch's epilogue:
+//   P1  y = x z                      -> y (row-major), y^T
+//   P2  a = z y  -> l, w (row-major)        |  b = y y -> b^T          (one launch: first / second half of the grid)
+//   P3  z' = w + 1/4 l b             -> z, z^T (in place: P3 reads neither)
+enum { TQ_Y = 0, TQ_DUAL = 1, TQ_ZF = 2 };
+
+template <int M, int EPI>
+__global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restrict__ A0_all, const float* __restrict__ BT0_all,
+                                                            const float* __restrict__ A1_all, const float* __restrict__ aux_all,
+                                                            float* __restrict__ O0_all, float* __restrict__ O1_all, float* __restrict__ O2_all) {
+    constexpr int NJ = M / 16, TB = M / 32, NBLK = TB * TB * TP_HEADS;
+    // Block -> (head, 32-row band by, 32-column band bx) such that the TB blocks of one (head, by) -- which read the SAME rows of A --
+    // sit on one XCD (block b runs on XCD b % 8: used for speed only)
+    int L = blockIdx.x;
+    bool second = false;                                    // TQ_DUAL: blocks NBLK.. compute b = y y
+    if (EPI == TQ_DUAL && L >= NBLK) { L -= NBLK; second = true; }
+    const int xcd = L & 7, q = L >> 3;
+    const int grp = (q / TB) * 8 + xcd;                     // (head, by) pair, TP_HEADS * TB of them
+    const int head = grp / TB, by = grp - head * TB, bx = q - (q / TB) * TB;
+    const size_t hoff = (size_t)head * M * M;
+    const float* A = (second ? A1_all : A0_all) + hoff;
+    const float* BT = BT0_all + hoff;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ti = 2 * by + (wave >> 1), tj = 2 * bx + (wave & 1);
+    const int r = lane & 15, kq = lane >> 4;
+    const tp_f32x4* ap = (const tp_f32x4*)(A + (size_t)(16 * ti + r) * M + 4 * kq);
+    const tp_f32x4* bp = (const tp_f32x4*)(BT + (size_t)(16 * tj + r) * M + 4 * kq);
+    tp_f32x4 a[NJ], b[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { a[j] = ap[4 * j]; b[j] = bp[4 * j]; }
+    // lane holds C[row0 + i][col], i < 4; the elementwise operands of the epilogue are requested with the panels
+    const int row0 = 16 * ti + 4 * kq, col = 16 * tj + r;
+    tp_f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI == TQ_DUAL && !second) || EPI == TQ_ZF) {
+        const float* X = aux_all + hoff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ax[i] = X[(size_t)(row0 + i) * M + col];
+    }
+    __builtin_amdgcn_sched_barrier(0);      // every load is issued before the first MFMA (left alone, hipcc sinks each load to its use: 30 VGPRs, serial latencies)
+    tp_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: the dependent-issue latency is 40 cycles
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][0], b[j][0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][1], b[j][1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][2], b[j][2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][3], b[j][3], acc1, 0, 0, 0);
+    }
+    const tp_f32x4 v = acc0 + acc1;
+    if constexpr (EPI == TQ_Y) {                             // y row-major + y^T
+        float* O0 = O0_all + hoff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) O0[(size_t)(row0 + i) * M + col] = v[i];
+        *(tp_f32x4*)(O1_all + hoff + (size_t)col * M + row0) = v;
+    } else if constexpr (EPI == TQ_DUAL) {
+        if (second) {                                        // b^T (consumed as a B operand)
+            *(tp_f32x4*)(O2_all + hoff + (size_t)col * M + row0) = v;
+        } else {                                             // l = 7 z - a ; w = 1/4 (15 l - 92 z)      (ax = z)
+            float* O0 = O0_all + hoff; float* O1 = O1_all + hoff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float l = 7.0f * ax[i] - v[i];
+                O0[(size_t)(row0 + i) * M + col] = l;
+                O1[(size_t)(row0 + i) * M + col] = 0.25f * (15.0f * l - 92.0f * ax[i]);
+            }
+        }
+    } else {                                                 // z' = w + 1/4 l b      (ax = w): row-major + transposed
+        float* O0 = O0_all + hoff;
+        tp_f32x4 z;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { z[i] = fmaf(0.25f, v[i], ax[i]); O0[(size_t)(row0 + i) * M + col] = z[i]; }
+        *(tp_f32x4*)(O1_all + hoff + (size_t)col * M + row0) = z;
+    }
+}
+
+// z0 = x^T / (scal0 * scal1) in both layouts
+__global__ __launch_bounds__(256) void tm_pinv_init2_kernel(const float* __restrict__ x, int m, const unsigned* __restrict__ scal,
+                                                             float* __restrict__ z, float* __restrict__ zt) {
+    const float inv = 1.0f / (__uint_as_float(scal[0]) * __uint_as_float(scal[1]));
+    const size_t per = (size_t)m * m, total = per * TP_HEADS;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t h = e / per, rr = e % per; const int i = (int)(rr / m), j = (int)(rr % m);
+        const float v = x[e] * inv;
+        zt[e] = v;
+        z[h * per + (size_t)j * m + i] = v;
+    }
+}
+
+bool tm_pinv_tiles_supported(int m) { return m == 64 || m == 128 || m == 192 || m == 256 || m == 384; }
+
+template <int M>
+static int tm_pinv_tiles_run(const float* X, float* Z, float* ZT, float* Wp, float* BT, float* Y, float* YT, float* Lb,
+                             const unsigned* scal, int iters, float** z_final, hipStream_t st) {
+    hipLaunchKernelGGL(tm_pinv_init2_kernel, dim3(256), dim3(256), 0, st, X, M, scal, Z, ZT);
+    const unsigned nblk = (M / 32) * (M / 32) * TP_HEADS;
+    const dim3 block(256);
+    for (int it = 0; it < iters; ++it) {
+        hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_Y>), dim3(nblk), block, 0, st, X, ZT, (const float*)nullptr, (const float*)nullptr, Y, YT, (float*)nullptr);
+        hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_DUAL>), dim3(2 * nblk), block, 0, st, Z, YT, Y, Z, Lb, Wp, BT);
+        hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_ZF>), dim3(nblk), block, 0, st, Lb, BT, (const float*)nullptr, Wp, Z, ZT, (float*)nullptr);
+    }
+    *z_final = Z;
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+// X [H][m][m] -> *z_final = the buffer (Za or Zb) that holds the pseudo-inverse, row-major
+int tm_pinv_tiles(const float* X, float* Za, float* ZTa, float* Zb, float* ZTb, float* XZ, float* T1T, float* ST, const unsigned* scal,
+                  int m, int iters, float** z_final, hipStream_t st) {
+    switch (m) {
+        case 64: return tm_pinv_tiles_run<64>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+        case 128: return tm_pinv_tiles_run<128>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+        case 192: return tm_pinv_tiles_run<192>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+        case 256: return tm_pinv_tiles_run<256>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+        case 384: return tm_pinv_tiles_run<384>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+    }
+    return ACMIL_ERR_UNSUPPORTED;
+}
