@@ -475,6 +475,11 @@ class ACMIL_GA(_GatedBase):
         split-f16 range word (None when the arithmetic has none); the caller looks at it later (`int(status) != 0` = redo these
         bags with precision="fp32"), e.g. after it has enqueued the next batch, so the GPU never idles on the check
         (train.evaluate does that).  precision overrides the module's arithmetic for this call."""
+        if len(bags) > ops.MAX_BATCH and not defer_guard:      # one launch takes 64 bags: longer lists go out in groups
+            out = []
+            for i in range(0, len(bags), ops.MAX_BATCH):
+                out += self.forward_batch(bags[i:i + ops.MAX_BATCH], precision=precision)
+            return out
         prec = precision or self.precision
         packed, dims = self._packed() if prec == self.precision else self._packed_cached(prec)
         bags = [b if b.is_contiguous() else b.contiguous() for b in bags]

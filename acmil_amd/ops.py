@@ -15,6 +15,7 @@ from . import _lib
 
 _DT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
 GA_DA = 128
+MAX_BATCH = 64       # ACMIL_MAX_BATCH: bags per acmil_ga_forward_batch / _guarded launch
 
 
 def _stream() -> int:
