@@ -286,9 +286,8 @@ int gb_run(const GbRun& r) {
     // 3-5 as ONE kernel per 64-patch tile when the caller holds the pre-split operands (training step, split arithmetic)
     rc = ACMIL_ERR_UNSUPPORTED;
     if (r.w16 && r.wT16 && !r.dA_ext && r.mode != ACMIL_MODE_F32 && gb_use_tile())
-        rc = ga_bwd_tile_launch(r.h, r.A_out, r.stats, r.ck, r.coef, r.Ww, r.d_afeat, bcat, r.w16, r.wT16, G, dpre, part, N, K, Di, st);
+        rc = ga_bwd_tile_launch(r.h, r.A_out, r.stats, r.ck, r.coef, r.Ww, r.d_afeat, bcat, r.w16, r.wT16, G, dpre, part, N, K, Di, st, &blocks);
     if (rc == ACMIL_OK) {
-        blocks = (int)ga_bwd_tile_part_records(N);
     } else if (rc != ACMIL_ERR_UNSUPPORTED) {
         return rc;
     } else {

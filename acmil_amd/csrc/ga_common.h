@@ -24,6 +24,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)   (cdna_hip_programming.md section 3).
 __host__ __device__ static inline int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// Fragment-ordered hi / lo plane pairs (operands of ga_bwd_tile.hip; written by ga_pack.hip and, for the d_afeat columns, by the
+// step's tail kernel): element (row, k) of a [rows][16 nks] matrix lives where the MFMA B fragment of 32-row tile row / 32 and
+// 16-wide K step k / 16 wants it -- lane = 32 * ((k >> 3) & 1) + (row & 31) holds 8 consecutive k as 16 bytes -- so a wave's
+// fragment (1 KB) and its hi / lo pair (2 KB) are contiguous: the kernel loads them global -> registers with fully used cache lines.
+__host__ __device__ static inline size_t ga_frag_off(int row, int k, int nks, int plane) {
+    return ((((size_t)(row >> 5) * nks + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Packed-weight buffer layout (built by ga_pack.hip, consumed by ga_forward.hip).  All offsets in bytes.
 //
@@ -58,8 +66,8 @@ __host__ __device__ static inline GaLayout ga_layout(int D, int Di, int K, int C
     L.wcat_off = off; off += (size_t)2 * GA_DA * Di * 4;     // [Wv; Wu] as one [2 Da, Di] matrix, [bv; bu]: the backward's
     L.bcat_off = off; off += (size_t)2 * GA_DA * 4;          // single-GEMM operands (ga_backward.hip)
     L.wcatT_off = off; off += (size_t)2 * GA_DA * Di * 4;    // [Wv; Wu]^T [Di][2 Da]: K-contiguous operand of the dpre product
-    L.w16_off = off;   off += (size_t)2 * 2 * GA_DA * Di * 2;    // f16 hi / lo planes of [Wv; Wu] [2 Da][Di]              } operands of the fused
-    L.wT16_off = off;  off += (size_t)2 * Di * GA_WT_KX * 2;     // bf16 hi / lo planes of [[Wv;Wu]^T | d_afeat^T | 0] [Di][288] } backward tile kernel
+    L.w16_off = off;   off += (size_t)2 * 2 * GA_DA * Di * 2;    // f16 hi / lo of [Wv; Wu] [2 Da][Di], fragment order (ga_frag_off) } operands of the fused
+    L.wT16_off = off;  off += (size_t)2 * Di * GA_WT_KX * 2;     // bf16 hi / lo of [[Wv;Wu]^T | d_afeat^T | 0] [Di][288], same order } backward tile kernel
     L.total = (off + 255) & ~(size_t)255;
     return L;
 }

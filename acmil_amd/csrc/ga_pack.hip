@@ -115,19 +115,20 @@ __global__ __launch_bounds__(256) void ga_pack_kernel(GaPackArgs a) {
                 const size_t r = e - ncat - nwc - CD;
                 const int di = (int)(r / (2 * GA_DA)), u = (int)(r % (2 * GA_DA));
                 wcatT[r] = u < GA_DA ? a.Wv[(size_t)u * L.Di + di] : a.Wu[(size_t)(u - GA_DA) * L.Di + di];
-            } else if (e < ncat + nwc + CD + 2 * ncat) {  // f16 hi / lo planes of [Wv; Wu] [2 Da][Di]
+            } else if (e < ncat + nwc + CD + 2 * ncat) {  // f16 hi / lo of [Wv; Wu] [2 Da][Di] in fragment order
                 const size_t r = e - ncat - nwc - CD - ncat;
                 const float w = r < ncat / 2 ? a.Wv[r] : a.Wu[r - ncat / 2];
                 _Float16 h, l; split_f16(w, h, l);
                 _Float16* p16 = (_Float16*)(a.out + L.w16_off);
-                p16[r] = h; p16[ncat + r] = l;
+                const int u = (int)(r / L.Di), k = (int)(r % L.Di);
+                p16[ga_frag_off(u, k, L.Di / 16, 0)] = h; p16[ga_frag_off(u, k, L.Di / 16, 1)] = l;
             } else {                                      // bf16 hi / lo planes of [[Wv;Wu]^T | (d_afeat^T: filled by the step's tail kernel) | 0] [Di][288]
                 const size_t r = e - ncat - nwc - CD - 2 * ncat;
                 const int di = (int)(r / GA_WT_KX), u = (int)(r % GA_WT_KX);
                 const float w = u < GA_DA ? a.Wv[(size_t)u * L.Di + di] : u < 2 * GA_DA ? a.Wu[(size_t)(u - GA_DA) * L.Di + di] : 0.0f;
                 const __bf16 h = (__bf16)w, l = (__bf16)(w - (float)h);
                 __bf16* pT = (__bf16*)(a.out + L.wT16_off);
-                pT[r] = h; pT[nT + r] = l;
+                pT[ga_frag_off(di, u, GA_WT_KX / 16, 0)] = h; pT[ga_frag_off(di, u, GA_WT_KX / 16, 1)] = l;
             }
         }
         return;

@@ -296,8 +296,8 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
             a.d_afeat[e] = s;
             if (a.wT16) {      // extension K slot kk of row di of the backward tile kernel's [[Wv;Wu]^T | d_afeat^T] operand (bf16 hi / lo planes)
                 const __bf16 dh = (__bf16)s, dl = (__bf16)(s - (float)dh);
-                a.wT16[(size_t)di * GA_WT_KX + 2 * GA_DA + kk] = dh;
-                a.wT16[(size_t)Di * GA_WT_KX + (size_t)di * GA_WT_KX + 2 * GA_DA + kk] = dl;
+                a.wT16[ga_frag_off(di, 2 * GA_DA + kk, GA_WT_KX / 16, 0)] = dh;
+                a.wT16[ga_frag_off(di, 2 * GA_DA + kk, GA_WT_KX / 16, 1)] = dl;
             }
             const float afv = af[e];
             const float prod = s * afv;

@@ -45,9 +45,9 @@ int wgrad_launch(const float* A1, int lda1, const void* B1, int b1_dtype, int ld
                  const float* A2, int lda2, const void* B2, int b2_dtype, int ldb2, int M2, int N2, float* C2,
                  int K, void* workspace, hipStream_t st, GemmArgs* g1, GemmArgs* g2);
 
-// ga_bwd_tile.hip: G recompute + gate pass + dpre as one kernel per 64-patch tile (needs the pre-split operands of the packed
-// buffer, with the d_afeat columns of wT16 filled); one partial record per tile
+// ga_bwd_tile.hip: G recompute + gate pass + dpre as one kernel per 64- / 32-patch tile (needs the pre-split operands of the packed
+// buffer, with the d_afeat columns of wT16 filled); one partial record per tile (*records; ga_bwd_tile_part_records = upper bound)
 size_t ga_bwd_tile_part_records(int N);
 int ga_bwd_tile_launch(const float* h, const float* A, const float* stats, const float* ck, const float* coef, const float* Ww,
                        const float* d_afeat, const float* bcat, const void* w16, const void* wT16, float* dS, float* dpre,
-                       float* part, int N, int K, int Di, hipStream_t st);
+                       float* part, int N, int K, int Di, hipStream_t st, int* records);
