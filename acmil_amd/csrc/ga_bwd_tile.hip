@@ -151,6 +151,10 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
             for (int r = 0; r < 16; ++r) Gt[(32 * mt + mfma32_row(r, hi)) * BT_GLD + col] = acc[mt][r] + b;
     }
+#ifdef BT_PROF
+    const unsigned long long ptA = __builtin_amdgcn_s_memtime();
+    unsigned long long ptB = 0, ptR = 0;
+#endif
 
     // ================================================================ 2: gate pass (wave w: rows RPW w .. RPW w + RPW - 1)
     {
@@ -166,19 +170,33 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             return *(const bt_fv*)(a.h + (size_t)(n < N ? n : N - 1) * DI + FPL * lane);
         };
         bt_fv hcur = hrow_load(0);
-        static_assert(KP * RPW <= 64, "the scores of a wave's rows fit one register");
-        float sA = -INFINITY;
+        // everything that depends only on (branch k, row rr) is formed ONCE per wave, one (k, rr) pair per lane (lane RPW k + rr):
+        // P = softmax probability (0 where masked / padded / past the bag) and Q = P sum_j coef[k][j] P_j (the diversity term of dA);
+        // the row loop reads them back with v_readlane (as uniform per-row arithmetic they were ~16 VALU instructions per branch and
+        // row on all 64 lanes -- the gate pass is VALU-issue bound)
+        static_assert(KP * RPW <= 64, "the (branch, row) pairs of a wave fit one register");
+        const int lk = lane / RPW, lr = lane % RPW;
+        float P_all = 0.0f, Q_all = 0.0f;
         {
-            const int k = lane / RPW, n = n0 + RPW * wave + (lane % RPW);
-            if (k < K && n < N) sA = a.A[(size_t)k * N + n];
+            const int n = n0 + RPW * wave + lr;
+            const bool ok = lk < K && n < N;
+            const int kc = lk < K ? lk : 0;
+            const float s = a.A[(size_t)kc * N + (n < N ? n : N - 1)];
+            const float M = a.stats[2 * kc], Lsum = a.stats[2 * kc + 1];
+            const bool masked = !ok || !(s > -5e8f);                  // masked_fill(-1e9) positions, padded branches, rows past the bag
+            P_all = masked ? 0.0f : __expf(s - M) * __builtin_amdgcn_rcpf(Lsum);
+            if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (rows / columns >= K are zero in the table)
+                float sdiv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const float Pj = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (RPW * j + lr), __builtin_bit_cast(int, P_all)));
+                    sdiv = fmaf(lk < KP ? a.coef[lk * KP + j] : 0.0f, Pj, sdiv);
+                }
+                Q_all = P_all * sdiv;
+            }
         }
-        // small per-step tables: ONE vector load each, broadcast by v_readlane (as ~40 scalar loads in unrolled conditional code
-        // they were waited for one by one: ~16 k cycles per tile)
-        static_assert(KP * KP <= 64, "coefficient table fits a wave");
-        const float cfv = (a.coef && lane < KP * KP) ? a.coef[lane] : 0.0f;       // rows / columns >= K are zero in the table
         const float ckv = lane < K ? a.ck[lane] : 0.0f;
-        const float stv = lane < 2 * K ? a.stats[lane] : 1.0f;
-        float daf[KP][FPL], ww[KP][2], ck[KP], Mk[KP], iL[KP], cf[KP][KP];
+        float daf[KP][FPL], ww[KP][2], ck[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const int kc = k < K ? k : 0;
@@ -190,13 +208,11 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             ww[k][0] = wv[0]; ww[k][1] = wv[1];
         }
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-#pragma unroll
-            for (int j = 0; j < KP; ++j) cf[k][j] = ga_readlane(cfv, k * KP + j);
-            ck[k] = ga_readlane(ckv, k);
-            Mk[k] = ga_readlane(stv, (2 * k) & 63);
-            iL[k] = __builtin_amdgcn_rcpf(ga_readlane(stv, (2 * k + 1) & 63));
-        }
+        for (int k = 0; k < KP; ++k) ck[k] = ga_readlane(ckv, k);
+#ifdef BT_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ptB = __builtin_amdgcn_s_memtime();
+#endif
         ga_lds_barrier();                                             // G tile complete (all waves' columns)
 #ifdef BT_PROF
         pt1c = __builtin_amdgcn_s_memtime();
@@ -217,19 +233,8 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
                 for (int f = 0; f < FPL; ++f) dp = fmaf(daf[k][f], hcur[f], dp);
                 dp = ga_wave_sum(dp);
-                const float s = ga_readlane(sA, (RPW * k + rr) & 63);
-                const bool masked = !(s > -5e8f);                     // masked_fill(-1e9) positions, padded branches, rows past the bag
-                P[k] = masked ? 0.0f : __expf(s - Mk[k]) * iL[k];
-                dA[k] = masked ? 0.0f : P[k] * (dp - ck[k]);
-            }
-            if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]
-#pragma unroll
-                for (int k = 0; k < KP; ++k) {
-                    float sdiv = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) sdiv = fmaf(cf[k][j], P[j], sdiv);
-                    dA[k] = fmaf(P[k], sdiv, dA[k]);
-                }
+                P[k] = ga_readlane(P_all, (RPW * k + rr) & 63);
+                dA[k] = fmaf(P[k], dp - ck[k], ga_readlane(Q_all, (RPW * k + rr) & 63));     // P = 0 (masked) makes Q = 0 too
             }
             typedef float bt_f2 __attribute__((ext_vector_type(2)));
             const bt_f2 gv = *(const bt_f2*)(grow + 8 * lane), gu = *(const bt_f2*)(grow + 4 * GA_DA + 8 * lane);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             hcur = hnext;
         }
 #ifdef BT_PROF
-        pt1c = __builtin_amdgcn_s_memtime() - pt1c;
+        ptR = __builtin_amdgcn_s_memtime();
 #endif
         // workgroup partial record: [k][128] dWw, [k] dbw, [128] dbv, [128] dbu -- the 8 waves fold into two slots in a fixed
         // order (waves 0 / 1 write, 2 / 3 add, ...: four rounds), so the record is bitwise reproducible
@@ -342,9 +347,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             __builtin_amdgcn_sched_barrier(0);
         }
 #ifdef BT_PROF
-        if (blockIdx.x == 3 && tid == 0)
-            printf("BT phases (cycles): stage+gemm1 %llu  Gt+prefetch %llu  gate rows %llu  records %llu  gemm3 %llu\n", pt1 - pt0, pt2 - pt1 - pt1c, pt1c, 0ull,
-                   __builtin_amdgcn_s_memtime() - pt2);
+        const unsigned long long pt3 = __builtin_amdgcn_s_memtime();
 #endif
         // relu mask + store: lane = column, registers = rows (128-byte row segments per half wave); the 16 mask bytes first, then the
         // stores back to back (one LDS read + wait + branch per store serialised the 32 stores of a wave)
@@ -365,6 +368,11 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                     if (n0 + 32 * (mt0 + m) + mfma32_row(r, hi) < N) dp[(size_t)mfma32_row(r, hi) * DI] = ((mb[r] >> (col & 7)) & 1) ? acc3[m][r] : 0.0f;
             }
         }
+#ifdef BT_PROF
+        if ((blockIdx.x == 3 || blockIdx.x == 300) && tid == 0)
+            printf("BT phases (cycles) blk %d: stage+gemm1 %llu  Gt write %llu  gate loads+pre %llu  barrier %llu  gate rows %llu  records %llu  gemm3 %llu  epilogue %llu  total %llu\n",
+                   (int)blockIdx.x, pt1 - pt0, ptA - pt1, ptB - ptA, pt1c - ptB, ptR - pt1c, pt2 - ptR, pt3 - pt2, __builtin_amdgcn_s_memtime() - pt3, __builtin_amdgcn_s_memtime() - pt0);
+#endif
     }
 }
 

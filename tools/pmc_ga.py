@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--whole-step", action="store_true",
                     help="workloads without one dominant kernel (transmil, train): sum the counters over ALL kernels and divide by the steps")
     args = ap.parse_args()
+    args.out = os.path.abspath(args.out)      # rocprofv3 runs from /tmp
     os.makedirs(args.out, exist_ok=True)
     WARM = 20 if args.whole_step else 3      # whole-step workloads: the first steps carry one-off allocations, keep them out of the average
     calib = [os.path.join(ROOT, "build", "exp", "hbm_calib"), "8"]
@@ -96,8 +97,14 @@ def main():
     r = subprocess.run(bench, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     steps_total = args.steps + WARM
+    per_kernel = {}
     for tag, counters in PASSES.items():
         res = run_pass(tag, counters, bench, args.out)
+        if args.whole_step and tag in ("fetch", "write", "sq"):      # per-kernel view of the step: HBM bytes and matrix-pipe busy cycles per launch
+            for (kn, cn), (avg, cnt) in res.items():
+                if cn in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES") and cnt >= args.steps:
+                    short = kn.split("(")[0].replace("void ", "")[:60]
+                    per_kernel.setdefault(short, {"launches": cnt})[cn] = avg
         for c in counters:
             if args.whole_step:
                 t, n = total(res, c)
@@ -116,6 +123,10 @@ def main():
         us = line["roofline"]["us_per_launch"]
     f_kb, w_kb = summary["per_launch_avg"]["FETCH_SIZE"], summary["per_launch_avg"]["WRITE_SIZE"]
     summary["traffic_bytes_per_launch"] = int(f_kb * 1024 * k_rd + w_kb * 1024 * k_wr)
+    if per_kernel:
+        for kn, d in per_kernel.items():
+            d["hbm_bytes_per_launch"] = int(d.get("FETCH_SIZE", 0.0) * 1024 * k_rd + d.get("WRITE_SIZE", 0.0) * 1024 * k_wr)
+        summary["per_kernel"] = dict(sorted(per_kernel.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]))
     summary["traffic_note"] = "FETCH_SIZE x fetch_correction + WRITE_SIZE x write_correction, KB -> bytes, average over the launches of the bench command"
     # effective shader clock under this kernel (the chip clocks to its 1 400 W budget): GRBM_GUI_ACTIVE counts per XCD, 8 XCDs;
     # matrix-pipe busy fraction against the NOMINAL 2.4 GHz and against the cycles that actually elapsed
