@@ -143,10 +143,15 @@ static int ga_dephase() {
 static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
 
 // tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
-// workgroup per CU: the weight stream is staged once per 256 patches).  ACMIL_GA2_WAVES=4|8 overrides; read once.
-static int ga_v2_waves() {
-    static const int v = [] { const char* e = getenv("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
-    return v;
+// workgroup per CU: the weight stream is staged once per 256 patches).  A launch with more 128-patch tiles than CUs but not enough to
+// give every CU two (one large bag: 391 tiles at N = 50 000) runs the 8-wave geometry: with 4 waves half of the CUs would carry two
+// workgroups and set the pace while the others idle at one (measured 78 - 81 vs 84 - 86 us for one 50 000-patch bag); everything
+// else runs 4 waves.  ACMIL_GA2_WAVES=4|8 overrides; read once.
+static int ga_v2_waves(long long total_patches) {
+    static const int forced = [] { const char* e = getenv("ACMIL_GA2_WAVES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
+    if (forced) return forced;
+    const long long tiles128 = (total_patches + 127) / 128;
+    return (tiles128 > 256 && tiles128 <= 448) ? 8 : 4;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
@@ -252,7 +257,7 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     }
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
-    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(maxN, total_patches);
+    a.waves = ga_use_v2(mode) ? ga_v2_waves(total_patches) : ga_pick_waves(maxN, total_patches);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
@@ -329,7 +334,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(N);
+    a.waves = ga_use_v2(mode) ? ga_v2_waves(N) : ga_pick_waves(N);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
