@@ -293,8 +293,10 @@ def other_workloads(args):
         "roofline": {"kernel": "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
                      "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
                      "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4),
-                     "traffic": pmc_traffic("train", args.precision, 1)[0] if N == 10000 else None,
-                     "traffic_source": pmc_traffic("train", args.precision, 1)[1] if N == 10000 else "no PMC summary at this bag size",
+                     # PMC summaries of the step: tools/pmc_ga.py --workload train --whole-step with --batch 1 (N = 10 000) / --batch 50
+                     # and --extra "--train-n 50000" (the batch argument only names the file for this workload)
+                     "traffic": pmc_traffic("train", args.precision, {10000: 1, 50000: 50}.get(N, -1))[0],
+                     "traffic_source": pmc_traffic("train", args.precision, {10000: 1, 50000: 50}.get(N, -1))[1],
                      "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -433,7 +435,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64,
                     help="slides per step (1..64): bags of one step go through ONE fused launch (acmil_ga_forward_batch); 1 = the "
                          "reference's strictly per-slide call pattern.  A launch of 64 bags is 48 rounds of tiles on the 512 "
-                         "persistent workgroups: the ragged last round and merge + heads weigh 2 % instead of 9 % at 16 bags")
+                         "persistent workgroups: the ragged last round and merge + heads weigh 2 %% instead of 9 %% at 16 bags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="ga_eval", choices=["ga_eval", "ga_cfg3", "transmil", "train", "ga_uni", "ga_gigapath", "ga_clip_l"],
                     help="ga_eval = the BASELINE.json headline (default); ga_cfg3 = configs[2] (N=50000, D=384, D_inner=128, bf16 "

@@ -23,6 +23,7 @@ python tools/pmc_ga.py --precision fp32 --batch 16 --steps 12 --out $OUT/pmc > $
 python tools/pmc_ga.py --workload ga_cfg3 --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_cfg3.log 2>&1
 python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
 python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
+python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --extra "--train-n 50000" --out $OUT/pmc > $OUT/pmc_train50k.log 2>&1
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
 for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
