@@ -80,10 +80,17 @@ class RangeTicket:
     waits for THAT event only -- work enqueued after the launch keeps the GPU busy meanwhile (a plain `int(status)` is a
     stream-ordered read-back: it would wait for everything enqueued since).  (Measured alternative, dropped: routing the copy
     through a side stream costs more in cross-queue waits than the ~50 us the copy engine hand-off costs on the compute stream.)"""
-    _pool: list = []
+    _pool: list = []          # free one-word views of pinned slabs (a fresh pin_memory() call costs up to tens of ms: never in a loop)
+
+    @classmethod
+    def _take(cls) -> torch.Tensor:
+        if not cls._pool:
+            slab = torch.empty(64, dtype=torch.int32).pin_memory()
+            cls._pool.extend(slab[i:i + 1] for i in range(64))
+        return cls._pool.pop()
 
     def __init__(self, status: torch.Tensor):
-        self.host = RangeTicket._pool.pop() if RangeTicket._pool else torch.empty(1, dtype=torch.int32).pin_memory()
+        self.host = RangeTicket._take()
         self.host.copy_(status, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(status.device))
@@ -96,6 +103,14 @@ class RangeTicket:
             RangeTicket._pool.append(self.host)
             self.host = None
         return self._value
+
+    def __del__(self):          # a ticket nobody read: its word goes back once the copy has certainly landed
+        try:
+            host = getattr(self, "host", None)
+            if host is not None and self.event.query():
+                RangeTicket._pool.append(host)
+        except Exception:      # interpreter shutdown
+            pass
 
 
 class _GatedBase(nn.Module):
@@ -146,36 +161,45 @@ class _GatedBase(nn.Module):
                 a.attention_U[0].weight, a.attention_U[0].bias, a.attention_weights.weight,
                 a.attention_weights.bias], wc, bc, ws, bs
 
-    def _packed(self, precision: Optional[str] = None):
+    def _param_list(self):
+        base, wc, bc, ws, bs = self._raw_params()
+        return base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
+
+    @staticmethod
+    def _param_key(allp):
+        """Identity of the current parameter VALUES: storage pointers + torch's version counters (one pass, shared by the caches)."""
+        return tuple([p.data_ptr() for p in allp] + [p._version for p in allp])
+
+    def _pack_now(self, precision: str):
+        base, wc, bc, ws, bs = self._raw_params()
+        return ops.ga_pack_weights(*[p.detach() for p in base], [p.detach() for p in wc], [p.detach() for p in bc],
+                                   None if ws is None else ws.detach(), None if bs is None else bs.detach(), precision)
+
+    def _packed(self, precision: Optional[str] = None, key=None):
         """Packed fragment stream of the current parameter values; re-packed only when a parameter changed
         (tracked through tensor version counters / storage pointers).  precision: pack for another arithmetic mode than the
-        module's (the fp32 re-run of the range guard); not cached."""
-        base, wc, bc, ws, bs = self._raw_params()
+        module's (the fp32 re-run of the range guard); not cached.  key: a _param_key the caller has already formed."""
         if precision is not None and precision != self.precision:
-            return ops.ga_pack_weights(*[p.detach() for p in base], [p.detach() for p in wc], [p.detach() for p in bc],
-                                       None if ws is None else ws.detach(), None if bs is None else bs.detach(), precision)
-        allp = base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
-        key = (self.precision,) + tuple((p.data_ptr(), p._version) for p in allp)
+            return self._pack_now(precision)
+        if key is None:
+            key = self._param_key(self._param_list())
         cache = getattr(self, "_pack_cache", None)
-        if cache is None or cache[0] != key:
-            packed, dims = ops.ga_pack_weights(*[p.detach() for p in base], [p.detach() for p in wc],
-                                               [p.detach() for p in bc], None if ws is None else ws.detach(),
-                                               None if bs is None else bs.detach(), self.precision)
-            cache = (key, packed, dims)
+        if cache is None or cache[0] != key or cache[3] != self.precision:
+            packed, dims = self._pack_now(self.precision)
+            cache = (key, packed, dims, self.precision)
             self._pack_cache = cache
         return cache[1], cache[2]
 
-    def _packed_cached(self, precision: str):
+    def _packed_cached(self, precision: str, key=None):
         """As _packed(precision), but cached per mode (the fp32 repeats of the range guard: eval loops hit it per flagged batch)."""
         if precision == self.precision:
-            return self._packed()
-        base, wc, bc, ws, bs = self._raw_params()
-        allp = base + list(wc) + list(bc) + ([ws, bs] if ws is not None else [])
-        key = (precision,) + tuple((p.data_ptr(), p._version) for p in allp)
+            return self._packed(key=key)
+        if key is None:
+            key = self._param_key(self._param_list())
         cache = self.__dict__.setdefault("_pack_cache_alt", {})
         hit = cache.get(precision)
         if hit is None or hit[0] != key:
-            packed, dims = self._packed(precision)
+            packed, dims = self._pack_now(precision)
             hit = cache[precision] = (key, packed, dims)
         return hit[1], hit[2]
 
@@ -268,12 +292,12 @@ class _GatedBase(nn.Module):
             self._w1_cache = cache
         return cache[1]
 
-    def _eval_forward(self, xb, packed, dims, want_scores=True, want_preds=True, want_bag_feat=False):
+    def _eval_forward(self, xb, packed, dims, want_scores=True, want_preds=True, want_bag_feat=False, key=None):
         """Unmasked forward: the fully fused kernel where a family exists, else score pass + pooling pass."""
         if self._is_fused() and self.precision == "f16x3" and self.range_guard:
             # one library call, no host read-back: split-f16 launch, then its exact-fp32 repeat predicated ON THE DEVICE on the range
             # status (it exits at once for an in-range bag), then merge + heads -- the loop `for x: model(x)` stays asynchronous
-            p32, _ = self._packed_cached("fp32")
+            p32, _ = self._packed_cached("fp32", key=key)
             out = ops.ga_forward_guarded([xb], packed, p32, dims, self._fb_counter(xb.device), want_scores=want_scores,
                                          want_preds=want_preds, want_bag_feat=want_bag_feat)
             for k in ("A_out", "sub_preds", "slide_pred", "bag_feat"):
@@ -351,8 +375,9 @@ class ABMIL(_GatedBase):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._masking_now = False
             return _GaTrainFn.apply(self, xb, None, len(params), *params)[0]
-        packed, dims = self._packed()
-        out = self._eval_forward(xb, packed, dims, want_scores=False)
+        key = self._param_key(params)
+        packed, dims = self._packed(key=key)
+        out = self._eval_forward(xb, packed, dims, want_scores=False, key=key)
         return out["sub_preds"]
 
 
@@ -385,11 +410,12 @@ class ACMIL_GA(_GatedBase):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._masking_now = masking
             return _GaTrainFn.apply(self, xb, uniforms, len(params), *params)
-        packed, dims = self._packed()
+        key = self._param_key(params)          # once per call: both packed-weight caches compare against it
+        packed, dims = self._packed(key=key)
         if masking:
             out = self._masked_forward(xb, packed, dims, uniforms)
         else:
-            out = self._eval_forward(xb, packed, dims)
+            out = self._eval_forward(xb, packed, dims, key=key)
         self._last = out
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["A_out"].unsqueeze(0)
 

@@ -101,6 +101,20 @@ def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
     return _ws_bytes(_lib.load().acmil_ga_workspace_bytes(N, dims.D, dims.Di, dims.K, dims.C, mode), device)
 
 
+_BATCH_WS_NEED: Dict[tuple, int] = {}
+
+
+def _batch_ws_need(lib, B: int, ns: Sequence[int], Ns, dims: "GaDims", mode: int) -> int:
+    """acmil_ga_batch_workspace_bytes, remembered per (bag sizes, shape, mode): the per-slide eval loop asks the same question every call."""
+    key = (tuple(ns), dims.D, dims.Di, dims.K, dims.C, mode)
+    need = _BATCH_WS_NEED.get(key)
+    if need is None:
+        if len(_BATCH_WS_NEED) > 4096:
+            _BATCH_WS_NEED.clear()
+        need = _BATCH_WS_NEED[key] = lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, mode)
+    return need
+
+
 def _range_status(ws: torch.Tensor) -> torch.Tensor:
     """Device view of the split-f16 range status word of a GA workspace (control block, word 1).  Non-zero = a projected
     feature left the f16 range or was not finite (which is also what a bag value outside the range causes: its hi half
@@ -108,7 +122,10 @@ def _range_status(ws: torch.Tensor) -> torch.Tensor:
     on this workspace (the last workgroup of a launch overwrites it; csrc/ga_common.h), so it must be read -- or copied with
     `status.clone()` -- before the next launch on the same stream's workspace.  Reading it (`int(...)`) synchronises; the
     modules do that (lagged, see architecture/transformer.py), the raw ops do not."""
-    return ws[4:8].view(torch.int32)
+    v = ws.__dict__.get("_acmil_status")      # one view per workspace tensor (slicing + view cost ~4 us of host time per call)
+    if v is None:
+        v = ws.__dict__["_acmil_status"] = ws[4:8].view(torch.int32)
+    return v
 
 
 def _check_x(x: torch.Tensor, dims: GaDims) -> None:
@@ -190,16 +207,20 @@ def ga_forward_guarded(xs: Sequence[torch.Tensor], packed: torch.Tensor, packed_
             raise RuntimeError("acmil_amd: all bags of a batch must share one dtype")
     _need_cuda(packed, packed_fp32, fallback_count)
     dev = xs[0].device
-    f32 = dict(dtype=torch.float32, device=dev)
-    Ns = (ctypes.c_int * B)(*[x.shape[0] for x in xs])
+    ns = [x.shape[0] for x in xs]
+    Ns = (ctypes.c_int * B)(*ns)
     xp = (ctypes.c_void_p * B)(*[x.data_ptr() for x in xs])
-    A = [torch.empty(dims.K, x.shape[0], **f32) for x in xs] if want_scores else None
+    A = [torch.empty(dims.K, n, dtype=torch.float32, device=dev) for n in ns] if want_scores else None
     Ap = (ctypes.c_void_p * B)(*[t.data_ptr() for t in A]) if want_scores else None
-    sub = torch.empty(B, dims.K, dims.C, **f32) if want_preds else None
-    slide = torch.empty(B, dims.C, **f32) if (want_preds and dims.has_bag_head) else None
-    af = torch.empty(B, dims.K, dims.Di, **f32) if want_afeat else None
-    bf = torch.empty(B, dims.Di, **f32) if want_bag_feat else None
-    ws = _ws_bytes(lib.acmil_ga_batch_workspace_bytes(B, Ns, dims.D, dims.Di, dims.K, dims.C, _lib.MODE_F16X3), dev)
+    sub = slide = None
+    if want_preds:      # one allocation for the logits of all bags: [B][K*C] then [B][C]
+        KC, Cc = dims.K * dims.C, dims.C
+        buf = torch.empty(B * (KC + (Cc if dims.has_bag_head else 0)), dtype=torch.float32, device=dev)
+        sub = buf[:B * KC].view(B, dims.K, dims.C)
+        slide = buf[B * KC:].view(B, Cc) if dims.has_bag_head else None
+    af = torch.empty(B, dims.K, dims.Di, dtype=torch.float32, device=dev) if want_afeat else None
+    bf = torch.empty(B, dims.Di, dtype=torch.float32, device=dev) if want_bag_feat else None
+    ws = _ws_bytes(_batch_ws_need(lib, B, ns, Ns, dims, _lib.MODE_F16X3), dev)
     rc = lib.acmil_ga_forward_guarded(B, xp, Ns, _DT[xs[0].dtype], packed.data_ptr(), packed_fp32.data_ptr(), *dims.args(), Ap,
                                       _ptr(sub), _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), _ptr(fallback_count),
                                       ws.data_ptr(), _stream())

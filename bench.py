@@ -564,8 +564,10 @@ def main(argv=None):
             rate_b1 = n_m1 / (time.perf_counter() - tm)
             pend = None
             from acmil_amd.train import EVAL_BATCH as EB
-            for i in range(3):
-                model.forward_batch([bags[(i * EB + j) % N_BAGS] for j in range(EB)])
+            for i in range(3):      # warm-up as the loop runs (deferred guard: the pinned status words exist before the timed region)
+                _, pend = model.forward_batch([bags[(i * EB + j) % N_BAGS] for j in range(EB)], defer_guard=True)
+                int(pend)
+            pend = None
             torch.cuda.synchronize()
             tm = time.perf_counter()
             n_mb = max(10, args.steps)
