@@ -143,15 +143,16 @@ static int ga_dephase() {
 static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
 
 // tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
-// workgroup per CU: the weight stream is staged once per 256 patches).  A launch with more 128-patch tiles than CUs but not enough to
-// give every CU two (one large bag: 391 tiles at N = 50 000) runs the 8-wave geometry: with 4 waves half of the CUs would carry two
-// workgroups and set the pace while the others idle at one (measured 78 - 81 vs 84 - 86 us for one 50 000-patch bag); everything
-// else runs 4 waves.  ACMIL_GA2_WAVES=4|8 overrides; read once.
+// workgroup per CU: the weight stream is staged once per 256 patches).  A launch with more 128-patch tiles than CUs but only a few
+// per CU (one large bag: 391 tiles at N = 50 000) runs the 8-wave geometry -- tools/time_single_bag.py, us per forward incl. merge +
+// heads, 4 / 8 waves: 313 tiles 78.3 / 72.6, 391: 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- while up to one tile per CU
+// (256 tiles: 57.1 / 68.7; a single tile: 43.8 / 62.5) and the batched launches (6 256 tiles: 872 / 896) run 4 waves.
+// ACMIL_GA2_WAVES=4|8 overrides; read once.
 static int ga_v2_waves(long long total_patches) {
     static const int forced = [] { const char* e = getenv("ACMIL_GA2_WAVES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
     if (forced) return forced;
     const long long tiles128 = (total_patches + 127) / 128;
-    return (tiles128 > 256 && tiles128 <= 448) ? 8 : 4;
+    return (tiles128 > 256 && tiles128 <= 1024) ? 8 : 4;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once

@@ -609,9 +609,9 @@ def main(argv=None):
     p1 = (2.0 if x_dtype == torch.float16 else 3.0) if split else 1.0
     executed = g1 * p1 + g2 * (3.0 if split else 1.0)
     version = 1 if (os.environ.get("ACMIL_GA_KERNEL") == "1" or not split) else 2
-    if version == 2:      # csrc/ga_forward.hip::ga_v2_waves: 8-wave workgroups when the launch has more 128-patch tiles than CUs but < 2 per CU
+    if version == 2:      # csrc/ga_forward.hip::ga_v2_waves: 8-wave workgroups when the launch has more 128-patch tiles than CUs but at most 4 per CU
         tiles128 = (B * N_PATCH + 127) // 128
-        waves = 8 if 256 < tiles128 <= 448 else 4
+        waves = 8 if 256 < tiles128 <= 1024 else 4
         if os.environ.get("ACMIL_GA2_WAVES") in ("4", "8"):
             waves = int(os.environ["ACMIL_GA2_WAVES"])
     else:                 # ga_pick_waves of the round-1 kernel
