@@ -572,10 +572,15 @@ int ga_launch_fwd_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
     const dim3 grid(a.tile_start[a.nbags]), block(64 * WAVES);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>
                                    : ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>;
-    static const hipError_t attr[2] = {   // once per process, not per launch
-        hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS),
-        hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)};
-    if (attr[0] != hipSuccess || attr[1] != hipSuccess) return ACMIL_ERR_LAUNCH;
+    static bool attr_set[16] = {};      // per DEVICE, once (a process may drive several GPUs)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)ga_fwd_kernel<ND, KP, MODE, XDT, WAVES, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+            return ACMIL_ERR_LAUNCH;
+        attr_set[dev] = true;
+    }
     hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }

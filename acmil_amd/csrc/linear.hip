@@ -57,13 +57,17 @@ extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void
 template <int ND, int XDT>
 static int lin_launch(const LinArgs& a, hipStream_t st) {
     using G = Ga2Geom<ND, 1, XDT>;
-    static const int slots = [] {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 512;
-        return 2 * prop.multiProcessorCount;
-    }();
-    static const hipError_t attr = hipFuncSetAttribute((const void*)lin_kernel<ND, XDT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    if (attr != hipSuccess) return ACMIL_ERR_LAUNCH;
+    // per DEVICE: the dynamic-LDS attribute and the CU count (a process may drive several GPUs, or switch device after the first call)
+    static int slots_of[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
+    if (slots_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)lin_kernel<ND, XDT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        slots_of[dev] = 2 * prop.multiProcessorCount;
+    }
+    const int slots = slots_of[dev];
     const long long tiles = (long long)((a.M + G::ROWS - 1) / G::ROWS) * a.nchunks;
     const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
     hipLaunchKernelGGL((lin_kernel<ND, XDT>), grid, block, G::LDS, st, a);

@@ -37,9 +37,9 @@ N_BAGS = 16      # resident bags (grown to the batch size in main)
 
 SOURCES_OF = {     # kernel sources whose change invalidates a workload's PMC summary
     "ga": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"),
-    "transmil": ("transmil.hip", "transmil_attn.hip", "gemm_f32.hip", "gemm_internal.h"),
+    "transmil": ("transmil.hip", "transmil_attn.hip", "transmil_pinv.hip", "linear_kernel.h", "linear.hip", "gemm_f32.hip", "gemm_internal.h"),
     "train": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h", "ga_step.hip", "ga_train.hip", "ga_bwd_tile.hip", "ga_backward.hip",
-              "wgrad.hip", "optim.hip"),
+              "ga_pack.hip", "wgrad.hip", "optim.hip"),
 }
 
 
