@@ -9,12 +9,15 @@
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long long n, float lr, double beta1, double beta2, float eps,
                                                         float wd, long long launch, const float* __restrict__ skip_flag,
-                                                        int* __restrict__ skipped) {
+                                                        int* __restrict__ skipped, float* __restrict__ flag_report) {
     // device-side skip (like an AMP overflow skip): a non-zero / NaN flag -- the all-reduced range flag of a split-f16 training
     // step, csrc/ga_step.hip -- leaves parameters and moments untouched and is counted in *skipped; the host learns about it
     // later (optim.py).  The step number of the bias corrections is the launch ordinal minus the launches skipped so far, so
     // the update stays torch.optim.AdamW's for the steps that are applied.
     __shared__ float s_bc[2];
+    // the flag, reported to the host without a copy on the stream: one lane stores it to a device-visible address (pinned host
+    // memory); the host reads it after the event it records behind this launch
+    if (flag_report && blockIdx.x == 0 && threadIdx.x == 0) __builtin_nontemporal_store(skip_flag ? skip_flag[0] : 0.0f, flag_report);
     if (skip_flag && !(skip_flag[0] == 0.0f)) {
         if (skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
         return;
@@ -37,13 +40,20 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     }
 }
 
-extern "C" int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
-                                double beta1, double beta2, float eps, float weight_decay, long long step, const float* skip_flag,
-                                int* skipped, void* stream) {
+extern "C" int acmil_adamw_step_report(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                                       double beta1, double beta2, float eps, float weight_decay, long long step, const float* skip_flag,
+                                       int* skipped, float* flag_report, void* stream) {
     if (n <= 0 || step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return ACMIL_ERR_SHAPE;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return ACMIL_ERR_NULL;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr,
-                       beta1, beta2, eps, weight_decay, step, skip_flag, skipped);
+                       beta1, beta2, eps, weight_decay, step, skip_flag, skipped, flag_report);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+extern "C" int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                                double beta1, double beta2, float eps, float weight_decay, long long step, const float* skip_flag,
+                                int* skipped, void* stream) {
+    return acmil_adamw_step_report(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, skip_flag, skipped,
+                                   nullptr, stream);
 }

@@ -71,8 +71,8 @@ class FlatAdamW:
 
     @torch.no_grad()
     def step(self, track_flag: bool = False) -> int:
-        """One launch.  track_flag: also copy the range flag to pinned host memory (asynchronously) so that `poll_skipped`
-        can tell later whether the device applied this step.  Returns this call's id."""
+        """One launch.  track_flag: the launch also stores the range flag into pinned host memory so that `poll_skipped` can tell
+        later whether the device applied this step.  Returns this call's id."""
         g = self.param_groups[0]
         self.step_count += 1
         self._step_id += 1
@@ -80,20 +80,22 @@ class FlatAdamW:
         b1, b2 = g["betas"]
         lib = _lib.load()
         kept = [(o, self.flat[o:o + n].clone()) for o, n in self._frozen]
-        rc = lib.acmil_adamw_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                  self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                  self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
-                                  self._skipped_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "acmil_adamw_step")
+        track = track_flag and self.guard_flag is not None
+        if track and len(self._pending) >= 12:
+            raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
+        slot = self._step_id % 16
+        # tracked: the launch itself stores the flag into pinned host memory (no copy on the stream)
+        rc = lib.acmil_adamw_step_report(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                         self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                         self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
+                                         self._skipped_dev.data_ptr(), self._host_flags.data_ptr() + 4 * slot if track else None,
+                                         torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "acmil_adamw_step_report")
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
             self.on_step()
-        if track_flag and self.guard_flag is not None:
-            if len(self._pending) >= 12:
-                raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
-            slot = self._step_id % 16
-            self._host_flags[slot:slot + 1].copy_(self.guard_flag, non_blocking=True)
+        if track:
             ev = torch.cuda.Event()
             ev.record()
             self._pending.append((self._step_id, ev, slot))

@@ -414,6 +414,11 @@ int acmil_gate_bwd(const float* G, const float* dy, float* dG, long long N, int 
 int acmil_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, double beta1,
                      double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
                      void* stream);
+/* The same; flag_report (may be NULL) = a DEVICE-VISIBLE address -- pinned host memory -- that receives the value of *skip_flag
+ * (0.0f without one) from the launch itself: the host learns whether the step was applied without a copy on the stream. */
+int acmil_adamw_step_report(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, double beta1,
+                            double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
+                            float* flag_report, void* stream);
 
 #ifdef __cplusplus
 }
