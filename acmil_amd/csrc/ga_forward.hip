@@ -143,16 +143,14 @@ static int ga_dephase() {
 static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
 
 // tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
-// workgroup per CU: the weight stream is staged once per 256 patches).  A launch with more 128-patch tiles than CUs but only a few
-// per CU (one large bag: 391 tiles at N = 50 000) runs the 8-wave geometry -- tools/time_single_bag.py, us per forward incl. merge +
-// heads, 4 / 8 waves: 313 tiles 78.3 / 72.6, 391: 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- while up to one tile per CU
-// (256 tiles: 57.1 / 68.7; a single tile: 43.8 / 62.5) and the batched launches (6 256 tiles: 872 / 896) run 4 waves.
-// ACMIL_GA2_WAVES=4|8 overrides; read once.
-static int ga_v2_waves(long long total_patches) {
-    static const int forced = [] { const char* e = getenv("ACMIL_GA2_WAVES"); const int v = e ? atoi(e) : 0; return (v == 4 || v == 8) ? v : 0; }();
-    if (forced) return forced;
-    const long long tiles128 = (total_patches + 127) / 128;
-    return (tiles128 > 256 && tiles128 <= 1024) ? 8 : 4;
+// workgroup per CU: the weight stream is staged once per 256 patches).  4 waves is the default for every launch, so the pooled results
+// of a bag do not depend on what else shares its launch (tile partition = summation order).  The 8-wave geometry is an opt-in
+// (ACMIL_GA2_WAVES=8, read once); measured with tools/time_single_bag.py, us per forward incl. merge + heads, 4 / 8 waves:
+// one bag of 313 tiles 78.3 / 72.6, 391 (N = 50 000): 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- but 256 tiles:
+// 57.1 / 68.7, a single tile: 43.8 / 62.5, and the batched launches (6 256 tiles): 872 / 896.
+static int ga_v2_waves() {
+    static const int v = [] { const char* e = getenv("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    return v;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
@@ -258,7 +256,7 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     }
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
-    a.waves = ga_use_v2(mode) ? ga_v2_waves(total_patches) : ga_pick_waves(maxN, total_patches);
+    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(maxN, total_patches);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
@@ -335,7 +333,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.waves = ga_use_v2(mode) ? ga_v2_waves(N) : ga_pick_waves(N);
+    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(N);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;

@@ -609,11 +609,8 @@ def main(argv=None):
     p1 = (2.0 if x_dtype == torch.float16 else 3.0) if split else 1.0
     executed = g1 * p1 + g2 * (3.0 if split else 1.0)
     version = 1 if (os.environ.get("ACMIL_GA_KERNEL") == "1" or not split) else 2
-    if version == 2:      # csrc/ga_forward.hip::ga_v2_waves: 8-wave workgroups when the launch has more 128-patch tiles than CUs but at most 4 per CU
-        tiles128 = (B * N_PATCH + 127) // 128
-        waves = 8 if 256 < tiles128 <= 1024 else 4
-        if os.environ.get("ACMIL_GA2_WAVES") in ("4", "8"):
-            waves = int(os.environ["ACMIL_GA2_WAVES"])
+    if version == 2:      # csrc/ga_forward.hip::ga_v2_waves: 4 waves unless the opt-in is set
+        waves = 8 if os.environ.get("ACMIL_GA2_WAVES") == "8" else 4
     else:                 # ga_pick_waves of the round-1 kernel
         waves = 4 if (B * N_PATCH >= 1024 * 128 or N_PATCH < 32768) else 8
     traffic, traffic_src = pmc_traffic(args.workload, args.precision, B)
