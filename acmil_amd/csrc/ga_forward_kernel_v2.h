@@ -59,10 +59,12 @@ struct Ga2Probe {
 };
 #endif
 
-template <int ND, int KP, int XDT, int WV = 4>
+template <int ND, int KP, int XDT, int WV = 4, bool TRI = false>
 struct Ga2Geom {
     static constexpr int WAVES = WV;                                // 4: one wave per SIMD, two workgroups per CU; 8: ONE 256-patch workgroup
-    static constexpr int WGS = 8 / WV;                              //    per CU (the weight stream crosses L2 -> LDS once per 256 patches)
+    // TRI: THREE 4-wave workgroups per CU = three waves per SIMD (the D_inner = 128 family with 16-bit bags: 64 accumulator
+    // registers and a 12 KiB ring slot leave room for it; the pooling image then holds the hi and the lo planes one after the other)
+    static constexpr int WGS = TRI ? 3 : 8 / WV;                    //    per CU (the weight stream crosses L2 -> LDS once per 256 patches)
     static constexpr int XE = (XDT == ACMIL_DTYPE_F32) ? 4 : 2;     // bytes per bag element
     static constexpr int WROWS = 2 * ND;                            // fragment rows per step ("hi" rows then "lo" rows)
     static_assert(WROWS % WAVES == 0, "every wave copies the same number of consecutive fragment rows");
@@ -80,7 +82,7 @@ struct Ga2Geom {
     static_assert(ND % 2 == 0, "whole 64-column pairs");        // (the fused GA kernel further needs ND % 4 == 0: asserted there)
     static constexpr int Di = 32 * ND;
     static constexpr int RING = NB * SLOT;
-    static constexpr int PTILE = 4608;                              // wave-private transposition image: 2 x 4 planes x 576 B (f16) or [32][36] fp32
+    static constexpr int PTILE = TRI ? 2304 : 4608;                 // wave-private transposition image: 2 x 4 planes x 576 B (f16; TRI: 4 planes, hi then lo) or [32][36] fp32
     static constexpr int COMB = KP * Di * 4;                        // wave's combine record [KP][Di]
     static constexpr int PW = (PTILE > COMB) ? PTILE : COMB;        // per-wave epilogue scratch
     static constexpr int TAB_BYTES = (2 + KP) * GA_DA * 4 + 32;     // bv[128], bu[128], Ww[KP][128], bw[8]
@@ -119,13 +121,17 @@ __device__ __forceinline__ float ga2_dpp(float v, float idv) {
 }
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// three workgroups per CU: the pooled (eval) kernel of the D_inner = 128 family on 16-bit bags, 4-wave geometry
+template <int ND, int XDT, bool POOL, int WV, bool PAIR>
+struct Ga2Tri { static constexpr bool value = POOL && ND == 4 && XDT != ACMIL_DTYPE_F32 && WV == 4 && !PAIR; };
+
 template <int ND, int KP, int XDT, bool POOL, bool SAVEH, int WV = 4, bool PAIR = false>
-__global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
+__global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 3 : 2)) void ga_fwd2_kernel(GaFwdArgs a) {
     static_assert(ND % 4 == 0, "D_inner must be a multiple of 128");
     static_assert(!PAIR || ND == 8, "the wave-pair split is built for D_inner = 256 (two h tiles per GEMM2 step)");
     static_assert(!PAIR || WV == 4, "exchange buffers: 4 KiB of the free slot's per-wave region (5 - 6 KiB at 4 waves)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = Ga2Geom<ND, KP, XDT, WV>;
+    using G = Ga2Geom<ND, KP, XDT, WV, Ga2Tri<ND, XDT, POOL, WV, PAIR>::value>;
     constexpr int WAVES = G::WAVES, NTHR = 64 * WAVES;
     constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
     constexpr int Di = G::Di, PD = G::PD, NB = G::NB;
@@ -872,26 +878,56 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) {
                 __builtin_amdgcn_sched_barrier(0);
-                *(f16x8*)(scr + wr_off) = hh[d][0];
-                *(f16x8*)(scr + wr_off + 2 * 576) = hh[d][1];
-                *(f16x8*)(scr + 2304 + wr_off) = hl[d][0];
-                *(f16x8*)(scr + 2304 + wr_off + 2 * 576) = hl[d][1];
-                __builtin_amdgcn_wave_barrier();
                 f32x16 accp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+                if constexpr (G::PTILE >= 4608) {
+                    *(f16x8*)(scr + wr_off) = hh[d][0];
+                    *(f16x8*)(scr + wr_off + 2 * 576) = hh[d][1];
+                    *(f16x8*)(scr + 2304 + wr_off) = hl[d][0];
+                    *(f16x8*)(scr + 2304 + wr_off + 2 * 576) = hl[d][1];
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    // K step st = patches 16st .. 16st+15; two transposed reads (4 patches each) per fragment
-                    const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st));
-                    const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st + 64));
-                    const h16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st));
-                    const h16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st + 64));
-                    const f16x8 Bh = __builtin_shufflevector(__builtin_bit_cast(f16x4, a0), __builtin_bit_cast(f16x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
-                    const f16x8 Bl = __builtin_shufflevector(__builtin_bit_cast(f16x4, b0), __builtin_bit_cast(f16x4, b1), 0, 1, 2, 3, 4, 5, 6, 7);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bh, accp, 0, 0, 0);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PL[st], Bh, accp, 0, 0, 0);
-                    accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bl, accp, 0, 0, 0);
+                    for (int st = 0; st < 2; ++st) {
+                        // K step st = patches 16st .. 16st+15; two transposed reads (4 patches each) per fragment
+                        const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st));
+                        const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st + 64));
+                        const h16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st));
+                        const h16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + 2304 + rd_off + 256 * st + 64));
+                        const f16x8 Bh = __builtin_shufflevector(__builtin_bit_cast(f16x4, a0), __builtin_bit_cast(f16x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+                        const f16x8 Bl = __builtin_shufflevector(__builtin_bit_cast(f16x4, b0), __builtin_bit_cast(f16x4, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bh, accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PL[st], Bh, accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bl, accp, 0, 0, 0);
+                    }
+                } else {
+                    // one 2304-byte image: the hi planes, then (after they have been read) the lo planes; same products, same order
+                    // of accumulation per K step is NOT kept (hi-plane products of both K steps first) -- this variant has its own
+                    // tolerance-level identity with the two-image form, not a bitwise one
+                    *(f16x8*)(scr + wr_off) = hh[d][0];
+                    *(f16x8*)(scr + wr_off + 2 * 576) = hh[d][1];
+                    __builtin_amdgcn_wave_barrier();
+                    f16x8 Bh[2];
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const h16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st));
+                        const h16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st + 64));
+                        Bh[st] = __builtin_shufflevector(__builtin_bit_cast(f16x4, a0), __builtin_bit_cast(f16x4, a1), 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);          // the hi planes are in registers
+                    __builtin_amdgcn_wave_barrier();
+                    *(f16x8*)(scr + wr_off) = hl[d][0];
+                    *(f16x8*)(scr + wr_off + 2 * 576) = hl[d][1];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const h16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st));
+                        const h16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((ltr_t)(scr + rd_off + 256 * st + 64));
+                        const f16x8 Bl = __builtin_shufflevector(__builtin_bit_cast(f16x4, b0), __builtin_bit_cast(f16x4, b1), 0, 1, 2, 3, 4, 5, 6, 7);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bh[st], accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PL[st], Bh[st], accp, 0, 0, 0);
+                        accp = __builtin_amdgcn_mfma_f32_32x32x16_f16(PH[st], Bl, accp, 0, 0, 0);
+                    }
                 }
                 // D rows: register r of lane half hi is branch (r&3) + 8(r>>2) + 4hi -> registers 0..3 = branches 4hi .. 4hi+3
 #pragma unroll
@@ -1006,23 +1042,26 @@ __global__ __launch_bounds__(64 * WV, 2) void ga_fwd2_kernel(GaFwdArgs a) {
 // count are looked up per DEVICE (a process may drive several GPUs, or switch device after the first call)
 template <int ND, int KP, int XDT, int WV, bool PAIR>
 int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
-    using G = Ga2Geom<ND, KP, XDT, WV>;
-    static int slots_of[16] = {0};
+    using GP = Ga2Geom<ND, KP, XDT, WV, Ga2Tri<ND, XDT, true, WV, PAIR>::value>;      // the pooled (eval) kernel's geometry
+    using GS = Ga2Geom<ND, KP, XDT, WV, false>;                                       // the score pass
+    static int cus_of[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
-    if (slots_of[dev] == 0) {
+    if (cus_of[dev] == 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, true, false, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, false, true, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, true, false, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, GP::LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)ga_fwd2_kernel<ND, KP, XDT, false, true, WV, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, GS::LDS) != hipSuccess)
             return ACMIL_ERR_LAUNCH;
-        slots_of[dev] = G::WGS * prop.multiProcessorCount;
+        cus_of[dev] = prop.multiProcessorCount;
     }
-    const int slots = slots_of[dev];
+    static const bool no_tri = getenv("ACMIL_GA2_NO_TRI") != nullptr;      // A/B knob: two workgroups per CU for every family
+    const int wgs = pool ? ((GP::WGS == 3 && no_tri) ? 2 : GP::WGS) : GS::WGS;
+    const int slots = wgs * cus_of[dev];
     const int tiles = a.tile_start[a.nbags];
     const dim3 grid(tiles < slots ? tiles : slots), block(64 * WV);
     void (*kern)(GaFwdArgs) = pool ? ga_fwd2_kernel<ND, KP, XDT, true, false, WV, PAIR> : ga_fwd2_kernel<ND, KP, XDT, false, true, WV, PAIR>;
-    hipLaunchKernelGGL(kern, grid, block, G::LDS, st, a);
+    hipLaunchKernelGGL(kern, grid, block, pool ? GP::LDS : GS::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
