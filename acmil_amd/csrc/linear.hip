@@ -84,17 +84,20 @@ static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
     return ACMIL_ERR_UNSUPPORTED;
 }
 
-extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
-                                  const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream) {
+// Control words of a call (32-bit, at `workspace`): 0 / 1 tile counters of the main / remainder launch, 2 range status, 4 / 5
+// finished-workgroup counters.  init: zero them here (the C entry: any 256-byte scratch will do); !init: the caller zeroed them once
+// and every launch leaves the counters at zero (TransMIL: one memset per forward instead of one per Linear layer; the status word
+// then accumulates over the forward and is not looked at).
+int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out, const float* bias, int act,
+                  float beta, float* y, long long ldy, void* workspace, hipStream_t st, bool init) {
     if (M <= 0 || !lin_dims_ok(n_out, K) || ldx < K || ldy < n_out) return ACMIL_ERR_SHAPE;
     if (act != 0 && act != 1) return ACMIL_ERR_UNSUPPORTED;
     if (!x || !packed || !y || !workspace) return ACMIL_ERR_NULL;
     const int xe = (x_dtype == ACMIL_DTYPE_F32) ? 4 : 2;
     if (((size_t)x & 15) != 0 || ((size_t)ldx * xe) % 16 != 0) return ACMIL_ERR_SHAPE;     // 16-byte LDS-DMA pieces
     if (((size_t)y & 15) != 0 || ldy % 4 != 0) return ACMIL_ERR_SHAPE;                     // 16-byte row stores
-    hipStream_t st = (hipStream_t)stream;
     unsigned* ctr = (unsigned*)workspace;
-    if (hipMemsetAsync(ctr, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (init && hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
@@ -102,17 +105,22 @@ extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long
     const LinPlan P = lin_plan(n_out);
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
-        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr;
+        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr; a.done = ctr + 4;
         rc = P.nd == 6 ? lin_launch_dt<6>(a, x_dtype, st) : lin_launch_dt<8>(a, x_dtype, st);
         if (rc != ACMIL_OK) return rc;
     }
     if (P.nd_rem) {
         const int c0 = P.nmain * 32 * P.nd;
         a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
-        a.bias = bias ? bias + c0 : nullptr; a.tile_counter = ctr + 1;
+        a.bias = bias ? bias + c0 : nullptr; a.tile_counter = ctr + 1; a.done = ctr + 5;
         rc = lin_launch_dt<4>(a, x_dtype, st);
     }
     return rc;
+}
+
+extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
+                                  const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream) {
+    return lin_f16x3_run(x, x_dtype, M, K, ldx, packed, n_out, bias, act, beta, y, ldy, workspace, (hipStream_t)stream, true);
 }
 
 // Gated-attention scores of an already projected bag h [N, L] in ONE pass over h (Attention_Gated.forward,
@@ -133,7 +141,7 @@ extern "C" int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int 
     if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
     a.x = h; a.ldx = ldh; a.M = N; a.K = L; a.bias = bias_vu; a.act = 2; a.beta = 0.0f; a.y = nullptr; a.ldy = 0;
-    a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr;
+    a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr; a.done = nullptr;
     a.ww = Ww; a.bw = bw; a.scores = A; a.kb = K; a.status = nullptr;
     return lin_launch_dt<8>(a, h_dtype, st);
 }

@@ -22,6 +22,8 @@ struct LinArgs {
     const float* bias;      // [n_out of this launch] or null (indexed by output column - col0)
     float* y;               // [M, ldy] fp32; this launch writes columns col0 .. col0 + nchunks * 32 ND
     unsigned* tile_counter; // zeroed word (dynamic tile drawing) or null
+    unsigned* done;         // zeroed word or null: finished-workgroup count; the last workgroup puts both words back to zero, so a
+                            // caller that zeroed them once (TransMIL: once per forward) needs no memset between launches
     long long ldx, ldy;
     int M, K, nchunks, col0, act;   // act: 0 none, 1 relu, 2 gated-attention scores (below)
     float beta;                     // y = act(acc + bias) + beta * y_old   (residual adds)
@@ -354,5 +356,12 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
         T = TN;
     }
 #undef LIN_DMA_AT
-    ga_wait_vm<0>();
+    ga_wait_vm<0>();      // (also: every tile draw of this workgroup has returned)
+    if (dynamic && a.done) {
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned d = atomicAdd(a.done, 1u);
+            if (d == gridDim.x - 1) { atomicExch(a.done, 0u); atomicExch(a.tile_counter, 0u); }
+        }
+    }
 }

@@ -74,9 +74,11 @@ __global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int ns
 // grid (m, 2): workgroup = (landmark j, q or k half); thread = (float4 column, row phase): `phases` threads share a column and
 // take rows phase, phase + phases, ... (float4 loads, 4 in flight), then a fixed-order LDS reduce over the phases.
 __global__ __launch_bounds__(1024) void tm_landmark_kernel(const float* __restrict__ qkv, int l, int m, int Di, int phases,
-                                                          float* __restrict__ QL, float* __restrict__ KL) {
+                                                          float* __restrict__ QL, float* __restrict__ KL, unsigned* __restrict__ scal_zero) {
     extern __shared__ __attribute__((aligned(16))) float lm_red[];   // [phases][Di]
     const int j = blockIdx.x, half = blockIdx.y;
+    // the two atomic-max words of this layer's Moore-Penrose scaling (tm_pinv_maxsum_kernel, two launches further down the stream)
+    if (scal_zero && j == 0 && half == 0 && threadIdx.x < 2) scal_zero[threadIdx.x] = 0u;
     const int c4n = Di / 4;
     const int c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n;
     const int d = Di / TM_HEADS;
@@ -397,8 +399,9 @@ static bool tm_pinv_x3() { static const bool v = getenv("ACMIL_TM_PINV_X3") != n
 
 extern "C" size_t acmil_linear_packed_bytes(int n_out, int K);
 extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream);
-extern "C" int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out,
-                                  const float* bias, int act, float beta, float* y, long long ldy, void* workspace, void* stream);
+// linear.hip: the packed Linear kernel on control words the CALLER has zeroed (once per forward here); every launch leaves them zero
+int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out, const float* bias, int act,
+                  float beta, float* y, long long ldy, void* workspace, hipStream_t st, bool init);
 
 // y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
 // Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
@@ -412,7 +415,7 @@ static int tm_linear(const float* x, int M, int K, long long ldx, const float* W
     if (lin_ok) {
         int rc = acmil_linear_pack(W, K, n_out, K, pkw, st);
         if (rc != ACMIL_OK) return rc;
-        return acmil_linear_f16x3(x, ACMIL_DTYPE_F32, M, K, ldx, pkw, n_out, bias, act, beta, y, ldy, linws, st);
+        return lin_f16x3_run(x, ACMIL_DTYPE_F32, M, K, ldx, pkw, n_out, bias, act, beta, y, ldy, linws, st, false);
     }
     TM_LINEAR(0, 1, M, n_out, K, 1.0f, x, (int)ldx, 0, W, ACMIL_DTYPE_F32, K, 0, beta, y, (int)ldy, 0, bias, act, nullptr, 1, gws, st);
     return ACMIL_OK;
@@ -448,7 +451,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     {
         int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
         const int threads = ((Di / 4) * phases + 63) / 64 * 64;
-        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL);
+        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, scal);
     }
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
@@ -464,7 +467,6 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration
     TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
     rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
-    if (hipMemsetAsync(scal, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
     TM_CHECK_LAUNCH();
     float* zc = Z; float* zn = T2;     // ping-pong z
@@ -538,6 +540,8 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     float* weff = (float*)(ws + W.WEFF); float* beff = (float*)(ws + W.BEFF);
     void* gws = ws + W.GEMM;
     const size_t tokbytes = (size_t)g.n * Di;
+    // control words of the packed Linear launches: zeroed ONCE per forward (every launch leaves its counters at zero again)
+    if (hipMemsetAsync(ws + W.LINWS, 0, 32, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
     { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, ws + W.PKW, ws + W.LINWS, gws, st); if (r1 != ACMIL_OK) return r1; }
     hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
