@@ -239,20 +239,56 @@ __global__ __launch_bounds__(256) void tm_seqconv_kernel(const float* __restrict
     }
 }
 
-// PPEG weights: weff[tap 0..48][c] = w7 + pad(w5) + pad(w3) + identity at the centre ; beff[c] = b7 + b5 + b3
-__global__ void tm_ppeg_pack_kernel(const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
-                                    const float* b3, int C, float* weff, float* beff) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    for (int ky = 0; ky < 7; ++ky)
-        for (int kx = 0; kx < 7; ++kx) {
-            float v = w7[(size_t)c * 49 + ky * 7 + kx];
-            if (ky >= 1 && ky <= 5 && kx >= 1 && kx <= 5) v += w5[(size_t)c * 25 + (ky - 1) * 5 + (kx - 1)];
-            if (ky >= 2 && ky <= 4 && kx >= 2 && kx <= 4) v += w3[(size_t)c * 9 + (ky - 2) * 3 + (kx - 2)];
-            if (ky == 3 && kx == 3) v += 1.0f;
-            weff[(size_t)(ky * 7 + kx) * C + c] = v;
-        }
-    beff[c] = b7[c] + b5[c] + b3[c];
+// PPEG weights: weff[tap 0..48][c] = w7 + pad(w5) + pad(w3) + identity at the centre ; beff[c] = b7 + b5 + b3.  One thread per
+// (tap, channel) element (a thread per channel walked its 49 + 25 + 9 taps as a chain of dependent loads: 13.8 us); the same launch
+// passes the cls row through (transMIL.py:39: cls_token is not convolved) -- it was a launch of its own.
+__global__ __launch_bounds__(256) void tm_ppeg_pack_kernel(const float* w7, const float* b7, const float* w5, const float* b5, const float* w3,
+                                                          const float* b3, int C, float* weff, float* beff, const float* cls_in, float* cls_out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 49 * C) return;
+    const int tap = e / C, c = e - tap * C;
+    const int ky = tap / 7, kx = tap - 7 * ky;
+    float v = w7[(size_t)c * 49 + tap];
+    if (ky >= 1 && ky <= 5 && kx >= 1 && kx <= 5) v += w5[(size_t)c * 25 + (ky - 1) * 5 + (kx - 1)];
+    if (ky >= 2 && ky <= 4 && kx >= 2 && kx <= 4) v += w3[(size_t)c * 9 + (ky - 2) * 3 + (kx - 2)];
+    if (tap == 24) v += 1.0f;
+    weff[(size_t)tap * C + c] = v;
+    if (tap == 0) { beff[c] = b7[c] + b5[c] + b3[c]; cls_out[c] = cls_in[c]; }
+}
+
+// the end of the forward: LayerNorm of the cls row and the class logits in ONE launch (were a LayerNorm launch + a 1 x C GEMM: 19 us)
+__global__ __launch_bounds__(256) void tm_cls_head_kernel(const float* __restrict__ x, int dim, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ W,
+                                                         const float* __restrict__ b, int C, float* __restrict__ logits) {
+    __shared__ float ln[1024];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float v[4], s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; v[i] = c < dim ? x[c] : 0.0f; s += v[i]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / dim;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float d = (tid + 256 * i < dim) ? v[i] - mean : 0.0f; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[1][wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / dim + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int c = tid + 256 * i; if (c < dim) ln[c] = (v[i] - mean) * rstd * gamma[c] + beta[c]; }
+    __syncthreads();
+    for (int c = wave; c < C; c += 4) {
+        float t = 0.0f;
+        for (int d = lane; d < dim; d += 64) t = fmaf(ln[d], W[(size_t)c * dim + d], t);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) logits[c] = t + b[c];
+    }
 }
 
 // depth-wise 7x7 on the [side x side] token grid, channels-last (token p = y*side + x lives at row p of `in`).
@@ -551,8 +587,8 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     int rc = tm_layer(g, W, ws, XA, l1, st); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
     // PPEG: cls passthrough + combined depth-wise 7x7
-    hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((Di + 63) / 64), dim3(64), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff);
-    hipLaunchKernelGGL(tm_copy_kernel, dim3(1), dim3(256), 0, st, XA + (size_t)g.pad * Di, XB + (size_t)g.pad * Di, (size_t)Di);
+    hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
+                       XA + (size_t)g.pad * Di, XB + (size_t)g.pad * Di);
     {
         const int tiles = (g.side + TM_PT - 1) / TM_PT;
         hipLaunchKernelGGL(tm_ppeg_kernel, dim3((Di + 63) / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
@@ -562,9 +598,9 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
     rc = tm_layer(g, W, ws, XB, l2, st); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
-    // final LayerNorm on the cls row only, then fc2
-    hipLaunchKernelGGL(tm_layernorm_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, LN, 1, Di, norm_w, norm_b, 0);
+    // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
+    if (Di > 1024) return ACMIL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);
     TM_CHECK_LAUNCH();
-    TM_GEMM(0, 1, 1, C, Di, 1.0f, LN, Di, 0, fc2_w, ACMIL_DTYPE_F32, Di, 0, 0.0f, logits, C, 0, fc2_b, 0, nullptr, 1, gws, st);
     return ACMIL_OK;
 }
