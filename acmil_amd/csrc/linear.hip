@@ -13,9 +13,9 @@ __host__ __device__ static inline LinPlan lin_plan(int n_out) {
     return LinPlan{8, n_out / 256, (n_out % 256) ? 4 : 0};
 }
 
-__global__ __launch_bounds__(256) void lin_pack_kernel(LinPackArgs a) {
+__device__ __forceinline__ void lin_pack_rows(const LinPackArgs& a, unsigned block) {
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t row = (size_t)block * 4 + (threadIdx.x >> 6);
     const int S1 = a.K / 16;
     const LinPlan P = lin_plan(a.n_out);
     const size_t per = (size_t)S1 * 2 * P.nd;                 // fragment rows of one main chunk
@@ -36,6 +36,15 @@ __global__ __launch_bounds__(256) void lin_pack_kernel(LinPackArgs a) {
     }
     *(f16x8*)(a.out + row * GA_FRAG_ROW + lane * 16) = v;
 }
+__global__ __launch_bounds__(256) void lin_pack_kernel(LinPackArgs a) { lin_pack_rows(a, blockIdx.x); }
+
+// several weight matrices in ONE launch (grid.y = job): TransMIL packs its five Linear layers at the start of a forward
+#define LIN_PACK_MAX_JOBS 8
+struct LinPackMulti { LinPackArgs job[LIN_PACK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void lin_pack_multi_kernel(LinPackMulti m) {
+    // (the argument struct is only read, with a wave-uniform index)
+    lin_pack_rows(m.job[blockIdx.y], blockIdx.x);
+}
 
 static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K > 0 && n_out % 128 == 0 && K % 16 == 0; }
 
@@ -43,6 +52,23 @@ extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
     if (!lin_dims_ok(n_out, K)) return 0;
     const LinPlan P = lin_plan(n_out);
     return (size_t)(K / 16) * GA_FRAG_ROW * ((size_t)2 * P.nd * P.nmain + 2 * P.nd_rem);
+}
+
+// internal: n <= 8 packs in one launch; every job's shape must satisfy acmil_linear_packed_bytes != 0
+int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st) {
+    if (n <= 0 || n > LIN_PACK_MAX_JOBS) return ACMIL_ERR_SHAPE;
+    LinPackMulti m;
+    size_t maxrows = 0;
+    for (int j = 0; j < LIN_PACK_MAX_JOBS; ++j) {
+        const int q = j < n ? j : 0;
+        if (!lin_dims_ok(n_out[q], K[q]) || ldw[q] < K[q]) return ACMIL_ERR_SHAPE;
+        if (!W[q] || !packed[q]) return ACMIL_ERR_NULL;
+        m.job[j] = LinPackArgs{W[q], (char*)packed[q], ldw[q], n_out[q], K[q]};
+        const size_t rows = acmil_linear_packed_bytes(n_out[q], K[q]) / GA_FRAG_ROW;
+        if (rows > maxrows) maxrows = rows;
+    }
+    hipLaunchKernelGGL(lin_pack_multi_kernel, dim3((unsigned)((maxrows + 3) / 4), (unsigned)n), dim3(256), 0, st, m);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
 extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream) {

@@ -398,10 +398,11 @@ static TmWs tm_ws(const TmGeom& g) {
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
     w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
-    // packed-weight Linear kernel (linear.hip): one fragment stream at a time (the largest of fc1 / to_qkv / to_out) + its counters
+    // packed-weight Linear kernel (linear.hip): the fragment streams of all five Linear layers (fc1; to_qkv, to_out of both layers:
+    // PKW + {0, fc1, fc1 + qkv, fc1 + qkv + out, ...}), packed by ONE launch at the start of a forward, + the kernel's counters
     {
-        size_t pk = (size_t)g.Di * g.D * 4, q = (size_t)3 * g.Di * g.Di * 4;
-        w.PKW = off; off += tm_al(pk > q ? pk : q);
+        const size_t pk = tm_al((size_t)g.Di * g.D * 4), q = tm_al((size_t)3 * g.Di * g.Di * 4), o = tm_al((size_t)g.Di * g.Di * 4);
+        w.PKW = off; off += pk + 2 * (q + o);
         w.LINWS = off; off += 256;
     }
     // split-K scratch: the largest need over EVERY product of the forward (a small bag with a wide feature vector splits
@@ -438,19 +439,22 @@ extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void
 // linear.hip: the packed Linear kernel on control words the CALLER has zeroed (once per forward here); every launch leaves them zero
 int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out, const float* bias, int act,
                   float beta, float* y, long long ldy, void* workspace, hipStream_t st, bool init);
+int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st);
 
 // y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
 // Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
 // launch, ~4 us) where its shape rules hold -- 216 / 216 / 197 TF on the three cfg4 shapes against 199 / 201 / 186 for the generic
 // split GEMM; otherwise, and for ACMIL_TM_FP32_GEMM=1 (exact fp32 MFMA), the generic GEMMs.  ACMIL_TM_GENERIC_GEMM=1: A/B knob.
 static int tm_linear(const float* x, int M, int K, long long ldx, const float* W, int n_out, const float* bias, int act, float beta,
-                     float* y, long long ldy, char* pkw, void* linws, void* gws, hipStream_t st) {
+                     float* y, long long ldy, char* pkw, void* linws, void* gws, hipStream_t st, bool prepacked = false) {
     static const bool generic = getenv("ACMIL_TM_GENERIC_GEMM") != nullptr;
     const bool lin_ok = !tm_linear_exact() && !generic && acmil_linear_packed_bytes(n_out, K) != 0 && ((size_t)x & 15) == 0 &&
                         ((size_t)ldx * 4) % 16 == 0 && ldy >= n_out && ((size_t)y & 15) == 0 && ldy % 4 == 0;
     if (lin_ok) {
-        int rc = acmil_linear_pack(W, K, n_out, K, pkw, st);
-        if (rc != ACMIL_OK) return rc;
+        if (!prepacked) {
+            const int rc = acmil_linear_pack(W, K, n_out, K, pkw, st);
+            if (rc != ACMIL_OK) return rc;
+        }
         return lin_f16x3_run(x, ACMIL_DTYPE_F32, M, K, ldx, pkw, n_out, bias, act, beta, y, ldy, linws, st, false);
     }
     TM_LINEAR(0, 1, M, n_out, K, 1.0f, x, (int)ldx, 0, W, ACMIL_DTYPE_F32, K, 0, beta, y, (int)ldy, 0, bias, act, nullptr, 1, gws, st);
@@ -469,7 +473,8 @@ static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) 
 }
 
 // one TransLayer in place on X [npad][Di] (token i at row pad + i):  X[pad:] += to_out(attention(LayerNorm(X[pad:])))
-static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st) {
+static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st, char* pk_qkv = nullptr,
+                    char* pk_out = nullptr) {
     const int Di = g.Di, m = g.m, d = g.d, npad = g.npad, H = TM_HEADS;
     float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV); float* S1 = (float*)(ws + W.S1);
     float* S3 = (float*)(ws + W.S3); float* OUT = (float*)(ws + W.OUT); float* QL = (float*)(ws + W.QL);
@@ -483,7 +488,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_layernorm_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, LN, g.n, Di, p.norm_w, p.norm_b, g.pad);
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
-    { const int rq = tm_linear(LN, npad, Di, Di, p.qkv_w, 3 * Di, nullptr, 0, 0.0f, QKV, 3 * Di, ws + W.PKW, ws + W.LINWS, gws, st); if (rq != ACMIL_OK) return rq; }
+    { const int rq = tm_linear(LN, npad, Di, Di, p.qkv_w, 3 * Di, nullptr, 0, 0.0f, QKV, 3 * Di, pk_qkv ? pk_qkv : ws + W.PKW, ws + W.LINWS, gws, st, pk_qkv != nullptr); if (rq != ACMIL_OK) return rq; }
     {
         int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
         const int threads = ((Di / 4) * phases + 63) / 64 * 64;
@@ -554,7 +559,8 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
     TM_CHECK_LAUNCH();
     // X[pad:] += OUT[pad:] Wout^T + b   (only the last n rows are kept by the reference)
-    return tm_linear(OUT + (size_t)g.pad * Di, g.n, Di, Di, p.out_w, Di, p.out_b, 0, 1.0f, X + (size_t)g.pad * Di, Di, ws + W.PKW, ws + W.LINWS, gws, st);
+    return tm_linear(OUT + (size_t)g.pad * Di, g.n, Di, Di, p.out_w, Di, p.out_b, 0, 1.0f, X + (size_t)g.pad * Di, Di, pk_out ? pk_out : ws + W.PKW, ws + W.LINWS, gws, st,
+                     pk_out != nullptr);
 }
 
 extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
@@ -578,13 +584,28 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     const size_t tokbytes = (size_t)g.n * Di;
     // control words of the packed Linear launches: zeroed ONCE per forward (every launch leaves its counters at zero again)
     if (hipMemsetAsync(ws + W.LINWS, 0, 32, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
-    // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
-    { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, ws + W.PKW, ws + W.LINWS, gws, st); if (r1 != ACMIL_OK) return r1; }
-    hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
-    TM_CHECK_LAUNCH();
+    // the fragment streams of the five Linear layers in ONE launch (the library keeps no state between calls: packed per forward)
+    char* pk1 = nullptr; char* pkq[2] = {nullptr, nullptr}; char* pko[2] = {nullptr, nullptr};
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};
     TmLayerW l2 = {layer2[0], layer2[1], layer2[2], layer2[3], layer2[4], layer2[5]};
-    int rc = tm_layer(g, W, ws, XA, l1, st); if (rc != ACMIL_OK) return rc;
+    {
+        static const bool generic = getenv("ACMIL_TM_GENERIC_GEMM") != nullptr;
+        if (!tm_linear_exact() && !generic && acmil_linear_packed_bytes(Di, D) && acmil_linear_packed_bytes(3 * Di, Di) && acmil_linear_packed_bytes(Di, Di)) {
+            const size_t pk = tm_al((size_t)Di * D * 4), q = tm_al((size_t)3 * Di * Di * 4), o = tm_al((size_t)Di * Di * 4);
+            char* base = ws + W.PKW;
+            pk1 = base; pkq[0] = base + pk; pko[0] = pkq[0] + q; pkq[1] = pko[0] + o; pko[1] = pkq[1] + q;
+            const float* Wp[5] = {fc1_w, l1.qkv_w, l1.out_w, l2.qkv_w, l2.out_w};
+            const int ldw[5] = {D, Di, Di, Di, Di}, no[5] = {Di, 3 * Di, Di, 3 * Di, Di}, Kk[5] = {D, Di, Di, Di, Di};
+            void* outp[5] = {pk1, pkq[0], pko[0], pkq[1], pko[1]};
+            const int rp = lin_pack_multi(Wp, ldw, no, Kk, outp, 5, st);
+            if (rp != ACMIL_OK) return rp;
+        }
+    }
+    // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
+    { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, pk1 ? pk1 : ws + W.PKW, ws + W.LINWS, gws, st, pk1 != nullptr); if (r1 != ACMIL_OK) return r1; }
+    hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
+    TM_CHECK_LAUNCH();
+    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0]); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
     // PPEG: cls passthrough + combined depth-wise 7x7
     hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
@@ -596,7 +617,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     TM_CHECK_LAUNCH();
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
-    rc = tm_layer(g, W, ws, XB, l2, st); if (rc != ACMIL_OK) return rc;
+    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1]); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
     // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
     if (Di > 1024) return ACMIL_ERR_UNSUPPORTED;
