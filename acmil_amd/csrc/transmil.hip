@@ -126,6 +126,52 @@ __global__ __launch_bounds__(256) void tm_softmax_short_kernel(float* __restrict
     for (int i = 0; i < VPL; ++i) { const int c = lane + 64 * i; if (c < cols) p[c] = v[i] * inv; }
 }
 
+// sim2 = softmax_j(scale q_l k_l^T) [H][m][m] in one launch: one wave per (head, row); lane j + 64 c forms its dot product over the
+// d features with plain fp32 FMAs (K = d = 48 at cfg4: 144 FMAs per lane), then the row softmax as tm_softmax_short_kernel.  Was a
+// batched GEMM launch (14.5 us of launch latency for 28 MFLOP) + a softmax launch.
+template <int VPL>
+__global__ __launch_bounds__(256) void tm_sim2_softmax_kernel(const float* __restrict__ QL, const float* __restrict__ KL, float* __restrict__ S2,
+                                                             int m, int d, float scale) {
+    __shared__ float qs[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r = (long long)blockIdx.x * 4 + wave;      // row index over [H][m]
+    const int h = (int)(r / m);
+    const bool live = r < (long long)TM_HEADS * m;
+    const float* q = QL + (size_t)(live ? r : 0) * d;
+    for (int k = lane; k < d; k += 64) qs[wave][k] = q[k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (!live) return;
+    const float* Kh = KL + (size_t)h * m * d;
+    float v[VPL], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int j = lane + 64 * c;
+        float acc = 0.0f;
+        if (j < m) {
+            const f32x4* kr = (const f32x4*)(Kh + (size_t)j * d);
+            for (int k4 = 0; k4 < d / 4; ++k4) {
+                const f32x4 kv = kr[k4];
+                acc = fmaf(qs[wave][4 * k4], kv[0], acc); acc = fmaf(qs[wave][4 * k4 + 1], kv[1], acc);
+                acc = fmaf(qs[wave][4 * k4 + 2], kv[2], acc); acc = fmaf(qs[wave][4 * k4 + 3], kv[3], acc);
+            }
+        }
+        v[c] = j < m ? acc * scale : -INFINITY;
+        mx = fmaxf(mx, v[c]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) { v[c] = (lane + 64 * c < m) ? __expf(v[c] - mx) : 0.0f; sum += v[c]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    float* out = S2 + (size_t)r * m;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) { const int j = lane + 64 * c; if (j < m) out[j] = v[c] * inv; }
+}
+
 // in-place softmax over long rows (one workgroup of 1024 threads per row; 3 passes, the row stays in L2)
 __global__ __launch_bounds__(1024) void tm_softmax_long_kernel(float* __restrict__ x, int cols) {
     __shared__ float red[16];
@@ -506,8 +552,17 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     rc = tm_softmax_short(S1, (long long)H * npad, m, st); if (rc != ACMIL_OK) return rc;
     }
     // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration
-    TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
-    rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
+    if (d % 4 == 0 && d <= 128 && m <= 512) {
+        const unsigned blocks = (unsigned)(((long long)H * m + 3) / 4);
+        if (m <= 64) hipLaunchKernelGGL(tm_sim2_softmax_kernel<1>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
+        else if (m <= 128) hipLaunchKernelGGL(tm_sim2_softmax_kernel<2>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
+        else if (m <= 256) hipLaunchKernelGGL(tm_sim2_softmax_kernel<4>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
+        else hipLaunchKernelGGL(tm_sim2_softmax_kernel<8>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
+        TM_CHECK_LAUNCH();
+    } else {
+        TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
+        rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
+    }
     hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
     TM_CHECK_LAUNCH();
     float* zc = Z; float* zn = T2;     // ping-pong z
