@@ -185,16 +185,21 @@ class GradBucket:
         self.flat.zero_()
 
     def sync_from_grads(self):
-        """Re-point after an autograd pass that replaced .grad tensors."""
+        """Re-point after an autograd pass that replaced .grad tensors.  (The fused step writes into the bucket views: then this is
+        one pointer comparison per parameter -- building a view per parameter and step cost ~90 us of host time.)"""
+        base = self.flat.data_ptr()
         off = 0
         for p in self.params:
-            view = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
-            off += p.numel()
+            n = p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                view = self.flat[off:off + n].view_as(p)
+                if g is None:
+                    view.zero_()
+                else:
+                    view.copy_(g)
+                p.grad = view
+            off += n
 
     def allreduce_mean(self, world: int):
         if world > 1:
