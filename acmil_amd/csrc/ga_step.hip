@@ -97,7 +97,8 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
         for (int w = 1; w < GA_MERGE_GROUPS; ++w) M = fmaxf(M, smx[w]);
         float acc = 0.0f, l = 0.0f;
         const int di = 64 * c + lane;
-        // (8 tiles per wave group and iteration in flight: at 391 tiles the 4-tile version was 7 dependent round trips, ~14 us)
+        // (8 tiles per wave group and iteration in flight: at 391 tiles the 4-tile version was 7 dependent round trips, ~14 us;
+        // 16 in flight measured the same)
         constexpr int MU = 8;
         for (int t0 = g; t0 < tiles; t0 += MU * GA_MERGE_GROUPS) {
             float pm[MU], pl[MU], pa[MU];
@@ -157,10 +158,20 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     float* S = dslide + ACMIL_MAX_CLASSES;         // [KP*KP] Gram of the softmax rows
     float* sc = S + 64;                            // scalars: [0..K) per-branch CE, [8] bag CE, [16 + 2k] M_k, [17 + 2k] L_k, [32] label
     float* ckp = sc + 64;                          // [16 waves][KP + 3] partial c_k
+    float* wcl = ckp + 16 * 16;                    // [K*C][Di] branch-head weights, then [C][Di] bag-head weights: loaded ONCE with the
+    float* wsl = wcl + (size_t)K * C * Di;         // first batch (the heads and their gradients both read them: were 2 x 3 round trips)
     const float invK = 1.0f / (float)K;
     const bool train = a.label != nullptr;
     if (tid == 0 && a.guard_flag) *a.guard_flag = (a.status && __builtin_nontemporal_load(a.status) != 0u) ? 1.0f : 0.0f;
     for (int e = tid; e < K * Di; e += 1024) af[e] = __hip_atomic_load(afeat_b + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: written sc1 by other CUs
+    {
+        const f32x4* wsrc = (const f32x4*)(a.packed + a.L.wc_off);
+        for (int e = tid; e < K * C * Di / 4; e += 1024) ((f32x4*)wcl)[e] = wsrc[e];
+        if (a.has_bag_head) {
+            const f32x4* ssrc = (const f32x4*)(a.packed + a.L.ws_off);
+            for (int e = tid; e < C * Di / 4; e += 1024) ((f32x4*)wsl)[e] = ssrc[e];
+        }
+    }
     if (train) {
         if (tid < 2 * K) sc[16 + tid] = __hip_atomic_load(a.stats + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 2 * K) sc[32] = (float)(int)a.label[0];
@@ -215,9 +226,9 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     __syncthreads();
     // heads (ga_heads_kernel's arithmetic): one wave per output, lanes stride the Di-long dot product
     {
-        const float* wc = (const float*)(a.packed + a.L.wc_off);
+        const float* wc = wcl;
         const float* bc = (const float*)(a.packed + a.L.bc_off);
-        const float* ws = (const float*)(a.packed + a.L.ws_off);
+        const float* ws = wsl;
         const float* bs = (const float*)(a.packed + a.L.bs_off);
         const int nout = K * C + (a.has_bag_head ? C : 0);
         for (int o = g; o < nout; o += 16) {
@@ -284,8 +295,8 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     // head gradients, d_afeat and c_k = d_afeat_k . afeat_k   (ga_bwd_heads_kernel's arithmetic); all branches in one sweep:
     // element e = kk * Di + di, partial c_k per wave through LDS, ONE barrier
     {
-        const float* wc = (const float*)(a.packed + a.L.wc_off);
-        const float* ws = (const float*)(a.packed + a.L.ws_off);
+        const float* wc = wcl;
+        const float* ws = wsl;
         float cp[KP];
 #pragma unroll
         for (int kk = 0; kk < KP; ++kk) cp[kk] = 0.0f;
@@ -335,12 +346,13 @@ __global__ __launch_bounds__(1024) void ga_tail_kernel(GaTailArgs a) {
     }
 }
 
-static size_t gs_tail_lds(int K, int Di) {
-    return ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64 + 16 * 16) * sizeof(float);
+static size_t gs_tail_lds(int K, int Di, int C) {
+    return ((size_t)K * Di + Di + 2 * (GS_MAXK * ACMIL_MAX_CLASSES + ACMIL_MAX_CLASSES) + 64 + 64 + 16 * 16 + (size_t)(K + 1) * C * Di) * sizeof(float);
 }
 
 static int gs_tail_launch(const GaTailArgs& t, int nbags, hipStream_t st) {
-    const size_t lds = gs_tail_lds(t.K, t.Di);
+    const size_t lds = gs_tail_lds(t.K, t.Di, t.C);
+    if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
     void (*tail)(GaTailArgs) = t.KP == 1 ? ga_tail_kernel<1> : t.KP == 5 ? ga_tail_kernel<5> : nullptr;
     if (!tail) return ACMIL_ERR_UNSUPPORTED;
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
