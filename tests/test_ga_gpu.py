@@ -384,3 +384,27 @@ def test_train_step_without_injected_uniforms_draws_on_the_device():
     top = torch.from_numpy(case["topk_idx"]).cuda()
     for b in range(k):
         assert set(out2["masked_idx"][b].tolist()) <= set(top[b].tolist())
+
+
+@pytest.mark.parametrize("xdtype", [torch.bfloat16, torch.float16])
+def test_d128_family_on_16bit_bags_three_workgroups_per_cu(xdtype):
+    """D_inner = 128 on 16-bit bags runs THREE 4-wave workgroups per CU with a pooling image that holds the hi and the lo planes one
+    after the other (ga_forward_kernel_v2.h, Ga2Tri): ragged bag sizes around the tile / wave boundaries, one launch of all of them and
+    single launches, against the oracle on the same (rounded) values; single == batched bit for bit."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    D, Di, K, C = 384, 128, 5, 2
+    sd = O.default_state_dict(D, Di, C, K)
+    model = _build(sd, K, C, D, Di, "f16x3").eval()
+    packed, dims = model._packed()
+    ns = [1, 31, 32, 33, 127, 128, 129, 300, 4097, 20000]
+    xs = [O.synthetic_bag(n, D, 700 + i)[0].to(xdtype).cuda() for i, n in enumerate(ns)]
+    out = ops.ga_forward_batch(xs, packed, dims, "f16x3", want_bag_feat=True)
+    for i, x in enumerate(xs):
+        ref = O.acmil_ga_forward(x.float().cpu().unsqueeze(0), sd, n_token=K)
+        assert (out["A_out"][i].cpu() - ref["A_out"][0]).abs().max() < TOL
+        assert (out["sub_preds"][i].cpu() - ref["sub_preds"]).abs().max() < TOL
+        assert (out["slide_pred"][i].cpu() - ref["slide_pred"][0]).abs().max() < TOL
+        assert (out["bag_feat"][i].cpu() - ref["bag_feat"][0]).abs().max() < TOL
+        single = ops.ga_forward(x, packed, dims, "f16x3")
+        assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
