@@ -188,3 +188,29 @@ def test_data_parallel_step_through_bucket_and_make_optimizer_matches_single_pro
         a, b = torch.load(o2, weights_only=False), torch.load(o1, weights_only=False)
     for pa, pb in zip(a, b):
         assert torch.allclose(pa, pb, atol=1e-6, rtol=1e-6)
+
+
+def test_grad_bucket_sync_repoints_only_what_autograd_replaced():
+    """GradBucket.sync_from_grads: gradients that still are the bucket's views are left alone (one pointer comparison each -- the
+    fused step writes into them); a .grad an autograd pass replaced is copied into the bucket and re-pointed; a missing one is zeroed."""
+    from acmil_amd import train as T
+    torch.manual_seed(0)
+    lin1, lin2 = torch.nn.Linear(6, 4), torch.nn.Linear(4, 3)
+    params = list(lin1.parameters()) + list(lin2.parameters())
+    bucket = T.GradBucket(params)
+    views = [p.grad for p in params]
+    bucket.flat[:bucket.numel].copy_(torch.arange(bucket.numel, dtype=torch.float32))
+    before = bucket.flat.clone()
+    bucket.sync_from_grads()
+    assert all(p.grad is v for p, v in zip(params, views)) and torch.equal(bucket.flat, before)       # nothing to do: nothing touched
+    params[1].grad = torch.full_like(params[1], 7.0)          # what autograd does: a fresh tensor
+    params[2].grad = None
+    bucket.sync_from_grads()
+    off = [0]
+    for p in params:
+        off.append(off[-1] + p.numel())
+    assert all(p.grad.data_ptr() == bucket.flat.data_ptr() + 4 * o for p, o in zip(params, off))
+    assert torch.equal(bucket.flat[off[1]:off[2]], torch.full((params[1].numel(),), 7.0))
+    assert torch.equal(bucket.flat[off[2]:off[3]], torch.zeros(params[2].numel()))
+    assert torch.equal(bucket.flat[off[0]:off[1]], before[off[0]:off[1]]) and torch.equal(bucket.flat[off[3]:off[4]], before[off[3]:off[4]])
+    assert params[0].grad is views[0] and params[3].grad is views[3]
