@@ -16,6 +16,10 @@
 #pragma once
 #include "ga_forward_kernel_v2.h"
 
+#ifndef LIN_XCD_ORDER
+#define LIN_XCD_ORDER 1
+#endif
+
 struct LinArgs {
     const void* x;          // [M, K] row-major, leading dimension ldx (elements), fp32 / fp16 / bf16
     const char* packed;     // fragment stream: chunk c at c * (K/16) * 2 ND KiB
@@ -62,9 +66,18 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     const size_t rowb = (size_t)a.ldx * G::XE;
 
     struct TileInfo { int m0, rmax, col; const char* xrow0; const char* wreg0; };
+    // draw index -> (row tile, column chunk): the chunks of one row tile read the same rows of x, so they go to workgroups of ONE XCD
+    // (draw d starts on XCD d % 8 for the first gridDim.x draws; each XCD has its own L2): the second and third readers hit
+    // there instead of crossing the fabric again.  Past the last full group of 8 row tiles the order is plain.
+    const int xcd_span = (rtiles / 8) * 8 * a.nchunks;
     auto tile_info = [&](int t) {
         TileInfo ti;
-        const int rt = t / a.nchunks, c = t - rt * a.nchunks;
+        int rt = t / a.nchunks, c = t - rt * a.nchunks;
+        if (LIN_XCD_ORDER && t < xcd_span) {
+            const int xcd = t & 7, q = t >> 3;
+            c = q % a.nchunks;
+            rt = (q / a.nchunks) * 8 + xcd;
+        }
         ti.m0 = rt * G::ROWS + wave * 32;
         const int m0c = ti.m0 < M ? ti.m0 : M - 1;
         ti.rmax = M - 1 - m0c;

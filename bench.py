@@ -38,6 +38,7 @@ N_BAGS = 16      # resident bags (grown to the batch size in main)
 SOURCES_OF = {     # kernel sources whose change invalidates a workload's PMC summary
     "ga": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"),
     "transmil": ("transmil.hip", "transmil_attn.hip", "transmil_pinv.hip", "linear_kernel.h", "linear.hip", "gemm_f32.hip", "gemm_internal.h"),
+    "wide": ("ga_common.h", "linear_kernel.h", "linear.hip", "ga_forward_kernel_v2.h", "ga_train.hip"),
     "train": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h", "ga_step.hip", "ga_train.hip", "ga_bwd_tile.hip", "ga_backward.hip",
               "ga_pack.hip", "wgrad.hip", "optim.hip"),
 }
@@ -47,7 +48,7 @@ def kernel_source_id(workload="ga_eval"):
     """Fingerprint of a workload's kernel sources; tools/pmc_ga.py stamps it into every PMC summary it writes."""
     import hashlib
     h = hashlib.sha1()
-    for f in SOURCES_OF.get(workload, SOURCES_OF["ga"]):
+    for f in SOURCES_OF.get("wide" if workload in ("ga_uni", "ga_gigapath", "ga_clip_l") else workload, SOURCES_OF["ga"]):
         with open(os.path.join(ROOT, "acmil_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -355,19 +356,22 @@ def wide_workload(args):
     torch.cuda.synchronize()
     with torch.no_grad():
         # the projection kernel alone (events on the launch stream), first: it also brings the device to operating clocks
-        w1 = model._packed_w1()
-        hbuf = torch.empty(N, Di, dtype=torch.float32, device=dev)
-        for i in range(5):
-            ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        n_k = 40
-        for i in range(n_k):
-            ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
-        e1.record()
-        torch.cuda.synchronize()
-        t_lin = e0.elapsed_time(e1) * 1e-3 / n_k
+        # (--no-b1: skipped -- the PMC passes of tools/pmc_ga.py want the step's own launches only)
+        t_lin = None
+        if not args.no_b1:
+            w1 = model._packed_w1()
+            hbuf = torch.empty(N, Di, dtype=torch.float32, device=dev)
+            for i in range(5):
+                ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            n_k = 40
+            for i in range(n_k):
+                ops.linear_f16x3(bags[i % nb], w1, Di, relu=True, out=hbuf)
+            e1.record()
+            torch.cuda.synchronize()
+            t_lin = e0.elapsed_time(e1) * 1e-3 / n_k
         dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
     t_slide = dt / args.steps
     nbytes, flops = algorithmic_work(N, D, Di, K, C)
@@ -384,10 +388,13 @@ def wide_workload(args):
                                % (N, D, Di, K, C, nb), "precision": args.precision, "sharding": "independent slides per GPU, no collective"},
         "roofline": {"kernel": "whole composed forward (lin_kernel projection + gated scores + pooling + merge + heads)", "bound": "mfma",
                      "achieved": round(flops / t_slide / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / t_slide / 1e12 / peak, 4),
-                     "traffic": None, "executed_tflops": round(executed / t_slide / 1e12, 1), "executed_frac": round(executed / t_slide / 1e12 / peak, 4),
-                     "projection_kernel": {"us_per_launch": round(t_lin * 1e6, 1), "achieved_tflops": round(g1 / t_lin / 1e12, 1),
-                                           "executed_frac": round((3.0 if args.precision == "f16x3" else 1.0) * g1 / t_lin / 1e12 / peak, 4),
-                                           "hbm_gbs": round((N * D * 4 + N * Di * 4) / t_lin / 1e9, 1)},
+                     # PMC summary of the whole composed forward: tools/pmc_ga.py --workload <name> --whole-step --batch 1
+                     "traffic": pmc_traffic(args.workload, args.precision, 1)[0], "traffic_source": pmc_traffic(args.workload, args.precision, 1)[1],
+                     "executed_tflops": round(executed / t_slide / 1e12, 1), "executed_frac": round(executed / t_slide / 1e12 / peak, 4),
+                     "projection_kernel": None if t_lin is None else {
+                         "us_per_launch": round(t_lin * 1e6, 1), "achieved_tflops": round(g1 / t_lin / 1e12, 1),
+                         "executed_frac": round((3.0 if args.precision == "f16x3" else 1.0) * g1 / t_lin / 1e12 / peak, 4),
+                         "hbm_gbs": round((N * D * 4 + N * Di * 4) / t_lin / 1e9, 1)},
                      "hbm": {"achieved": round((nbytes + 2.0 * N * Di * 4) / t_slide / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                              "frac": round((nbytes + 2.0 * N * Di * 4) / t_slide / 1e9 / 8000.0, 4),
                              "note": "algorithmic bytes + the h [N, D_inner] round trip of the composed path"},

@@ -22,6 +22,7 @@ python tools/pmc_ga.py --batch 1 --steps 100 --out $OUT/pmc > $OUT/pmc_ga_eval_b
 python tools/pmc_ga.py --precision fp32 --batch 16 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_fp32.log 2>&1
 python tools/pmc_ga.py --workload ga_cfg3 --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_cfg3.log 2>&1
 python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
+for w in ga_uni ga_gigapath ga_clip_l; do python tools/pmc_ga.py --workload $w --batch 1 --whole-step --steps 30 --out $OUT/pmc > $OUT/pmc_$w.log 2>&1; done
 python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
 python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --extra "--train-n 50000" --out $OUT/pmc > $OUT/pmc_train50k.log 2>&1
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
