@@ -267,10 +267,7 @@ __global__ void tm_pinv_init_kernel(const float* __restrict__ x, int m, const un
 }
 
 // out[i][h*d+dd] += sum_t w[h][t] * v[i + t - 16][h*d+dd]   (v = third column block of QKV, zero outside [0, npad))
-#ifndef TM_CONV_ROWS
-#define TM_CONV_ROWS 48                  // rows per workgroup; whole forward at N = 100 000, same box: 32 rows 2.865 ms, 48: 2.851, 64: 2.863,
-                                         // 128: 2.87 (+0.03 over 64 on its box), 256: 3.01 -- parallelism beats the smaller halo re-read
-#endif
+#define TM_CONV_ROWS 64
 __global__ __launch_bounds__(256) void tm_seqconv_kernel(const float* __restrict__ qkv, float* __restrict__ out, int npad, int Di,
                                                         const float* __restrict__ w) {
     __shared__ __attribute__((aligned(16))) float tile[(TM_CONV_ROWS + TM_RES - 1) * 64];
@@ -293,11 +290,10 @@ __global__ __launch_bounds__(256) void tm_seqconv_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < TM_RES; ++t) wr[t] = wh[t];
     // register blocking: 4 consecutive rows per pass share a 36-value window (36 instead of 132 LDS reads per 132 FMAs);
-    // wave rg takes rows RPWV rg .. RPWV rg + RPWV - 1
-    constexpr int RPWV = TM_CONV_ROWS / 4;
+    // wave rg takes rows 16 rg .. 16 rg + 15
 #pragma unroll 1
-    for (int blk = 0; blk < RPWV / 4; ++blk) {
-        const int rr0 = RPWV * rg + 4 * blk;
+    for (int blk = 0; blk < TM_CONV_ROWS / 16; ++blk) {
+        const int rr0 = 16 * rg + 4 * blk;
         if (r0 + rr0 >= npad) break;
         float in[TM_RES + 3];
 #pragma unroll
