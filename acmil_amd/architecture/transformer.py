@@ -256,8 +256,11 @@ class _GatedBase(nn.Module):
             if status is not None:
                 bad = int(status) != 0
             else:
+                # the generic GEMM's ReLU epilogue is fmaxf(v, 0): a NaN pre-activation (bag value >= 65504: hi = inf, lo = -inf) or a
+                # -inf one becomes 0 and max(h) stays finite -- so this route tests the BAG as well, one pass over x
                 hmax = h.max()
-                bad = not bool(torch.isfinite(hmax) & (hmax < 65504.0))
+                xabs = xb.abs().max()
+                bad = not bool(torch.isfinite(hmax) & (hmax < 65504.0) & torch.isfinite(xabs) & (xabs < 65504.0))
             if bad:
                 self._fb_host = getattr(self, "_fb_host", 0) + 1
                 prec = "fp32"

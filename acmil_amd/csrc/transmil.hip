@@ -654,7 +654,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
                                       float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2, void* workspace,
                                       void* stream) {
     if (N <= 0 || D <= 0 || Di <= 0 || C <= 0) return ACMIL_ERR_SHAPE;
-    if (Di % 16 != 0 || Di / 2 > 1024) return ACMIL_ERR_UNSUPPORTED;
+    if (Di % 16 != 0 || Di / 2 > 1024 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;      // (Di <= 1024: tm_cls_head_kernel's row buffer)
     if (!x || !fc1_w || !fc1_b || !cls_token || !layer1 || !layer2 || !ppeg || !norm_w || !norm_b || !fc2_w || !fc2_b || !logits || !workspace)
         return ACMIL_ERR_NULL;
     for (int i = 0; i < 6; ++i) if (!layer1[i] || !layer2[i] || !ppeg[i]) return ACMIL_ERR_NULL;
@@ -704,7 +704,6 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1]); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
     // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
-    if (Di > 1024) return ACMIL_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);
     TM_CHECK_LAUNCH();
     return ACMIL_OK;

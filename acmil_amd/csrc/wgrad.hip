@@ -219,7 +219,7 @@ __device__ __forceinline__ void wg_body(const WgProb& P, int K, int tile, int sp
 }
 
 template <int TM, int TN>
-__global__ __launch_bounds__((WgGeom<TM, TN>::THREADS), 2) void wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__((WgGeom<TM, TN>::THREADS), (TN == 256 ? 1 : 2)) void wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int pr = (int)blockIdx.x >= a.blocks0 ? 1 : 0;
     const WgProb& P = a.p[pr];

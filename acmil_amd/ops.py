@@ -163,7 +163,7 @@ def ga_forward(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, want_s
 
 def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaDims, mode, want_scores: bool = True,
                      want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, object]:
-    """acmil_ga_forward_batch: up to 16 bags [N_b, D] (same dtype) in one fused launch.
+    """acmil_ga_forward_batch: up to 64 bags (ACMIL_MAX_BATCH) [N_b, D] (same dtype) in one fused launch.
     Returns dict(A_out=list of [K,N_b], sub_preds [B,K,C], slide_pred [B,C], ...)."""
     lib = _lib.load()
     mode = mode_id(mode)
@@ -196,7 +196,7 @@ def ga_forward_batch(xs: Sequence[torch.Tensor], packed: torch.Tensor, dims: GaD
 def ga_forward_guarded(xs: Sequence[torch.Tensor], packed: torch.Tensor, packed_fp32: torch.Tensor, dims: GaDims,
                        fallback_count: Optional[torch.Tensor] = None, want_scores: bool = True, want_preds: bool = True,
                        want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, object]:
-    """acmil_ga_forward_guarded: the split-f16 fused forward of up to 16 bags followed, on the device, by its exact-fp32 repeat
+    """acmil_ga_forward_guarded: the split-f16 fused forward of up to 64 bags followed, on the device, by its exact-fp32 repeat
     if (and only if) a bag left the f16 range -- no host read-back, the outputs are the fp32-parity result either way.
     Same returns as ga_forward_batch; fallback_count: device int32 [1] the library increments when the repeat ran."""
     lib = _lib.load()
@@ -365,7 +365,11 @@ def ga_backward(x: torch.Tensor, h: torch.Tensor, A_out: torch.Tensor, afeat: to
     return grads
 
 
-_TRAIN_STEP_CHECKED: Dict[str, object] = {}
+# validated (parameter, gradient) sets of ga_train_step: key -> the tensors themselves.  The strong references are the point: while an
+# entry lives its tensors cannot be freed, so neither their id() nor their storage address can be taken over by a tensor of another
+# dtype / shape (the kernels get raw pointers); `p.data = ...` / `set_` change data_ptr and miss the cache.  A few models per process.
+_TRAIN_STEP_CHECKED: Dict[tuple, tuple] = {}
+_TRAIN_STEP_CHECKED_MAX = 8
 
 
 def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
@@ -386,8 +390,8 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
     # the same parameter / gradient tensors every step
     pp = [p.data_ptr() for p in params]
     gp = [g.data_ptr() for g in grads]
-    seen = (dev, tuple(pp), tuple(gp))
-    if _TRAIN_STEP_CHECKED.get("key") != seen:
+    seen = (dev, tuple(map(id, params)), tuple(pp), tuple(map(id, grads)), tuple(gp))
+    if seen not in _TRAIN_STEP_CHECKED:
         _need_cuda(*params, *grads)
         n_par = 7 + 2 * K + (2 if dims.has_bag_head else 0)
         if len(params) != n_par or len(grads) != n_par:
@@ -396,7 +400,9 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous() or g.shape != p.shape \
                     or p.device != dev or g.device != dev:
                 raise RuntimeError("acmil_amd.ga_train_step: parameters and gradients must be contiguous fp32 on the bag's device, same shapes")
-        _TRAIN_STEP_CHECKED["key"] = seen
+        if len(_TRAIN_STEP_CHECKED) >= _TRAIN_STEP_CHECKED_MAX:
+            _TRAIN_STEP_CHECKED.pop(next(iter(_TRAIN_STEP_CHECKED)))        # oldest entry (insertion order)
+        _TRAIN_STEP_CHECKED[seen] = (tuple(params), tuple(grads))
     _need_cuda(label, guard_flag)
     if label.device != dev or label.numel() < 1:
         raise RuntimeError("acmil_amd.ga_train_step: label must be a [1] tensor on the bag's device")

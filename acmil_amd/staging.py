@@ -41,17 +41,18 @@ class BagPrefetcher:
     one-slide-per-step loop needs; `.clone()` it to keep it longer.
     """
 
-    def __init__(self, dataset, order: Sequence[int], device: torch.device, depth: int = 3):
+    def __init__(self, dataset, order: Sequence[int], device: torch.device, depth: int = 3, max_bytes: Optional[int] = None):
         self.dataset, self.order, self.device = dataset, list(order), torch.device(device)
         self.depth = max(2, depth)
+        self.max_bytes = max_bytes            # budget for the device memory of ALL ring slots (None: `depth` slots whatever their size)
+        self.alloc_bytes = 0                  # device bytes the ring holds now
+        self.slots_made = 0
         self.cuda = self.device.type == "cuda"
         self._ready: "queue.Queue" = queue.Queue()
         self._free: "queue.Queue" = queue.Queue()
         self._stop = False
         if self.cuda:
-            self.copy_stream = torch.cuda.Stream(device=self.device)
-            for _ in range(self.depth):
-                self._free.put(_Slot())
+            self.copy_stream = torch.cuda.Stream(device=self.device)      # slots are created by the reader as bags need them (_take_slot)
         else:
             for _ in range(self.depth):
                 self._free.put(None)
@@ -65,6 +66,22 @@ class BagPrefetcher:
         self._stop = True
         self._free.put(None)
 
+    def _take_slot(self, need: int):
+        """A ring slot for a bag of `need` bytes (copy thread).  Free slots are reused first; a new slot is made while fewer than
+        `depth` exist and the ring stays inside `max_bytes` (the first two are unconditional: one computing, one filling); otherwise
+        wait for a slot to come back -- after telling the consumer (a "flush" marker) so that a group it is still filling is launched
+        with what it holds instead of waiting for bags that cannot be staged."""
+        try:
+            return self._free.get_nowait()
+        except queue.Empty:
+            pass
+        grown = int(need * 1.25)
+        if self.slots_made < self.depth and (self.slots_made < 2 or self.max_bytes is None or self.alloc_bytes + grown <= self.max_bytes):
+            self.slots_made += 1
+            return _Slot()
+        self._ready.put(("flush",))
+        return self._free.get()
+
     # ---- copy thread: read the item, wait (on the stream) for a free slot, issue the H2D on the copy stream
     def _reader(self):
         try:
@@ -72,19 +89,25 @@ class BagPrefetcher:
                 torch.cuda.set_device(self.device)
             for i in self.order:
                 item = self.dataset[i]                       # disk / decompression latency off the critical path
-                slot = self._free.get()                      # back-pressure: at most `depth` bags in flight
-                if self._stop:
-                    break
                 x = item["input"]
                 if not self.cuda:
+                    self._free.get()                         # back-pressure: at most `depth` bags in flight
+                    if self._stop:
+                        break
                     self._ready.put((None, x, int(item["label"]), i))
                     continue
                 n = x.numel()
+                slot = self._take_slot(n * x.element_size())  # back-pressure: at most `depth` bags / `max_bytes` of ring in flight
+                if self._stop or slot is None:
+                    break
                 with torch.cuda.stream(self.copy_stream):
                     if slot.consumed is not None:
                         self.copy_stream.wait_event(slot.consumed)   # kernels that read this slot are done
                     if slot.dev is None or slot.dev.numel() < n or slot.dev.dtype != x.dtype:
+                        old = 0 if slot.dev is None else slot.dev.numel() * slot.dev.element_size()
+                        slot.dev = None                      # (the old buffer goes back to the allocator before the new one is taken)
                         slot.dev = torch.empty(int(n * 1.25), dtype=x.dtype, device=self.device)
+                        self.alloc_bytes += slot.dev.numel() * slot.dev.element_size() - old
                         slot.copied = torch.cuda.Event()
                     slot.dev[:n].copy_(x.reshape(-1), non_blocking=True)
                     slot.copied.record(self.copy_stream)
@@ -111,6 +134,8 @@ class BagPrefetcher:
                     return
                 if got[0] == "error":
                     raise got[1]
+                if got[0] == "flush":                        # (only groups care; the previous slot has just been handed back)
+                    continue
                 slot, view, label, i = got
                 if self.cuda:
                     compute.wait_event(slot.copied)
@@ -123,7 +148,8 @@ class BagPrefetcher:
     def iter_groups(self, group: int) -> Iterator[list]:
         """Yield LISTS of up to `group` items (same dicts as __iter__) whose ring slots all stay valid until the next list is
         requested: what a batched launch over several bags needs (acmil_ga_forward_batch).  Needs depth >= 2 * group for the
-        copy of the next group to overlap the compute of this one (staged_groups sizes it)."""
+        copy of the next group to overlap the compute of this one (staged_groups sizes it).  A group is SHORTER than `group` when the
+        ring's byte budget is reached first (large slides): the reader's "flush" marker closes it."""
         compute = torch.cuda.current_stream(self.device) if self.cuda else None
         held: list = []
         done = False
@@ -146,6 +172,10 @@ class BagPrefetcher:
                         break
                     if got[0] == "error":
                         raise got[1]
+                    if got[0] == "flush":                    # the ring is full: launch what is staged (its slots come back after that)
+                        if items:
+                            break
+                        continue
                     slot, view, label, i = got
                     if self.cuda:
                         compute.wait_event(slot.copied)
@@ -161,6 +191,14 @@ def staged(dataset, order: Iterable[int], device, depth: int = 3) -> BagPrefetch
     return BagPrefetcher(dataset, list(order), torch.device(device), depth=depth)
 
 
-def staged_groups(dataset, order: Iterable[int], device, group: int = 16) -> Iterator[list]:
-    """Groups of up to `group` staged bags (for one batched launch each); the ring holds two groups."""
-    return BagPrefetcher(dataset, list(order), torch.device(device), depth=2 * group).iter_groups(group)
+STAGE_RING_BYTES = 16 << 30      # ceiling of the staging ring of a grouped loop (also capped at 1/8 of the device's memory)
+
+
+def staged_groups(dataset, order: Iterable[int], device, group: int = 16, max_bytes: Optional[int] = None) -> Iterator[list]:
+    """Groups of up to `group` staged bags (for one batched launch each).  The ring holds up to two groups, and never more than
+    `max_bytes` of device memory (default: min(16 GiB, 1/8 of the device)): with 2 x 64 slots each grown to the largest bag seen, a
+    set of 100 000 x 512 fp32 slides would otherwise pin 33 GB for staging alone; groups get shorter instead."""
+    device = torch.device(device)
+    if max_bytes is None and device.type == "cuda":
+        max_bytes = min(STAGE_RING_BYTES, torch.cuda.get_device_properties(device).total_memory // 8)
+    return BagPrefetcher(dataset, list(order), device, depth=2 * group, max_bytes=max_bytes).iter_groups(group)

@@ -305,7 +305,7 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     probs, labels, losses, divs = [], [], [], []
     label_dev = torch.arange(conf.n_class, device=device)
     if batched and device.type == "cuda" and hasattr(model, "forward_batch") and getattr(model, "_is_fused", lambda: False)():
-        # GA at the fused widths: up to 16 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times), and
+        # GA at the fused widths: up to EVAL_BATCH = 64 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times), and
         # the split-f16 range word of a batch is looked at only after the NEXT batch has been enqueued, so the GPU never idles
         # on the check; a flagged batch (never seen on real features) is re-read and repeated in fp32 arithmetic.
         n_total = len(order)

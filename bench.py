@@ -87,6 +87,28 @@ def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
     return nbytes, flops
 
 
+def host_cores():
+    """(physical cores, logical CPUs) of this host: distinct (physical id, core id) pairs of /proc/cpuinfo; (None, n) if unreadable."""
+    logical = os.cpu_count() or 1
+    try:
+        seen, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        seen.add((phys, core))
+                    phys = core = None
+        if core is not None:
+            seen.add((phys, core))
+        return (len(seen) or None), logical
+    except OSError:
+        return None, logical
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -175,10 +197,10 @@ def _timed(step, args, world, dev):
     return dt
 
 
-def other_workloads(args):
-    """Secondary bench lines (same JSON contract): the TransMIL eval forward (configs[3]) and the ACMIL training step
-    (configs[4]).  The driver's default invocation never takes this branch."""
-    world, rank, dev = _dist_setup(args)
+def other_workloads(args, ctx):
+    """Bench lines of the TransMIL eval forward (configs[3]) and the ACMIL training step (configs[4]), same JSON contract.
+    Returns the result dict (rank 0 prints it, or nests it under "secondary" of the default line)."""
+    world, rank, dev = ctx
     from acmil_amd import _lib
     _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
     if args.workload == "transmil":
@@ -237,9 +259,7 @@ def other_workloads(args):
             result["cpu_baseline"] = {"value": round(1.0 / el, 3), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
                                       "sample": "1 forward of the same N=100000 bag (%.1f s), torch-CPU oracle" % el}
             result["max_abs_err_vs_oracle"] = err
-        if rank == 0:
-            print(json.dumps(result))
-        return
+        return result
     # ---- training step (configs[4]): one bag per rank per step, fused HIP forward/loss/backward, ONE flat-bucket all-reduce, AdamW
     from acmil_amd import synthetic as S
     from acmil_amd import train as T
@@ -323,8 +343,7 @@ def other_workloads(args):
                                       "sample": "%d forward+backward steps on the same bags (%.1f s), torch-CPU oracle + autograd, no optimizer" % (n, el)}
         except TypeError as e:   # oracle signature drift must not kill the bench line
             result["cpu_baseline"] = {"value": None, "unit": "slides/s", "cores": 0, "kind": "port", "sample": "unavailable: %s" % e}
-    if rank == 0:
-        print(json.dumps(result))
+    return result
 
 
 WIDE_SHAPES = {   # the reference's wider feature extractors (Step3_WSI_classification_ACMIL.py:78-87): no single-kernel family, composed path
@@ -334,10 +353,10 @@ WIDE_SHAPES = {   # the reference's wider feature extractors (Step3_WSI_classifi
 }
 
 
-def wide_workload(args):
+def wide_workload(args, ctx):
     """ACMIL-ga eval forward at the wide D_inner families, one slide per step through the product module (`model(x)`: packed-weight
     projection kernel -> gated scores -> pooling -> merge + heads; h [N, D_inner] makes one HBM round trip).  Same JSON contract."""
-    world, rank, dev = _dist_setup(args)
+    world, rank, dev = ctx
     from acmil_amd import _lib, ops
     from acmil_amd import synthetic as S
     from acmil_amd.architecture.transformer import ACMIL_GA
@@ -414,11 +433,7 @@ def wide_workload(args):
         result["cpu_baseline"] = {"value": round(n / el, 2), "unit": "slides/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "sample": "%d forwards of one N=%d D=%d bag (%.1f s), torch-CPU oracle" % (n, N, D, el)}
         result["max_abs_err_vs_oracle"] = max((got[2].cpu() - ref["A_out"]).abs().max().item(), (got[0].cpu() - ref["sub_preds"]).abs().max().item())
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    return result
 
 
 # GA eval-forward workloads: the BASELINE.json headline and configs[2]
@@ -451,28 +466,81 @@ def main(argv=None):
     ap.add_argument("--train-n", type=int, default=10000, help="patches per bag of the train workload")
     ap.add_argument("--no-b1", action="store_true",
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default workload only: skip the nested `secondary` lines (configs[2], [3], [4])")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check on CPU with gloo: no GPU, no compute, no metric value")
     args = ap.parse_args(argv)
     maybe_self_launch(args, argv)         # --gpus N > 1 and no launcher: re-execute under torch.distributed.run
     if args.dry_run:
         return dry_run(args)
+    ctx = _dist_setup(args)
+    world, rank, dev = ctx
     if args.workload in ("transmil", "train"):
-        return other_workloads(args)
-    if args.workload in WIDE_SHAPES:
-        return wide_workload(args)
+        result = other_workloads(args, ctx)
+    elif args.workload in WIDE_SHAPES:
+        result = wide_workload(args, ctx)
+    else:
+        result = ga_workload(args, ctx)
+        if args.workload == "ga_eval" and not args.no_secondary:
+            result["secondary"] = secondary_lines(args, ctx)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
-    shape = GA_SHAPES[args.workload]
-    N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS = shape["N"], shape["D"], shape["Di"], shape["K"], shape["C"]
-    x_dtype = getattr(torch, shape["xdtype"])
-    s_in = 4 if x_dtype == torch.float32 else 2
-    world, rank, dev = _dist_setup(args)
+
+SECONDARY = (     # (key, argv overrides): the other BASELINE.json configs, measured AFTER the headline's timed region, on the same ranks
+    ("ga_cfg3", dict(workload="ga_cfg3", steps=20, warmup=5)),
+    ("transmil", dict(workload="transmil", steps=30, warmup=5)),
+    ("train_n10k", dict(workload="train", train_n=10000, steps=300, warmup=50)),
+    ("train_n50k", dict(workload="train", train_n=50000, steps=150, warmup=30)),
+)
+
+
+def secondary_lines(args, ctx):
+    """configs[2], [3], [4] on the driver-run line: each entry is the full JSON line `bench.py --workload <w>` would print with the
+    same --gpus (own `value`, `ms_per_step`, `roofline` incl. `traffic`), without the CPU-baseline and latency side legs.  They run
+    after the headline has been measured, so `value` / `ms_per_step` of the line itself are untouched.  At --gpus N > 1 every rank
+    takes part (the training step then includes its gradient all-reduce: `allreduce_us`)."""
+    import copy
+    import gc
+    out = {}
+    for key, over in SECONDARY:
+        a = copy.copy(args)
+        a.no_cpu_baseline = True
+        a.no_b1 = True
+        a.batch = 64
+        a.precision = "f16x3"
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = ga_workload(a, ctx) if a.workload in GA_SHAPES else other_workloads(a, ctx)
+            r["wall_s"] = round(time.perf_counter() - t0, 1)
+        except (Exception, SystemExit) as e:      # a secondary line must never cost the headline
+            r = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[key] = r
+        gc.collect()
+        if ctx[2].type == "cuda":
+            torch.cuda.empty_cache()
+    return out
+
+
+def ga_workload(args, ctx):
+    """The GA eval-forward line (BASELINE.json headline / configs[2]); returns the result dict."""
+    world, rank, dev = ctx
     if world > 1:
         import torch.distributed as dist
 
     from acmil_amd import _lib, ops
     from acmil_amd import synthetic as S
 
+    shape = GA_SHAPES[args.workload]
+    N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS = shape["N"], shape["D"], shape["Di"], shape["K"], shape["C"]
+    x_dtype = getattr(torch, shape["xdtype"])
+    s_in = 4 if x_dtype == torch.float32 else 2
     _lib.check(_lib.load().acmil_check_device(), "acmil_check_device")
     sd_cpu = S.ga_state_dict(D_FEAT, D_INNER, N_CLASS, N_TOKEN, seed=0)
     sd = {k: v.to(dev) for k, v in sd_cpu.items()}
@@ -549,7 +617,7 @@ def main(argv=None):
 
     # ---- the PRODUCT's own eval path (what a user of the drop-in module gets): `model(x)` per slide exactly as the reference's
     # evaluate loop calls it (Step3_WSI_classification_ACMIL.py:253-268; device-side range guard, no host read-back), and
-    # `model.forward_batch` as acmil_amd.train.evaluate drives it (16 bags per launch, range word looked at one batch late)
+    # `model.forward_batch` as acmil_amd.train.evaluate drives it (EVAL_BATCH bags per launch, range word looked at one batch late)
     module_rates = None
     if not args.no_b1 and world == 1:
         from acmil_amd.architecture.transformer import ACMIL_GA
@@ -696,14 +764,12 @@ def main(argv=None):
         result["cpu_baseline"] = {"value": round(cpu_sps, 2), "unit": "slides/s", "cores": cores, "kind": "port",
                                   "sample": "%d forwards of the same N=%d D=%d bags (%.1f s), torch-CPU oracle, best of thread counts %s "
                                             "on a %d-thread host" % (n_cpu, N_PATCH, D_FEAT, el, sorted(probe), all_cores),
+                                  "host_physical_cores": host_cores()[0], "host_logical_cpus": host_cores()[1],
                                   "probe_slides_per_s": {str(k): round(v, 2) for k, v in probe.items()},
                                   "ms_per_slide": round(1e3 / cpu_sps, 2)}
         result["speedup_vs_cpu"] = round(slides_per_s / cpu_sps, 1)
         result["max_abs_err_vs_oracle"] = err
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

@@ -7,7 +7,7 @@
 NOT vendored, not installed, no network).  The repo carries a fork, `architecture/nystrom_attention.py`, with the
 same algorithm for return_attn=False; the harness aliases it (sys.modules) and makes `Tensor.cuda` a no-op
 (transMIL.py:71 hard-codes .cuda()).  Neither shim touches the reference tree.  Fixtures are eval-mode only
-(train mode draws Dropout(0.1) masks) and B=1 (the pinv init couples batch rows through a global max).
+(train mode draws Dropout(0.1) masks); B=1 except one B=2 case (the pinv init couples batch rows through a global max).
 Stored: weights (reference ctor under manual_seed(0)), x, logits and the intermediates after layer1, PPEG, layer2,
 plus one moore_penrose_iter_pinv in/out pair.
 """
@@ -58,6 +58,14 @@ def main():
         np.savez(os.path.join(OUT, "transmil_eval_n%d_d384_c2.npz" % n), weights=np.array("weights_transmil_d384_c2"),
                  x=x.numpy(), logits=logits.numpy(), h1=feats["h1"].numpy(), hp=feats["hp"].numpy(), h2=feats["h2"].numpy())
         print("n=%d logits=%s" % (n, logits.numpy()))
+    # B = 2: the pinv initialisation couples the bags of a batch (global max over batch and heads, nystrom_attention.py:16-18)
+    g = torch.Generator().manual_seed(55)
+    x = torch.randn(2, 200, 384, generator=g)
+    x[1] *= 2.5
+    logits, feats = capture(model, x)
+    np.savez(os.path.join(OUT, "transmil_eval_b2_n200_d384_c2.npz"), weights=np.array("weights_transmil_d384_c2"), x=x.numpy(),
+             logits=logits.numpy(), h2=feats["h2"].numpy())
+    print("B=2 logits=%s" % logits.numpy())
     g = torch.Generator().manual_seed(60)
     a = torch.softmax(torch.randn(1, 8, 64, 64, generator=g), dim=-1)
     np.savez(os.path.join(OUT, "pinv_h8_m64.npz"), x=a.numpy(), z=vendored.moore_penrose_iter_pinv(a, 6).numpy())

@@ -22,6 +22,14 @@ def test_forward_matches_reference(name):
         np.testing.assert_allclose(out[key].numpy(), case[key], rtol=0, atol=2e-6, err_msg=key)
 
 
+def test_batch_forward_matches_reference():
+    """B = 2: the pinv initialisation's maxima run over batch and heads (nystrom_attention.py:16-18); the oracle keeps that coupling."""
+    case, sd = load_golden("transmil_eval_b2_n200_d384_c2")
+    out = TO.transmil_forward(torch.from_numpy(case["x"]), sd)
+    for key in ("h2", "logits"):
+        np.testing.assert_allclose(out[key].numpy(), case[key], rtol=0, atol=2e-6, err_msg=key)
+
+
 def test_pinv_matches_reference():
     z = np.load("tests/golden/pinv_h8_m64.npz")
     out = TO.moore_penrose_iter_pinv(torch.from_numpy(z["x"]), 6)

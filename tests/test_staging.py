@@ -59,3 +59,29 @@ def test_prefetcher_gpu_ring_reuse(depth):
         rf = r.float().to(dev)
         assert torch.allclose(s, rf.sum(), rtol=1e-5, atol=1e-3)
         assert float(m) == float(rf.abs().max()) and torch.allclose(l, rf[-1].sum(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_staged_groups_respect_the_byte_budget():
+    """the grouped eval ring is bounded by BYTES -- groups get shorter, every bag still arrives once, in order, intact."""
+    from acmil_amd.staging import staged_groups
+    sizes = [4000, 100, 12000, 12000, 50, 9000, 12000, 700, 12000, 3000, 12000, 12000, 64, 12000]
+    data = _Bags(sizes, d=128)
+    order = list(range(len(sizes))) * 2
+    dev = torch.device("cuda", 0)
+    budget = int(3.2 * 12000 * 128 * 2 * 1.25)          # about three of the largest bags (with the ring's 25 % head room)
+    pf_groups = staged_groups(data, order, dev, group=8, max_bytes=budget)
+    seen, lens, checks = [], [], []
+    for grp in pf_groups:
+        lens.append(len(grp))
+        for it in grp:
+            seen.append(it["index"])
+            checks.append((it["input"].float().sum(), data[it["index"]]["input"]))
+    torch.cuda.synchronize()
+    assert seen == order
+    assert max(lens) < 8, "the budget, not the group size, must have closed the groups: %s" % lens
+    for s, r in checks:
+        assert torch.allclose(s, r.float().to(dev).sum(), rtol=1e-5, atol=1e-3)
+    # unbounded ring of the same loop: full groups
+    lens2 = [len(g) for g in staged_groups(data, order, dev, group=8, max_bytes=1 << 40)]
+    assert lens2[:3] == [8, 8, 8]

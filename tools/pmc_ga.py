@@ -73,7 +73,7 @@ def main():
     WARM = 20 if args.whole_step else 3      # whole-step workloads: the first steps carry one-off allocations, keep them out of the average
     calib = [os.path.join(ROOT, "build", "exp", "hbm_calib"), "8"]
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", args.workload, "--precision", args.precision, "--batch", str(args.batch),
-             "--steps", str(args.steps), "--warmup", str(WARM), "--no-b1", "--no-cpu-baseline"] + args.extra.split()
+             "--steps", str(args.steps), "--warmup", str(WARM), "--no-b1", "--no-cpu-baseline", "--no-secondary"] + args.extra.split()
     summary = {"command": " ".join(["python", "bench.py"] + bench[2:]), "kernel": "ga_fwd2_kernel / ga_fwd_kernel", "per_launch_avg": {}, "calibration": {}}
     sys.path.insert(0, ROOT)
     import bench as B

@@ -28,10 +28,10 @@ python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --ext
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
 for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
-python bench.py > $OUT/bench_default.json 2>> $OUT/bench_default.log
-python bench.py --batch 16 --no-cpu-baseline > $OUT/bench_b16.json 2>> $OUT/bench_default.log
-python bench.py --batch 1 --no-cpu-baseline > $OUT/bench_b1.json 2>> $OUT/bench_default.log
-python bench.py --precision fp32 --batch 16 --no-cpu-baseline --no-b1 > $OUT/bench_fp32.json 2>> $OUT/bench_default.log
+python bench.py --no-secondary > $OUT/bench_default.json 2>> $OUT/bench_default.log
+python bench.py --batch 16 --no-cpu-baseline --no-secondary > $OUT/bench_b16.json 2>> $OUT/bench_default.log
+python bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/bench_b1.json 2>> $OUT/bench_default.log
+python bench.py --precision fp32 --batch 16 --no-cpu-baseline --no-b1 --no-secondary > $OUT/bench_fp32.json 2>> $OUT/bench_default.log
 python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cfg3.log
 for w in ga_uni ga_gigapath ga_clip_l; do python bench.py --workload $w --steps 50 > $OUT/bench_$w.json 2> $OUT/bench_$w.log; done
 python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
@@ -52,7 +52,7 @@ PY
 }
 best_of3 $OUT/bench_train_n10k.json --workload train > $OUT/bench_train_runs.log
 best_of3 $OUT/bench_train_n50k.json --workload train --train-n 50000 >> $OUT/bench_train_runs.log
-run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
+run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline --no-secondary
 run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
 run_stats bench_ga_uni --workload ga_uni --steps 50 --warmup 5 --no-cpu-baseline
 run_stats bench_ga_gigapath --workload ga_gigapath --steps 50 --warmup 5 --no-cpu-baseline
