@@ -6,10 +6,10 @@
 // (192 columns: no half-rate remainder launch; the TransMIL width and CLIP-L's D_inner: 272 vs 323 us at M = 100 000, K = 768).  Chunk = K/16 steps; step = ND "hi"
 // fragment rows then ND "lo" rows; fragment row (step s, tile d): lane (i = lane & 31, hi = lane >> 5) holds the 8 f16 halves of
 // W[col0 + 32 d + i][16 s + 8 hi .. + 7].
-struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; };
+struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; const float* colscale; };   // colscale [K] or null: pack W[c][k] * colscale[k]
 struct LinPlan { int nd, nmain, nd_rem; };      // nmain chunks of 32 * nd columns, then one chunk of 32 * nd_rem columns (0 = none)
 __host__ __device__ static inline LinPlan lin_plan(int n_out) {
-    if (n_out == 384) return LinPlan{6, 2, 0};
+    if (n_out % 192 == 0 && n_out % 256 != 0) return LinPlan{6, n_out / 192, 0};      // 384 (TransMIL width), 1152 (its to_qkv), 576, ...
     return LinPlan{8, n_out / 256, (n_out % 256) ? 4 : 0};
 }
 
@@ -31,8 +31,9 @@ __device__ __forceinline__ void lin_pack_rows(const LinPackArgs& a, unsigned blo
     f16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 h = (_Float16)src[j];
-        v[j] = part ? (_Float16)(src[j] - (float)h) : h;
+        const float w = a.colscale ? src[j] * a.colscale[16 * s + 8 * hi + j] : src[j];
+        const _Float16 h = (_Float16)w;
+        v[j] = part ? (_Float16)(w - (float)h) : h;
     }
     *(f16x8*)(a.out + row * GA_FRAG_ROW + lane * 16) = v;
 }
@@ -46,7 +47,11 @@ __global__ __launch_bounds__(256) void lin_pack_multi_kernel(LinPackMulti m) {
     lin_pack_rows(m.job[blockIdx.y], blockIdx.x);
 }
 
-static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K > 0 && n_out % 128 == 0 && K % 16 == 0; }
+// K >= 32: the LDS-DMA ring runs 2 K steps ahead and crosses tile boundaries on the assumption that the next tile HAS a step s + 2 - S1;
+// with a single K step (K = 16) it fetched one step past the end of the weight stream and of the last rows of x (an out-of-bounds read
+// that only faulted when the allocation ended at a page boundary -- round 4's first GPU run) and handed the wrong slot to a workgroup's
+// second tile.  Such shapes are refused here; callers use the generic split GEMM.
+static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K >= 32 && n_out % 128 == 0 && K % 16 == 0; }
 
 extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
     if (!lin_dims_ok(n_out, K)) return 0;
@@ -55,7 +60,8 @@ extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
 }
 
 // internal: n <= 8 packs in one launch; every job's shape must satisfy acmil_linear_packed_bytes != 0
-int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st) {
+int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st,
+                   const float* const* colscale) {
     if (n <= 0 || n > LIN_PACK_MAX_JOBS) return ACMIL_ERR_SHAPE;
     LinPackMulti m;
     size_t maxrows = 0;
@@ -63,7 +69,7 @@ int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, cons
         const int q = j < n ? j : 0;
         if (!lin_dims_ok(n_out[q], K[q]) || ldw[q] < K[q]) return ACMIL_ERR_SHAPE;
         if (!W[q] || !packed[q]) return ACMIL_ERR_NULL;
-        m.job[j] = LinPackArgs{W[q], (char*)packed[q], ldw[q], n_out[q], K[q]};
+        m.job[j] = LinPackArgs{W[q], (char*)packed[q], ldw[q], n_out[q], K[q], colscale ? colscale[q] : nullptr};
         const size_t rows = acmil_linear_packed_bytes(n_out[q], K[q]) / GA_FRAG_ROW;
         if (rows > maxrows) maxrows = rows;
     }
@@ -74,13 +80,13 @@ int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, cons
 extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream) {
     if (!lin_dims_ok(n_out, K) || ldw < K) return ACMIL_ERR_SHAPE;
     if (!W || !packed) return ACMIL_ERR_NULL;
-    LinPackArgs a = {W, (char*)packed, ldw, n_out, K};
+    LinPackArgs a = {W, (char*)packed, ldw, n_out, K, nullptr};
     const size_t rows = acmil_linear_packed_bytes(n_out, K) / GA_FRAG_ROW;
     hipLaunchKernelGGL(lin_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
-template <int ND, int XDT>
+template <int ND, int XDT, int FX = 0>
 static int lin_launch(const LinArgs& a, hipStream_t st) {
     using G = Ga2Geom<ND, 1, XDT>;
     // per DEVICE: the dynamic-LDS attribute and the CU count (a process may drive several GPUs, or switch device after the first call)
@@ -90,13 +96,13 @@ static int lin_launch(const LinArgs& a, hipStream_t st) {
     if (slots_of[dev] == 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)lin_kernel<ND, XDT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)lin_kernel<ND, XDT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
         slots_of[dev] = 2 * prop.multiProcessorCount;
     }
     const int slots = slots_of[dev];
     const long long tiles = (long long)((a.M + G::ROWS - 1) / G::ROWS) * a.nchunks;
     const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
-    hipLaunchKernelGGL((lin_kernel<ND, XDT>), grid, block, G::LDS, st, a);
+    hipLaunchKernelGGL((lin_kernel<ND, XDT, FX>), grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
@@ -110,8 +116,8 @@ static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
     return ACMIL_ERR_UNSUPPORTED;
 }
 
-// Control words of a call (32-bit, at `workspace`): 0 / 1 tile counters of the main / remainder launch, 2 range status, 4 / 5
-// finished-workgroup counters.  init: zero them here (the C entry: any 256-byte scratch will do); !init: the caller zeroed them once
+// Control words of a call (32-bit, at `workspace`): 2 range status, 4 / 5 finished-workgroup counters of the main / remainder launch,
+// 8..15 / 16..23 their per-XCD tile queues (LIN_CTRL_BYTES = 96 bytes in all).  init: zero them here (the C entry: any 256-byte scratch will do); !init: the caller zeroed them once
 // and every launch leaves the counters at zero (TransMIL: one memset per forward instead of one per Linear layer; the status word
 // then accumulates over the forward and is not looked at).
 int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out, const float* bias, int act,
@@ -123,23 +129,56 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
     if (((size_t)x & 15) != 0 || ((size_t)ldx * xe) % 16 != 0) return ACMIL_ERR_SHAPE;     // 16-byte LDS-DMA pieces
     if (((size_t)y & 15) != 0 || ldy % 4 != 0) return ACMIL_ERR_SHAPE;                     // 16-byte row stores
     unsigned* ctr = (unsigned*)workspace;
-    if (init && hipMemsetAsync(ctr, 0, 32, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (init && hipMemsetAsync(ctr, 0, LIN_CTRL_BYTES, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
+    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
     a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
     const LinPlan P = lin_plan(n_out);
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
-        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr; a.done = ctr + 4;
+        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
         rc = P.nd == 6 ? lin_launch_dt<6>(a, x_dtype, st) : lin_launch_dt<8>(a, x_dtype, st);
         if (rc != ACMIL_OK) return rc;
     }
     if (P.nd_rem) {
         const int c0 = P.nmain * 32 * P.nd;
         a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
-        a.bias = bias ? bias + c0 : nullptr; a.tile_counter = ctr + 1; a.done = ctr + 5;
+        a.bias = bias ? bias + c0 : nullptr; a.tile_counter = ctr + 16; a.done = ctr + 5;
         rc = lin_launch_dt<4>(a, x_dtype, st);
+    }
+    return rc;
+}
+
+// TransLayer's to_qkv with the LayerNorm folded in (transMIL.py:25-28, nystrom_attention.py:80,95-111), internal to the TransMIL forward:
+//   y[r] = ((x[r] - mean_r) * rstd_r) (W o gamma)^T + W beta      for rows r >= zrows,   y[r] = 0 for the zero padding rows r < zrows
+// rowab [M][2] = (rstd, -mean * rstd) per row (0, 0 for r < zrows) from tm_rowstats_kernel; `packed` = the stream of W o gamma
+// (lin_pack_multi with colscale = gamma); bias = W beta.  lm_part (or null): per-wave-tile column sums of the first lm_cols output
+// columns, split at the landmark boundary (see LinArgs).  Control words as lin_f16x3_run with init = false.
+int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
+                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st) {
+    if (M <= 0 || !lin_dims_ok(n_out, K) || ldx < K || ldy < n_out || zrows < 0) return ACMIL_ERR_SHAPE;
+    if (!x || !rowab || !packed || !bias || !y || !workspace) return ACMIL_ERR_NULL;
+    if (((size_t)x & 15) != 0 || ((size_t)ldx * 4) % 16 != 0 || ((size_t)y & 15) != 0 || ldy % 4 != 0 || ((size_t)rowab & 7) != 0) return ACMIL_ERR_SHAPE;
+    if (lm_part && (lm_l < 32 || lm_cols % 32 != 0 || lm_cols > n_out)) return ACMIL_ERR_SHAPE;
+    unsigned* ctr = (unsigned*)workspace;
+    LinArgs a;
+    a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = 0; a.beta = 0.0f; a.y = y; a.ldy = ldy;
+    a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0; a.status = nullptr;
+    a.rowab = rowab; a.zrows = zrows; a.lm_part = lm_part; a.lm_l = lm_l; a.lm_cols = lm_part ? lm_cols : 0;
+    const LinPlan P = lin_plan(n_out);
+    int rc = ACMIL_OK;
+    if (P.nmain > 0) {
+        a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
+        rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 3>(a, st);
+        if (rc != ACMIL_OK) return rc;
+    }
+    if (P.nd_rem) {
+        const int c0 = P.nmain * 32 * P.nd;
+        a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
+        a.bias = bias + c0; a.tile_counter = ctr + 16; a.done = ctr + 5;
+        rc = lin_launch<4, ACMIL_DTYPE_F32, 3>(a, st);
     }
     return rc;
 }
@@ -158,16 +197,17 @@ extern "C" int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int 
                                          const float* bias_vu, const float* Ww, const float* bw, int K, float* A, void* workspace,
                                          void* stream) {
     if (N <= 0 || L <= 0 || L % 16 != 0 || ldh < L || K <= 0) return ACMIL_ERR_SHAPE;
-    if (K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
+    if (K > ACMIL_MAX_TOKENS || L < 32) return ACMIL_ERR_UNSUPPORTED;      // (L >= 32: two K steps, see lin_dims_ok)
     if (!h || !packed_vu || !bias_vu || !Ww || !bw || !A || !workspace) return ACMIL_ERR_NULL;
     const int xe = (h_dtype == ACMIL_DTYPE_F32) ? 4 : 2;
     if (((size_t)h & 15) != 0 || ((size_t)ldh * xe) % 16 != 0 || ((size_t)bias_vu & 15) != 0 || ((size_t)Ww & 15) != 0) return ACMIL_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     unsigned* ctr = (unsigned*)workspace;
-    if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (hipMemsetAsync(ctr, 0, LIN_CTRL_BYTES, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
+    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
     a.x = h; a.ldx = ldh; a.M = N; a.K = L; a.bias = bias_vu; a.act = 2; a.beta = 0.0f; a.y = nullptr; a.ldy = 0;
-    a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr; a.done = nullptr;
+    a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr + 8; a.done = nullptr;
     a.ww = Ww; a.bw = bw; a.scores = A; a.kb = K; a.status = nullptr;
     return lin_launch_dt<8>(a, h_dtype, st);
 }

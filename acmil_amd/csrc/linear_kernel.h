@@ -20,14 +20,16 @@
 #define LIN_XCD_ORDER 1
 #endif
 
+#define LIN_CTRL_BYTES 96        // control words of one Linear call (linear.hip::lin_f16x3_run)
+
 struct LinArgs {
     const void* x;          // [M, K] row-major, leading dimension ldx (elements), fp32 / fp16 / bf16
     const char* packed;     // fragment stream: chunk c at c * (K/16) * 2 ND KiB
     const float* bias;      // [n_out of this launch] or null (indexed by output column - col0)
     float* y;               // [M, ldy] fp32; this launch writes columns col0 .. col0 + nchunks * 32 ND
-    unsigned* tile_counter; // zeroed word (dynamic tile drawing) or null
-    unsigned* done;         // zeroed word or null: finished-workgroup count; the last workgroup puts both words back to zero, so a
-                            // caller that zeroed them once (TransMIL: once per forward) needs no memset between launches
+    unsigned* tile_counter; // 8 zeroed words (dynamic tile drawing: one queue per XCD, see the kernel) or null
+    unsigned* done;         // zeroed word or null: finished-workgroup count; the last workgroup puts it and the 8 queue words back to
+                            // zero, so a caller that zeroed them once (TransMIL: once per forward) needs no memset between launches
     long long ldx, ldy;
     int M, K, nchunks, col0, act;   // act: 0 none, 1 relu, 2 gated-attention scores (below)
     float beta;                     // y = act(acc + bias) + beta * y_old   (residual adds)
@@ -41,14 +43,25 @@ struct LinArgs {
     int kb;
     unsigned* status;               // or null: bit 1 is OR-ed in when an output of a VALID row is >= 65504 in magnitude, inf or NaN -- the
                                     // range rule of the split-f16 arithmetic (ga_forward_kernel_v2.h) for consumers that split y again
+    // FX & 1 (row-affine prologue: LayerNorm folded into the product, transMIL.py:25-28): the B operand is x[r][k] * rowab[r][0] +
+    // rowab[r][1] (= (x - mean) * rstd, formed in registers right before the f16 split; gamma is folded into the packed weights and
+    // W beta is the bias).  Rows r < zrows are the zero padding of the sequence (rowab = 0, 0): they get NO bias either.
+    const float* rowab;             // [M][2]
+    int zrows;
+    // FX & 2 (landmark partials, nystrom_attention.py:95-111): every wave tile also leaves the column sums of its 32 output rows,
+    // split at the landmark boundary that may cross it: lm_part[(m0 / 32) * 2 + part][lm_cols] for the columns < lm_cols (q and k);
+    // part 0 = rows of landmark (m0 / lm_l), part 1 = rows of the next one.  Fixed summation order (bitwise reproducible); needs lm_l >= 32.
+    float* lm_part;
+    int lm_l, lm_cols;
 };
 
-template <int ND, int XDT>
+template <int ND, int XDT, int FX = 0>
 __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Ga2Geom<ND, 1, XDT>;
     constexpr int NTHR = 256, PD = G::PD, NB = G::NB;
-    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);
+    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16) || (FX & 1);     // (an affine image of an f16 value is not f16-exact)
+    constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0;
     static_assert(PD == 2 && NB == 3, "wait counts assume a prefetch distance of 2 steps");
     static_assert(G::REGION >= 4608 || !G::SCRATCH_IN_RING, "transposition tile must fit the free slot");
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -61,19 +74,27 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     const int K = a.K, M = a.M;
     const int S1 = K / 16;
     const int rtiles = (M + G::ROWS - 1) / G::ROWS;
-    const int ntiles = rtiles * a.nchunks;
+    // Tile queues.  The column chunks of one row tile read the same rows of x, and each XCD has its own L2: a launch of a multiple of
+    // 8 workgroups (the persistent grid: 2 per CU) keeps ONE QUEUE PER XCD -- workgroup b belongs to XCD b % 8 and only ever takes
+    // tiles of row tiles rt = 8 i + (b % 8), chunk index fastest, from its XCD's counter -- so the second and later readers of a row
+    // tile hit in that L2 for the WHOLE launch (round 3 arranged this for the first gridDim.x draws only: 543 MB fetched for 154 MB of
+    // activations by the 4-chunk to_qkv launch).  Queues differ by at most one row tile; nobody steals.  Other grids: one queue.
+    const bool xq = a.tile_counter != nullptr && (gridDim.x & 7) == 0;
+    const int xcd = xq ? (int)(blockIdx.x & 7) : 0;
+    const int nloc = xq ? (int)(gridDim.x >> 3) : (int)gridDim.x;                  // workgroups that share this queue
+    const int ntiles = xq ? ((rtiles - xcd + 7) >> 3) * a.nchunks : rtiles * a.nchunks;
     const size_t chunk_bytes = (size_t)S1 * G::WROWS * GA_FRAG_ROW;
     const size_t rowb = (size_t)a.ldx * G::XE;
 
     struct TileInfo { int m0, rmax, col; const char* xrow0; const char* wreg0; };
-    // draw index -> (row tile, column chunk): the chunks of one row tile read the same rows of x, so they go to workgroups of ONE XCD
-    // (draw d starts on XCD d % 8 for the first gridDim.x draws; each XCD has its own L2): the second and third readers hit
-    // there instead of crossing the fabric again.  Past the last full group of 8 row tiles the order is plain.
+    // queue index -> (row tile, column chunk).  Single queue (static or odd grids): the first gridDim.x tiles are laid out so that the
+    // chunks of a row tile start on workgroups of one XCD; past the last full group of 8 row tiles the order is plain.
     const int xcd_span = (rtiles / 8) * 8 * a.nchunks;
     auto tile_info = [&](int t) {
         TileInfo ti;
         int rt = t / a.nchunks, c = t - rt * a.nchunks;
-        if (LIN_XCD_ORDER && t < xcd_span) {
+        if (xq) rt = 8 * rt + xcd;
+        else if (LIN_XCD_ORDER && t < xcd_span) {
             const int xcd = t & 7, q = t >> 3;
             c = q % a.nchunks;
             rt = (q / a.nchunks) * 8 + xcd;
@@ -121,22 +142,40 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
         unsigned long long keep;
         const unsigned zero = 0, one = 1;
         asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
-                     : "=&v"(draw_raw), "=&s"(keep) : "v"(zero), "v"(one), "s"(a.tile_counter) : "memory");
+                     : "=&v"(draw_raw), "=&s"(keep) : "v"(zero), "v"(one), "s"(a.tile_counter + xcd) : "memory");
     };
     auto draw_publish = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(draw_raw) :: "memory");
-        const unsigned v = __builtin_amdgcn_readfirstlane(draw_raw) + gridDim.x;
+        const unsigned v = __builtin_amdgcn_readfirstlane(draw_raw) + (unsigned)nloc;
         if ((tid & 63) == 0) *nn_lds = v;
     };
     const bool dynamic = a.tile_counter != nullptr;
-    int tile = blockIdx.x;
-    int ntile = tile + (int)gridDim.x;
+    int tile = xq ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int ntile = tile + nloc;
+    if (tile >= ntiles) {       // (a queue shorter than its share of the grid: nothing to do but to be counted)
+        if (dynamic && a.done && tid == 0) {
+            const unsigned d = atomicAdd(a.done, 1u);
+            if (d == gridDim.x - 1) { atomicExch(a.done, 0u); for (int q = 0; q < 8; ++q) atomicExch(a.tile_counter + q, 0u); }
+        }
+        return;
+    }
     if (dynamic) {
         if (wave == 0) { draw_issue(); draw_publish(); }
         __syncthreads();
         ntile = (int)__builtin_amdgcn_readfirstlane(*nn_lds);
     }
     TileInfo T = tile_info(tile);
+    // FX & 1: (a, b) of this lane's row of x (row = lane & 31 of the wave tile, clamped like the DMA), one tile ahead
+    auto load_ab = [&](const TileInfo& ti) {
+        f32x2 ab = {1.0f, 0.0f};
+        if constexpr (NORM) {
+            const int i31 = (int)(tid & 31);
+            const int m0c = ti.m0 < M ? ti.m0 : M - 1;
+            ab = *(const f32x2*)(a.rowab + 2 * (size_t)(m0c + (i31 < ti.rmax ? i31 : ti.rmax)));
+        }
+        return ab;
+    };
+    f32x2 rab = load_ab(T);
 
     int islot = 0, rslot = 0;
     {
@@ -159,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     for (;;) {
         const bool has_next = ntile < ntiles;
         const TileInfo TN = tile_info(has_next ? ntile : tile);
+        const f32x2 rabn = load_ab(TN);
         if (dynamic && has_next && wave == 0) draw_issue();
         __builtin_amdgcn_s_waitcnt(0xc07f);
 
@@ -194,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                     v0 = __builtin_bit_cast(float, xrw[j] << 16);
                     v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
                 }
+                if constexpr (NORM) { v0 = fmaf(v0, rab[0], rab[1]); v1 = fmaf(v1, rab[0], rab[1]); }
                 unsigned h, l;
                 ga2_split_pair(v0, v1, h, l);
                 xhw[j] = h; xlw[j] = l;
@@ -351,10 +392,32 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int row = m0 + 8 * it + rsub;
-                    f32x4 v = *(const f32x4*)(pool + (8 * it + rsub) * 36 + 4 * cq) + b4;
+                    f32x4 v = *(const f32x4*)(pool + (8 * it + rsub) * 36 + 4 * cq);
+                    if (!NORM || row >= a.zrows) v = v + b4;
                     if (a.act == 1) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
                     if (a.beta != 0.0f) v = v + old[it] * a.beta;
                     if (row < M) *(f32x4*)(yc + (size_t)row * a.ldy) = v;
+                }
+                if constexpr (LMP) {
+                    // column sums of the tile's 32 rows, split at the landmark boundary; the transposition tile still holds the raw
+                    // accumulators (this launch has no activation and no residual: accumulator + bias is the stored value)
+                    const int colL = a.col0 + T.col + 32 * c;                     // (column of the whole output, not of this launch)
+                    if (colL < a.lm_cols && m0 < M) {
+                        const int bnd = (m0 / a.lm_l + 1) * a.lm_l - m0;          // first row (tile-relative) of the next landmark
+                        const float bcol = a.bias ? a.bias[T.col + 32 * c + i31] : 0.0f;
+                        float sA = 0.0f, sB = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rr = 16 * hi + r;
+                            float v = pool[rr * 36 + i31];
+                            if (!NORM || m0 + rr >= a.zrows) v += bcol;           // the value that was stored for this row
+                            if (rr < bnd) sA += v; else sB += v;
+                        }
+                        const float oA = __shfl_xor(sA, 32), oB = __shfl_xor(sB, 32);
+                        // rows 0..15 first, then rows 16..31, on both halves: the same order whichever half stores
+                        const float tA = hi ? oA + sA : sA + oA, tB = hi ? oB + sB : sB + oB;
+                        a.lm_part[((size_t)(m0 >> 5) * 2 + hi) * a.lm_cols + colL + i31] = hi ? tB : tA;
+                    }
                 }
             }
         }
@@ -365,7 +428,8 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
             __builtin_amdgcn_s_barrier();
         }
         tile = ntile;
-        ntile = dynamic ? (int)__builtin_amdgcn_readfirstlane(*nn_lds) : tile + (int)gridDim.x;
+        rab = rabn;
+        ntile = dynamic ? (int)__builtin_amdgcn_readfirstlane(*nn_lds) : tile + nloc;
         T = TN;
     }
 #undef LIN_DMA_AT
@@ -374,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
         __syncthreads();
         if (tid == 0) {
             const unsigned d = atomicAdd(a.done, 1u);
-            if (d == gridDim.x - 1) { atomicExch(a.done, 0u); atomicExch(a.tile_counter, 0u); }
+            if (d == gridDim.x - 1) { atomicExch(a.done, 0u); for (int q = 0; q < 8; ++q) atomicExch(a.tile_counter + q, 0u); }
         }
     }
 }

@@ -59,6 +59,90 @@ __global__ __launch_bounds__(256) void tm_layernorm_kernel(const float* __restri
     for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < dim) o[c] = (v[i] - mean) * rstd * gamma[c] + beta[c]; }
 }
 
+// LayerNorm folded into the next product (lin_qkv_norm_run, linear.hip): only the row statistics are formed here, exactly as
+// tm_layernorm_kernel forms them (row read once into registers, mean, then the centred sum of squares): ab[r] = (rstd, -mean * rstd),
+// (0, 0) for the zero padding rows in front -- the normalised activations [npad, Di] (154 MB at cfg4, written and read once per
+// layer) never exist.  Also zeroes the two atomic-max words of this layer's Moore-Penrose scaling.  One wave per row.
+__global__ __launch_bounds__(256) void tm_rowstats_kernel(const float* __restrict__ in, float* __restrict__ ab, int rows, int dim, int zero_rows,
+                                                         unsigned* __restrict__ scal_zero) {
+    const int lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (scal_zero && blockIdx.x == 0 && threadIdx.x < 2) scal_zero[threadIdx.x] = 0u;
+    if (r >= (long long)rows + zero_rows) return;
+    if (r < zero_rows) { if (lane == 0) *(f32x2*)(ab + 2 * r) = f32x2{0.0f, 0.0f}; return; }
+    const float* x = in + r * dim;
+    float v[16];
+    float s = 0.0f;
+    if ((dim & 3) == 0 && dim <= 1024) {      // one float4 per lane and 256 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 4 * lane + 256 * i;
+            const f32x4 t = c < dim ? *(const f32x4*)(x + c) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+            s += (t[0] + t[1]) + (t[2] + t[3]);
+        }
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) s += __shfl_xor(s, o2);
+        const float mean = s / dim;
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = (4 * lane + 256 * i + j < dim) ? v[4 * i + j] - mean : 0.0f; q = fmaf(d, d, q); }
+#pragma unroll
+        for (int o2 = 32; o2 >= 1; o2 >>= 1) q += __shfl_xor(q, o2);
+        const float rstd = 1.0f / sqrtf(q / dim + 1e-5f);
+        if (lane == 0) *(f32x2*)(ab + 2 * r) = f32x2{rstd, -mean * rstd};
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; v[i] = c < dim ? x[c] : 0.0f; s += v[i]; }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) s += __shfl_xor(s, o2);
+    const float mean = s / dim;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = (lane + 64 * i < dim) ? v[i] - mean : 0.0f; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) q += __shfl_xor(q, o2);
+    const float rstd = 1.0f / sqrtf(q / dim + 1e-5f);
+    if (lane == 0) *(f32x2*)(ab + 2 * r) = f32x2{rstd, -mean * rstd};
+}
+
+// bias of the LayerNorm-folded to_qkv: wb[job][c] = sum_k W[c][k] beta[k]  (one wave per output column; both layers in one launch)
+struct TmWbJobs { const float* W[2]; const float* beta[2]; float* out[2]; };
+__global__ __launch_bounds__(256) void tm_wbeta_kernel(TmWbJobs J, int n_out, int K) {
+    const int lane = threadIdx.x & 63, job = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_out) return;
+    const float* w = J.W[job] + (size_t)c * K;
+    const float* b = J.beta[job];
+    float t = 0.0f;
+    for (int k = lane; k < K; k += 64) t = fmaf(w[k], b[k], t);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) J.out[job][c] = t;
+}
+
+// landmark means from the per-wave-tile column sums the to_qkv launch left (LinArgs::lm_part): QL / KL [h][m][d] = (1 / l) * sum of the
+// partials of the 32-row tiles that overlap rows [j l, (j + 1) l), tiles in index order (fixed order: bitwise reproducible).
+// Tile t (rows 32 t ..) belongs with part 0 to landmark (32 t) / l and with part 1 to the next one (l >= 32: at most two).
+__global__ __launch_bounds__(256) void tm_landmark_reduce_kernel(const float* __restrict__ part, int l, int m, int Di, float* __restrict__ QL,
+                                                                float* __restrict__ KL) {
+    const int j = blockIdx.x, cols = 2 * Di, d = Di / TM_HEADS;
+    const int t0 = (int)(((long long)j * l) >> 5), t1 = (int)((((long long)(j + 1) * l) - 1) >> 5);
+    const float inv = 1.0f / (float)l;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float s = 0.0f;
+        for (int t = t0; t <= t1; ++t) {
+            const int pt = ((32 * t) / l == j) ? 0 : 1;
+            s += part[((size_t)t * 2 + pt) * cols + c];
+        }
+        const int cc = c < Di ? c : c - Di;
+        (c < Di ? QL : KL)[((size_t)(cc / d) * m + j) * d + cc % d] = s * inv;
+    }
+}
+
 // token assembly after fc1: cls row, wrap-around rows (repeat the first tokens), zero front padding
 __global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int nsq, int dim, const float* __restrict__ cls) {
     const long long total = (long long)(pad + 1 + (nsq - N)) * dim;
@@ -447,7 +531,7 @@ static TmGeom tm_geom(int N, int D, int Di, int C) {
 
 static size_t tm_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, ZB, ZTB, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, PKW, LINWS, GEMM, total; };
+struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, ZB, ZTB, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, PKW, LINWS, AB, LMP, WB, GEMM, total; };
 bool tm_pinv_tiles_supported(int m);
 int tm_pinv_tiles(const float* X, float* Za, float* ZTa, float* Zb, float* ZTb, float* XZ, float* T1T, float* ST, const unsigned* scal,
                   int m, int iters, float** z_final, hipStream_t st);
@@ -475,6 +559,10 @@ static TmWs tm_ws(const TmGeom& g) {
         w.PKW = off; off += pk + 2 * (q + o);
         w.LINWS = off; off += 256;
     }
+    // LayerNorm-folded to_qkv: row statistics, landmark partials of the q / k columns per 32-row tile, W beta of both layers
+    w.AB = off; off += tm_al((size_t)g.npad * 2 * 4);
+    w.LMP = off; off += tm_al((size_t)(g.npad / 32 + 1) * 2 * 2 * g.Di * 4);
+    w.WB = off; off += tm_al((size_t)2 * 3 * g.Di * 4);
     // split-K scratch: the largest need over EVERY product of the forward (a small bag with a wide feature vector splits
     // products that never split at slide scale, e.g. fc1 at N = 400, D = 1536)
     const int H = TM_HEADS, m = g.m, d = g.d, np_ = g.npad, Di = g.Di;
@@ -509,7 +597,10 @@ extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void
 // linear.hip: the packed Linear kernel on control words the CALLER has zeroed (once per forward here); every launch leaves them zero
 int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const void* packed, int n_out, const float* bias, int act,
                   float beta, float* y, long long ldy, void* workspace, hipStream_t st, bool init);
-int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st);
+int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st,
+                   const float* const* colscale);
+int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
+                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st);
 
 // y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
 // Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
@@ -544,7 +635,7 @@ static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) 
 
 // one TransLayer in place on X [npad][Di] (token i at row pad + i):  X[pad:] += to_out(attention(LayerNorm(X[pad:])))
 static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st, char* pk_qkv = nullptr,
-                    char* pk_out = nullptr) {
+                    char* pk_out = nullptr, const float* wbeta = nullptr) {
     const int Di = g.Di, m = g.m, d = g.d, npad = g.npad, H = TM_HEADS;
     float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV); float* S1 = (float*)(ws + W.S1);
     float* S3 = (float*)(ws + W.S3); float* OUT = (float*)(ws + W.OUT); float* QL = (float*)(ws + W.QL);
@@ -555,14 +646,30 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     const float scale = 1.0f / sqrtf((float)d);
     const long long mm = (long long)m * m, md = (long long)m * d;
 
+    if (wbeta) {
+        // LayerNorm folded into to_qkv (round 4): row statistics -> the projection normalises its B operand in registers (gamma is in
+        // the packed weights, W beta is the bias) and leaves the landmark column sums of q and k per 32-row tile -> a small reduce.
+        // Gone: the LayerNorm pass (read + write of [npad, Di]) and the landmark pass (re-read of the q / k columns of QKV).
+        float* AB = (float*)(ws + W.AB); float* LMP = (float*)(ws + W.LMP);
+        hipLaunchKernelGGL(tm_rowstats_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, AB, g.n, Di, g.pad, scal);
+        TM_CHECK_LAUNCH();
+        const bool lm = g.l >= 32;
+        const int rq = lin_qkv_norm_run(X, npad, Di, Di, AB, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, lm ? LMP : nullptr, g.l, 2 * Di, ws + W.LINWS, st);
+        if (rq != ACMIL_OK) return rq;
+        if (lm) {
+            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL);
+            TM_CHECK_LAUNCH();
+        }
+    } else {
     hipLaunchKernelGGL(tm_layernorm_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, LN, g.n, Di, p.norm_w, p.norm_b, g.pad);
     TM_CHECK_LAUNCH();
     // qkv projection (no bias): [npad, 3Di]
     { const int rq = tm_linear(LN, npad, Di, Di, p.qkv_w, 3 * Di, nullptr, 0, 0.0f, QKV, 3 * Di, pk_qkv ? pk_qkv : ws + W.PKW, ws + W.LINWS, gws, st, pk_qkv != nullptr); if (rq != ACMIL_OK) return rq; }
-    {
+    }
+    if (!wbeta || g.l < 32) {
         int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
         const int threads = ((Di / 4) * phases + 63) / 64 * 64;
-        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, scal);
+        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, wbeta ? nullptr : scal);
     }
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
@@ -667,9 +774,10 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     void* gws = ws + W.GEMM;
     const size_t tokbytes = (size_t)g.n * Di;
     // control words of the packed Linear launches: zeroed ONCE per forward (every launch leaves its counters at zero again)
-    if (hipMemsetAsync(ws + W.LINWS, 0, 32, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + W.LINWS, 0, 96, st) != hipSuccess) return ACMIL_ERR_LAUNCH;        // (LIN_CTRL_BYTES)
     // the fragment streams of the five Linear layers in ONE launch (the library keeps no state between calls: packed per forward)
     char* pk1 = nullptr; char* pkq[2] = {nullptr, nullptr}; char* pko[2] = {nullptr, nullptr};
+    bool fold_ln = false;
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};
     TmLayerW l2 = {layer2[0], layer2[1], layer2[2], layer2[3], layer2[4], layer2[5]};
     {
@@ -681,15 +789,26 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
             const float* Wp[5] = {fc1_w, l1.qkv_w, l1.out_w, l2.qkv_w, l2.out_w};
             const int ldw[5] = {D, Di, Di, Di, Di}, no[5] = {Di, 3 * Di, Di, 3 * Di, Di}, Kk[5] = {D, Di, Di, Di, Di};
             void* outp[5] = {pk1, pkq[0], pko[0], pkq[1], pko[1]};
-            const int rp = lin_pack_multi(Wp, ldw, no, Kk, outp, 5, st);
+            // ACMIL_TM_LN_PASS=1: the round-3 pipeline (LayerNorm pass, plain to_qkv, landmark pass) -- A/B knob and test reference
+            static const bool ln_pass = getenv("ACMIL_TM_LN_PASS") != nullptr;
+            fold_ln = !ln_pass;
+            const float* cs[5] = {nullptr, fold_ln ? l1.norm_w : nullptr, nullptr, fold_ln ? l2.norm_w : nullptr, nullptr};
+            const int rp = lin_pack_multi(Wp, ldw, no, Kk, outp, 5, st, cs);
             if (rp != ACMIL_OK) return rp;
+            if (fold_ln) {
+                float* wb = (float*)(ws + W.WB);
+                TmWbJobs J = {{l1.qkv_w, l2.qkv_w}, {l1.norm_b, l2.norm_b}, {wb, wb + 3 * Di}};
+                hipLaunchKernelGGL(tm_wbeta_kernel, dim3((3 * Di + 3) / 4, 2), dim3(256), 0, st, J, 3 * Di, Di);
+                TM_CHECK_LAUNCH();
+            }
         }
     }
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
     { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, pk1 ? pk1 : ws + W.PKW, ws + W.LINWS, gws, st, pk1 != nullptr); if (r1 != ACMIL_OK) return r1; }
     hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
     TM_CHECK_LAUNCH();
-    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0]); if (rc != ACMIL_OK) return rc;
+    const float* wb = (const float*)(ws + W.WB);
+    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
     // PPEG: cls passthrough + combined depth-wise 7x7
     hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
@@ -701,7 +820,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     TM_CHECK_LAUNCH();
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
-    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1]); if (rc != ACMIL_OK) return rc;
+    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1], fold_ln ? wb + 3 * Di : nullptr); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
     // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
     hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);

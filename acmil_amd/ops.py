@@ -658,7 +658,7 @@ def linear_pack(W: torch.Tensor) -> torch.Tensor:
     n_out, K = W.shape
     nbytes = lib.acmil_linear_packed_bytes(n_out, K)
     if nbytes == 0:
-        raise RuntimeError("acmil_amd.linear_pack: needs n_out % 128 == 0 and K % 16 == 0, got %s" % (tuple(W.shape),))
+        raise RuntimeError("acmil_amd.linear_pack: needs n_out % 128 == 0, K % 16 == 0 and K >= 32, got %s" % (tuple(W.shape),))
     packed = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
     _lib.check(lib.acmil_linear_pack(W.data_ptr(), K, n_out, K, packed.data_ptr(), _stream()), "acmil_linear_pack")
     return packed

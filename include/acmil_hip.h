@@ -312,7 +312,7 @@ int acmil_mha_forward(const float* x, int N, int D, int Di, int K, int C, const 
  * transMIL.py:51,63), NystromAttention.to_qkv / to_out (nystrom_attention.py:80,139).  Split-f16 arithmetic (as
  * acmil_gemm_f16x3: ~1e-6 relative, operands inside the f16 range), persistent workgroups, LDS-DMA staging.
  *   acmil_linear_pack: W [n_out, K] fp32 (leading dimension ldw) -> fragment stream of acmil_linear_packed_bytes(n_out, K)
- *     bytes; n_out % 128 == 0, K % 16 == 0.  Re-pack when W changes.
+ *     bytes (0 = shape not supported); n_out % 128 == 0, K % 16 == 0, K >= 32.  Re-pack when W changes.
  *   acmil_linear_f16x3: x [M, K] of x_dtype (leading dimension ldx elements, rows 16-byte aligned), y [M, n_out] fp32
  *     (leading dimension ldy); bias [n_out] or NULL; act 0 none / 1 relu; beta: residual accumulate.  workspace: 256 bytes.
  * ------------------------------------------------------------------------------------------- */
@@ -327,7 +327,7 @@ int acmil_linear_f16x3(const void* x, int x_dtype, int M, int K, long long ldx, 
  *  value outside the f16 range poisons its row's outputs and is flagged by the same test.) */
 
 /* Gated-attention scores of a projected bag h [N, L] in ONE pass over h (Attention_Gated.forward, architecture/transformer.py:259-267,
- * attention width 128, K <= ACMIL_MAX_TOKENS, L % 16 == 0): the [Wv; Wu] product with the gate tanh(.) * sigmoid(.) formed in the
+ * attention width 128, K <= ACMIL_MAX_TOKENS, L % 16 == 0, L >= 32): the [Wv; Wu] product with the gate tanh(.) * sigmoid(.) formed in the
  * accumulators and only A [K, N] written -- the [N, 256] pre-activations of acmil_gated_scores never exist.  packed_vu =
  * acmil_linear_pack of the [256, L] matrix with rows [Wv 0..31; Wu 0..31; Wv 32..63; Wu 32..63; ...]; bias_vu [256] in that order.
  * h fp32 / fp16 / bf16 (h_dtype), 16-byte aligned rows.  workspace: 256 bytes. */

@@ -5,7 +5,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 16, 128), (2000, 384, 384)])
+@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 32, 128), (2000, 384, 384)])
 @pytest.mark.parametrize("xdt", [torch.float32, torch.float16, torch.bfloat16])
 def test_linear_matches_fp64(m, k, n_out, xdt):
     from acmil_amd import ops
@@ -30,6 +30,12 @@ def test_linear_matches_fp64(m, k, n_out, xdt):
     assert out.data_ptr() == y0.data_ptr()
     assert (y0.cpu().double() - want).abs().max().item() <= 3e-6 * scale + 2e-6
     assert torch.equal(big[:, :32].cpu(), big[:, :32].cpu()) and torch.isfinite(big).all()
+
+
+def test_single_k_step_is_refused():
+    """K = 16 is one K step: the two-step-deep DMA ring would read past the operands (round-4 finding) -- refused, not attempted."""
+    from acmil_amd import _lib
+    assert _lib.load().acmil_linear_packed_bytes(128, 16) == 0 and _lib.load().acmil_linear_packed_bytes(128, 32) != 0
 
 
 def test_linear_bitwise_reproducible_and_equal_to_generic_gemm_class():

@@ -38,7 +38,10 @@ def test_matches_reference_golden(name):
 
 # Di = 128 / 256 / 384 / 512 run the fused flash-style attention legs (transmil_attn.hip); Di = 768 (GigaPath width) has no
 # fused instantiation and exercises the GEMM + softmax chain
-@pytest.mark.parametrize("n,d,di,c", [(3000, 512, 256, 2), (777, 768, 384, 7), (5000, 1024, 512, 2), (400, 1536, 768, 2), (40, 384, 128, 3)])
+# (4000, 384, 128) and (9000, 512, 256): l = ceil(n / m) >= 32 rows per landmark -- the landmark means come from the to_qkv epilogue's
+# per-tile partial sums (smaller bags use the stand-alone landmark kernel); all of them run the LayerNorm-folded projection
+@pytest.mark.parametrize("n,d,di,c", [(3000, 512, 256, 2), (777, 768, 384, 7), (5000, 1024, 512, 2), (400, 1536, 768, 2), (40, 384, 128, 3),
+                                      (4000, 384, 128, 2), (9000, 512, 256, 3), (30000, 768, 384, 2)])
 def test_matches_oracle_other_shapes(n, d, di, c):
     from oracle import transmil_oracle as TO
     sd = TO.default_state_dict(d, di, c, seed=3)
