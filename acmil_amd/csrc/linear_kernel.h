@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                         const float oA = __shfl_xor(sA, 32), oB = __shfl_xor(sB, 32);
                         // rows 0..15 first, then rows 16..31, on both halves: the same order whichever half stores
                         const float tA = hi ? oA + sA : sA + oA, tB = hi ? oB + sB : sB + oB;
-                        a.lm_part[((size_t)(m0 >> 5) * 2 + hi) * a.lm_cols + colL + i31] = hi ? tB : tA;
+                        if (!hi || bnd < 32)     // (part 1 is only read for tiles a landmark boundary crosses)
+                            a.lm_part[((size_t)(m0 >> 5) * 2 + hi) * a.lm_cols + colL + i31] = hi ? tB : tA;
                     }
                 }
             }

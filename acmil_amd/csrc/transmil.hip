@@ -130,17 +130,22 @@ __global__ __launch_bounds__(256) void tm_wbeta_kernel(TmWbJobs J, int n_out, in
 __global__ __launch_bounds__(256) void tm_landmark_reduce_kernel(const float* __restrict__ part, int l, int m, int Di, float* __restrict__ QL,
                                                                 float* __restrict__ KL) {
     const int j = blockIdx.x, cols = 2 * Di, d = Di / TM_HEADS;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= cols) return;
     const int t0 = (int)(((long long)j * l) >> 5), t1 = (int)((((long long)(j + 1) * l) - 1) >> 5);
     const float inv = 1.0f / (float)l;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-        float s = 0.0f;
-        for (int t = t0; t <= t1; ++t) {
-            const int pt = ((32 * t) / l == j) ? 0 : 1;
-            s += part[((size_t)t * 2 + pt) * cols + c];
-        }
-        const int cc = c < Di ? c : c - Di;
-        (c < Di ? QL : KL)[((size_t)(cc / d) * m + j) * d + cc % d] = s * inv;
+    float s = 0.0f;
+    int t = t0;
+    for (; t + 7 <= t1; t += 8) {          // 8 independent loads in flight, added in tile order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(t + u) * 2 + (((32 * (t + u)) / l == j) ? 0 : 1)) * cols + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; t <= t1; ++t) s += part[((size_t)t * 2 + (((32 * t) / l == j) ? 0 : 1)) * cols + c];
+    const int cc = c < Di ? c : c - Di;
+    (c < Di ? QL : KL)[((size_t)(cc / d) * m + j) * d + cc % d] = s * inv;
 }
 
 // token assembly after fc1: cls row, wrap-around rows (repeat the first tokens), zero front padding
@@ -512,7 +517,8 @@ struct TmLayerW { const float *norm_w, *norm_b, *qkv_w, *out_w, *out_b, *res_w; 
 // fused Nystrom attention legs (transmil_attn.hip)
 int tm_attn_fused_supported(int Di);
 size_t tm_attn3_partial_bytes(int npad, int Di);
-int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st);
+int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
+                   const float* convw, int* conv_done);
 int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st);
 
 struct TmGeom {
@@ -657,7 +663,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         const int rq = lin_qkv_norm_run(X, npad, Di, Di, AB, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, lm ? LMP : nullptr, g.l, 2 * Di, ws + W.LINWS, st);
         if (rq != ACMIL_OK) return rq;
         if (lm) {
-            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL);
+            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL);
             TM_CHECK_LAUNCH();
         }
     } else {
@@ -744,11 +750,14 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     } else {
         TM_GEMM(0, 0, m, d, m, 1.0f, zc, m, mm, AV, ACMIL_DTYPE_F32, d, md, 0.0f, W2, d, md, nullptr, 0, nullptr, H, gws, st);
     }
-    if (fused) { rc = tm_attn1_fused(QKV, KL, W2, OUT, npad, Di, scale, st); if (rc != ACMIL_OK) return rc; }
+    int conv_done = 0;
+    if (fused) { rc = tm_attn1_fused(QKV, KL, W2, OUT, npad, Di, scale, st, p.res_w, &conv_done); if (rc != ACMIL_OK) return rc; }
     else TM_GEMM(0, 0, npad, d, m, 1.0f, S1, m, (long long)npad * m, W2, ACMIL_DTYPE_F32, d, md, 0.0f, OUT, Di, d, nullptr, 0, nullptr, H, gws, st);
-    // + depth-wise residual conv of v along the sequence
-    hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
-    TM_CHECK_LAUNCH();
+    // + depth-wise residual conv of v along the sequence (a pass of its own only where the attention leg did not add it)
+    if (!conv_done) {
+        hipLaunchKernelGGL(tm_seqconv_kernel, dim3((Di + 63) / 64, (npad + TM_CONV_ROWS - 1) / TM_CONV_ROWS), dim3(256), 0, st, QKV, OUT, npad, Di, p.res_w);
+        TM_CHECK_LAUNCH();
+    }
     // X[pad:] += OUT[pad:] Wout^T + b   (only the last n rows are kept by the reference)
     return tm_linear(OUT + (size_t)g.pad * Di, g.n, Di, Di, p.out_w, Di, p.out_b, 0, 1.0f, X + (size_t)g.pad * Di, Di, pk_out ? pk_out : ws + W.PKW, ws + W.LINWS, gws, st,
                      pk_out != nullptr);

@@ -267,15 +267,25 @@ __device__ __forceinline__ int tma_perm_index(int lr, int EP, int e) {   // f16 
     return (((e2 * EP + e) * 2 + hi_n) * 8) + j;
 }
 
+// convw != null (round 4): the depth-wise residual convolution of v along the sequence (nystrom_attention.py:135-142; 33 taps per
+// head, zero padding) is added HERE, on the matrix pipe, instead of by a pass of its own over v and OUT (tm_seqconv_kernel: 540 MB of
+// HBM traffic and 125 us per layer at cfg4).  For the 32 output rows n of a block and the 64 input rows n' = 32 rb - 16 .. 32 rb + 47,
+//   conv[e][n] = sum_n' v[n'][e] T[n'][n],   T[n'][n] = w[h][n' - n + 16]  (0 outside 0..32):
+// a banded Toeplitz factor.  A = v^T comes straight from global memory in the MFMA's A layout (lane = feature e, 8 consecutive rows
+// per lane: every load instruction reads 128 contiguous bytes of one row of v), split hi / lo in registers; B = T depends only on
+// (lane, K step): a 8 KB table in LDS built once per workgroup.  4 K steps x ET tiles x 3 split products = 24 MFMAs per block next to
+// the 126 of the attention leg; the accumulators are the leg's own o[et] after their final scaling.
 template <int MT>
 __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict__ QKV, const float* __restrict__ KL,
                                                         const float* __restrict__ W2, float* __restrict__ OUT, int npad, int Di,
-                                                        float scale) {
+                                                        float scale, const float* __restrict__ convw) {
     constexpr int M = 32 * MT, D = 8 * MT, KS = D / 16, ET = (D + 31) / 32, EP = 32 * ET, LD = D + 8;
     constexpr int KLN = M * LD, W2N = MT * 2 * EP * 16;      // f16 elements per plane
     extern __shared__ __attribute__((aligned(16))) char smx[];
     _Float16* KLh = (_Float16*)smx; _Float16* KLl = KLh + KLN;
     _Float16* W2h = KLl + KLN;      _Float16* W2l = W2h + W2N;
+    tma_h8* Tch = (tma_h8*)(W2l + W2N);      // [4 K steps][64 lanes] hi halves of the Toeplitz B operand, then the lo halves
+    tma_h8* Tcl = Tch + 4 * 64;
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y;
@@ -304,10 +314,25 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         const int p = (l >> 5) * 2 * EP * 16 + tma_perm_index(l & 31, EP, e);
         W2h[p] = x; W2l[p] = (_Float16)(v - (float)x);
     }
+    if (convw && tid < 4 * 64) {
+        // B operand of the convolution: K slot (hi, j) of step kp <-> input row 16 kp + 8 hi + j of the 64-row window, column = output row
+        // n = lane & 31: tap = (16 kp + 8 hi + j) - n
+        const int kp = tid >> 6, ln = tid & 63, n = ln & 31, hh = ln >> 5;
+        tma_h8 th, tl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = 16 * kp + 8 * hh + j - n;
+            const float w = (tap >= 0 && tap <= 32) ? convw[h * 33 + tap] : 0.0f;
+            const _Float16 x = (_Float16)w;
+            th[j] = x; tl[j] = (_Float16)(w - (float)x);
+        }
+        Tch[kp * 64 + ln] = th; Tcl[kp * 64 + ln] = tl;
+    }
     __syncthreads();
 
     const int nblk = npad / 32, stride = gridDim.x * 8;
     int rb = blockIdx.x * 8 + wave;
+    const float* vcol = QKV + 2 * Di + h * D;          // v column block of this head
     f32x4 qn[KS][2];
     auto load_q = [&](int b) {
         const float* qp = QKV + (size_t)(b * 32 + i31) * 3 * Di + h * D + 8 * hi;
@@ -376,13 +401,46 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
             __builtin_amdgcn_sched_barrier(0);
         }
         const float inv = inv_s2 / sum;
+#pragma unroll
+        for (int et = 0; et < ET; ++et)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[et][r] *= inv;
+        if (convw) {
+            const int rowb = rb * 32 - 16 + 8 * hi;                // first input row of this lane's K slots, step 0
+            float cur[ET][8], nxt[ET][8];
+            auto load_v = [&](int kp, float (&dst)[ET][8]) {
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = rowb + 16 * kp + j, e = 32 * et + i31;
+                        dst[et][j] = (r >= 0 && r < npad && e < D) ? vcol[(size_t)r * 3 * Di + e] : 0.0f;
+                    }
+            };
+            load_v(0, cur);
+#pragma unroll
+            for (int kp = 0; kp < 4; ++kp) {
+                if (kp < 3) load_v(kp + 1, nxt);
+                const tma_h8 bh = Tch[kp * 64 + lane], bl = Tcl[kp * 64 + lane];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    tma_h8 ah, al;
+                    tma_split8(cur[et], ah, al);
+                    TMA_MFMA3(o[et], ah, al, bh, bl);
+                }
+#pragma unroll
+                for (int et = 0; et < ET; ++et)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cur[et][j] = nxt[et][j];
+            }
+        }
         float* op = OUT + (size_t)(rb * 32 + i31) * Di + h * D;
 #pragma unroll
         for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int e = 32 * et + 8 * gq + 4 * hi;
-                if (e < D) *(f32x4*)(op + e) = f32x4{o[et][4 * gq] * inv, o[et][4 * gq + 1] * inv, o[et][4 * gq + 2] * inv, o[et][4 * gq + 3] * inv};
+                if (e < D) *(f32x4*)(op + e) = f32x4{o[et][4 * gq], o[et][4 * gq + 1], o[et][4 * gq + 2], o[et][4 * gq + 3]};
             }
     }
 }
@@ -510,9 +568,10 @@ size_t tm_attn3_partial_bytes(int npad, int Di) {
 static bool tm_attn_exact() { static const bool v = getenv("ACMIL_TM_ATTN_FP32") != nullptr; return v; }
 
 template <int MT>
-static int tm_attn1x_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+static int tm_attn1x_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
+                            const float* convw) {
     constexpr int M = 32 * MT, D = 8 * MT, ET = (D + 31) / 32, EP = 32 * ET;
-    const size_t lds = ((size_t)2 * M * (D + 8) + (size_t)2 * MT * 2 * EP * 16) * sizeof(_Float16);
+    const size_t lds = ((size_t)2 * M * (D + 8) + (size_t)2 * MT * 2 * EP * 16) * sizeof(_Float16) + 2 * 4 * 64 * 16;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)tm_attn1x_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ACMIL_ERR_LAUNCH;
@@ -520,13 +579,21 @@ static int tm_attn1x_launch(const float* QKV, const float* KL, const float* W2, 
     }
     const int nblk = npad / 32;
     int gx = (nblk + 7) / 8; if (gx > 32) gx = 32;
-    hipLaunchKernelGGL(tm_attn1x_kernel<MT>, dim3(gx, TMA_HEADS), dim3(512), lds, st, QKV, KL, W2, OUT, npad, Di, scale);
+    hipLaunchKernelGGL(tm_attn1x_kernel<MT>, dim3(gx, TMA_HEADS), dim3(512), lds, st, QKV, KL, W2, OUT, npad, Di, scale, convw);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
 template <int MT>
-static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
-    if (!tm_attn_exact()) return tm_attn1x_launch<MT>(QKV, KL, W2, OUT, npad, Di, scale, st);
+static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
+                           const float* convw, int* conv_done) {
+    // ACMIL_TM_SEQCONV_PASS=1: keep the residual convolution as a pass of its own (A/B knob); the exact-fp32 leg never folds it
+    static const bool conv_pass = getenv("ACMIL_TM_SEQCONV_PASS") != nullptr;
+    if (!tm_attn_exact()) {
+        const bool fold = convw != nullptr && !conv_pass;
+        *conv_done = fold ? 1 : 0;
+        return tm_attn1x_launch<MT>(QKV, KL, W2, OUT, npad, Di, scale, st, fold ? convw : nullptr);
+    }
+    *conv_done = 0;
     constexpr int M = 32 * MT, D = 8 * MT, ET = (D + 31) / 32, EP = 32 * ET;
     const size_t lds = ((size_t)D * (M + 4) + (size_t)M * (EP + 8)) * sizeof(float);
     static bool attr_set = false;      // idempotent attribute; racing callers set the same value
@@ -540,12 +607,14 @@ static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, f
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
-int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st) {
+// convw [8][33] (res_conv.weight) or null; *conv_done = 1 when the leg added the residual convolution of v itself
+int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
+                   const float* convw, int* conv_done) {
     switch (Di) {
-        case 128: return tm_attn1_launch<2>(QKV, KL, W2, OUT, npad, Di, scale, st);
-        case 256: return tm_attn1_launch<4>(QKV, KL, W2, OUT, npad, Di, scale, st);
-        case 384: return tm_attn1_launch<6>(QKV, KL, W2, OUT, npad, Di, scale, st);
-        case 512: return tm_attn1_launch<8>(QKV, KL, W2, OUT, npad, Di, scale, st);
+        case 128: return tm_attn1_launch<2>(QKV, KL, W2, OUT, npad, Di, scale, st, convw, conv_done);
+        case 256: return tm_attn1_launch<4>(QKV, KL, W2, OUT, npad, Di, scale, st, convw, conv_done);
+        case 384: return tm_attn1_launch<6>(QKV, KL, W2, OUT, npad, Di, scale, st, convw, conv_done);
+        case 512: return tm_attn1_launch<8>(QKV, KL, W2, OUT, npad, Di, scale, st, convw, conv_done);
     }
     return ACMIL_ERR_UNSUPPORTED;
 }
