@@ -29,6 +29,7 @@ extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
 
 #define TM_HEADS 8
 #define TM_RES 33
+#define TM_QKV_GUARD 16      // zero rows kept before and after QKV [npad, 3 Di]: the convolution folded into the attn1 leg reads +-16 rows
 
 // ------------------------------------------------------------------------------------------------ small kernels
 // rows [0, zero_rows) of out are zeroed; rows [zero_rows, zero_rows + rows) = LayerNorm(in row) (eps 1e-5).  One wave per row.
@@ -149,7 +150,10 @@ __global__ __launch_bounds__(256) void tm_landmark_reduce_kernel(const float* __
 }
 
 // token assembly after fc1: cls row, wrap-around rows (repeat the first tokens), zero front padding
-__global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int nsq, int dim, const float* __restrict__ cls) {
+__global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int nsq, int dim, const float* __restrict__ cls,
+                                   float* __restrict__ guard_lo, float* __restrict__ guard_hi, int guard_n) {
+    // the zero guard rows of QKV (once per forward: nothing else writes them)
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < guard_n; e += gridDim.x * blockDim.x) { guard_lo[e] = 0.0f; guard_hi[e] = 0.0f; }
     const long long total = (long long)(pad + 1 + (nsq - N)) * dim;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long r = e / dim; const int c = e % dim;
@@ -550,7 +554,7 @@ static TmWs tm_ws(const TmGeom& g) {
     TmWs w; size_t off = 0;
     const size_t tok = tm_al((size_t)g.npad * g.Di * 4), mm = tm_al((size_t)TM_HEADS * g.m * g.m * 4), md = tm_al((size_t)TM_HEADS * g.m * g.d * 4);
     w.XA = off; off += tok; w.XB = off; off += tok; w.LN = off; off += tok; w.OUT = off; off += tok;
-    w.QKV = off; off += tm_al((size_t)g.npad * 3 * g.Di * 4);
+    w.QKV = off; off += tm_al((size_t)(g.npad + 2 * TM_QKV_GUARD) * 3 * g.Di * 4);      // (+ the guard rows; QKV itself starts TM_QKV_GUARD rows in)
     w.S1 = off; off += tm_al((size_t)TM_HEADS * g.npad * g.m * 4);
     w.S3 = off; off += tm_al((size_t)TM_HEADS * g.m * g.npad * 4);
     w.QL = off; off += md; w.KL = off; off += md; w.AV = off; off += md; w.W2 = off; off += md;
@@ -643,7 +647,7 @@ static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) 
 static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st, char* pk_qkv = nullptr,
                     char* pk_out = nullptr, const float* wbeta = nullptr) {
     const int Di = g.Di, m = g.m, d = g.d, npad = g.npad, H = TM_HEADS;
-    float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV); float* S1 = (float*)(ws + W.S1);
+    float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV) + (size_t)TM_QKV_GUARD * 3 * g.Di; float* S1 = (float*)(ws + W.S1);
     float* S3 = (float*)(ws + W.S3); float* OUT = (float*)(ws + W.OUT); float* QL = (float*)(ws + W.QL);
     float* KL = (float*)(ws + W.KL); float* S2 = (float*)(ws + W.S2); float* Z = (float*)(ws + W.Z);
     float* XZ = (float*)(ws + W.XZ); float* T1 = (float*)(ws + W.T1); float* T2 = (float*)(ws + W.T2);
@@ -814,7 +818,11 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
     { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, pk1 ? pk1 : ws + W.PKW, ws + W.LINWS, gws, st, pk1 != nullptr); if (r1 != ACMIL_OK) return r1; }
-    hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token);
+    {
+        float* qkv0 = (float*)(ws + W.QKV);
+        hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token, qkv0,
+                           qkv0 + (size_t)(TM_QKV_GUARD + g.npad) * 3 * Di, TM_QKV_GUARD * 3 * Di);
+    }
     TM_CHECK_LAUNCH();
     const float* wb = (const float*)(ws + W.WB);
     int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr); if (rc != ACMIL_OK) return rc;

@@ -332,7 +332,13 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
 
     const int nblk = npad / 32, stride = gridDim.x * 8;
     int rb = blockIdx.x * 8 + wave;
-    const float* vcol = QKV + 2 * Di + h * D;          // v column block of this head
+    // v column block of this head from the first guard row on, as a buffer resource (see the convolution below)
+    const unsigned ldv4 = 3u * (unsigned)Di * 4u;
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(QKV + 2 * Di + h * D - (size_t)16 * 3 * Di), 0, (int)(((size_t)npad + 32) * 3 * Di * 4 - (size_t)(2 * Di + h * D) * 4), 0x00020000);
+    int lane_off[ET];
+#pragma unroll
+    for (int et = 0; et < ET; ++et) { const int e = 32 * et + i31; lane_off[et] = (8 * hi * 3 * Di + (e < D ? e : D - 1)) * 4; }
     f32x4 qn[KS][2];
     auto load_q = [&](int b) {
         const float* qp = QKV + (size_t)(b * 32 + i31) * 3 * Di + h * D + 8 * hi;
@@ -347,23 +353,34 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
             const float v[8] = {qn[st][0][0], qn[st][0][1], qn[st][0][2], qn[st][0][3], qn[st][1][0], qn[st][1][1], qn[st][1][2], qn[st][1][3]};
             tma_split8(v, qh[st], ql[st]);
         }
-        if (rb + stride < nblk) load_q(rb + stride);
 
         f32x16 acc[MT];
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        // LDS fragment addresses = ONE per-lane byte offset, made opaque per block, + compile-time constants that fit the ds_read
+        // offset field.  Left to itself hipcc hoisted ~27 separate address registers out of the block loop and parked them in
+        // scratch: every reload carries an s_waitcnt vmcnt(0) that drains the q / v prefetches in flight.
+        int lbk = (i31 * LD + 8 * hi) * 2, lbw = (i31 * 2 + hi) * 16;
+        asm volatile("" : "+v"(lbk), "+v"(lbw));
+        const char* klh_b = (const char*)KLh + lbk; const char* kll_b = (const char*)KLl + lbk;
+        const char* w2h_b = (const char*)W2h + lbw; const char* w2l_b = (const char*)W2l + lbw;
 #pragma unroll
         for (int st = 0; st < KS; ++st) {
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                const int off = (32 * t + i31) * LD + 16 * st + 8 * hi;
-                const tma_h8 ah = *(const tma_h8*)(KLh + off), al = *(const tma_h8*)(KLl + off);
+                constexpr int dummy = 0; (void)dummy;
+                const int offb = (32 * t * LD + 16 * st) * 2;
+                const tma_h8 ah = *(const tma_h8*)(klh_b + offb), al = *(const tma_h8*)(kll_b + offb);
                 TMA_MFMA3(acc[t], ah, al, qh[st], ql[st]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the next block's queries are fetched HERE, into the registers the split q halves have just left (issued at the top of the
+        // loop they sat on top of the score accumulators' peak and hipcc parked them in scratch: a store waiting on an HBM load)
+        if (rb + stride < nblk) load_q(rb + stride);
+        __builtin_amdgcn_sched_barrier(0);
         float m2 = -INFINITY;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -382,6 +399,24 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
+        // the 64-row window of v for the convolution (4 K steps x ET x 8 rows per lane) is fetched INSIDE the product below, two K
+        // steps at a time at the points where a third of the softmax accumulators has just died: the loads fly under ~50 MFMAs
+        // and the register peak stays where it was (issued after the leg they cost 87 us per layer: 210 vs 123 us per launch)
+        float vw[4][ET][8];
+        // addresses: wave-uniform base (block, K step, row j, e tile) + one 32-bit lane offset (K half, feature); features e >= D of
+        // the last e tile read a clamped column -- those accumulator rows are never stored.  The first and the last block reach 16
+        // rows beyond the sequence: the caller keeps 16 ZERO guard rows on both sides of QKV (TM_QKV_GUARD, transmil.hip), so there
+        // is no checked path (a per-lane row test made hipcc spill 600 B per lane here).
+        // Buffer loads: ONE descriptor per kernel, a scalar byte offset per (block, K step, row) and a 32-bit lane offset per e tile
+        // (with flat loads hipcc materialised 64 per-lane 64-bit addresses ahead of the loop and spilled 700 B per lane).
+        const unsigned sblk = (unsigned)__builtin_amdgcn_readfirstlane(rb) * 32u * ldv4;
+        auto load_v = [&](int kp) {
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    vw[kp][et][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, lane_off[et], sblk + (unsigned)(16 * kp + j) * ldv4, 0));
+        };
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
 #pragma unroll
@@ -393,12 +428,16 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
                 tma_split8(pv, ph, pl);
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
-                    const int off = t * 2 * EP * 16 + (((e2 * EP + 32 * et + i31) * 2 + hi) * 8);
-                    const tma_h8 wh = *(const tma_h8*)(W2h + off), wl = *(const tma_h8*)(W2l + off);
+                    const int offb = (t * 2 * EP * 16 + (e2 * EP + 32 * et) * 16) * 2;
+                    const tma_h8 wh = *(const tma_h8*)(w2h_b + offb), wl = *(const tma_h8*)(w2l_b + offb);
                     TMA_MFMA3(o[et], wh, wl, ph, pl);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (convw) {
+                if (t == (MT >= 4 ? MT - 3 : 0)) { load_v(0); load_v(1); __builtin_amdgcn_sched_barrier(0); }
+                if (t == MT - 1) { load_v(2); load_v(3); __builtin_amdgcn_sched_barrier(0); }
+            }
         }
         const float inv = inv_s2 / sum;
 #pragma unroll
@@ -406,32 +445,15 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[et][r] *= inv;
         if (convw) {
-            const int rowb = rb * 32 - 16 + 8 * hi;                // first input row of this lane's K slots, step 0
-            float cur[ET][8], nxt[ET][8];
-            auto load_v = [&](int kp, float (&dst)[ET][8]) {
-#pragma unroll
-                for (int et = 0; et < ET; ++et)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = rowb + 16 * kp + j, e = 32 * et + i31;
-                        dst[et][j] = (r >= 0 && r < npad && e < D) ? vcol[(size_t)r * 3 * Di + e] : 0.0f;
-                    }
-            };
-            load_v(0, cur);
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
-                if (kp < 3) load_v(kp + 1, nxt);
                 const tma_h8 bh = Tch[kp * 64 + lane], bl = Tcl[kp * 64 + lane];
 #pragma unroll
                 for (int et = 0; et < ET; ++et) {
                     tma_h8 ah, al;
-                    tma_split8(cur[et], ah, al);
+                    tma_split8(vw[kp][et], ah, al);
                     TMA_MFMA3(o[et], ah, al, bh, bl);
                 }
-#pragma unroll
-                for (int et = 0; et < ET; ++et)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) cur[et][j] = nxt[et][j];
             }
         }
         float* op = OUT + (size_t)(rb * 32 + i31) * Di + h * D;
