@@ -1,5 +1,5 @@
 // linear.hip -- host side of the packed-weight Linear kernel (linear_kernel.h): weight packing and the C entry points.
-#include "linear_kernel.h"
+#include "linear64_kernel.h"
 
 // Packed stream of W [n_out, K] (row-major, leading dimension ldw) as output-column chunks (lin_plan): n_out / 256 chunks of ND = 8
 // (256 columns) then one ND = 4 chunk when n_out % 256 == 128 -- except n_out = 384, which runs as 2 chunks of ND = 6
@@ -106,8 +106,45 @@ static int lin_launch(const LinArgs& a, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
+// lin64_kernel (linear64_kernel.h): one 512-register wave per SIMD, 64 rows per wave, one workgroup per CU
+template <int ND, int XDT, int FX = 0>
+static int lin_launch64(const LinArgs& a, hipStream_t st) {
+    using G = Lin64Geom<ND, XDT>;
+    static int slots_of[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;
+    if (slots_of[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        if (hipFuncSetAttribute((const void*)lin64_kernel<ND, XDT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        slots_of[dev] = prop.multiProcessorCount;
+    }
+    const int slots = slots_of[dev];
+    const long long tiles = (long long)((a.M + G::ROWS - 1) / G::ROWS) * a.nchunks;
+    const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
+    hipLaunchKernelGGL((lin64_kernel<ND, XDT, FX>), grid, block, G::LDS, st, a);
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+// which kernel: lin64 needs four K steps per unrolled round; it is the default where it measured faster (profiles/r04_lin64_ablation.md:
+// long K loops, K >= 768, with at least one 256-row tile per CU -- the wide GA projections, 3 - 7 %); with K = 384 its epilogue, which no
+// second workgroup hides, costs what the leaner K loop gains.  ACMIL_LIN64=0 / 1 forces.
+static bool lin_use64(int M, int K, int nchunks) {
+    static const char* e = getenv("ACMIL_LIN64");
+    if (K % 64 != 0) return false;
+    if (e) return e[0] == '1';
+    return K >= 768 && (long long)((M + 255) / 256) * nchunks >= 256;
+}
+
 template <int ND>
 static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
+    if (a.act != 2 && lin_use64(a.M, a.K, a.nchunks)) {
+        switch (x_dtype) {
+            case ACMIL_DTYPE_F32: return lin_launch64<ND, ACMIL_DTYPE_F32>(a, st);
+            case ACMIL_DTYPE_F16: return lin_launch64<ND, ACMIL_DTYPE_F16>(a, st);
+            case ACMIL_DTYPE_BF16: return lin_launch64<ND, ACMIL_DTYPE_BF16>(a, st);
+        }
+        return ACMIL_ERR_UNSUPPORTED;
+    }
     switch (x_dtype) {
         case ACMIL_DTYPE_F32: return lin_launch<ND, ACMIL_DTYPE_F32>(a, st);
         case ACMIL_DTYPE_F16: return lin_launch<ND, ACMIL_DTYPE_F16>(a, st);
@@ -171,7 +208,8 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
         a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
-        rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 3>(a, st);
+        if (lin_use64(M, K, P.nmain)) rc = P.nd == 6 ? lin_launch64<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch64<8, ACMIL_DTYPE_F32, 3>(a, st);
+        else rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 3>(a, st);
         if (rc != ACMIL_OK) return rc;
     }
     if (P.nd_rem) {

@@ -1,13 +1,21 @@
-"""Timing of the packed-weight Linear kernel vs the generic split-f16 GEMM on the TransMIL cfg4 shapes."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from acmil_amd import ops
-for (m, k, n) in [(100000, 768, 384), (100608, 384, 1152), (100490, 384, 384), (50000, 512, 256), (50000, 1024, 512)]:
-    x = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda") * 0.03
-    packed = ops.linear_pack(w)
-    y = torch.empty(m, n, device="cuda")
-    for name, fn in (("linear", lambda: ops.linear_f16x3(x, packed, n, out=y)), ("gemm  ", lambda: ops.gemm(x, w, trans_b=True, precision="f16x3", out=y))):
+"""Timing of the packed-weight Linear kernels (lin_kernel vs lin64_kernel: ACMIL_LIN64=0 / 1 per subprocess) on the TransMIL cfg4 and
+wide-GA projection shapes, with a correctness check against fp64 on a row sample.  Run on the GPU box:  python tools/time_linear.py"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SHAPES = [(100000, 768, 384), (100224, 384, 1152), (100224, 384, 384), (50000, 1024, 512), (50000, 1536, 768), (50000, 768, 384), (3000, 512, 256)]
+
+
+def child():
+    import torch
+    from acmil_amd import ops
+    for (m, k, n) in SHAPES:
+        x = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda") * 0.03
+        b = torch.randn(n, device="cuda")
+        packed = ops.linear_pack(w)
+        y = torch.empty(m, n, device="cuda")
+        fn = lambda: ops.linear_f16x3(x, packed, n, bias=b, relu=True, out=y)
         for _ in range(3): fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -15,4 +23,17 @@ for (m, k, n) in [(100000, 768, 384), (100608, 384, 1152), (100490, 384, 384), (
         for _ in range(20): fn()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        print("%s M=%d K=%d N=%d: %.1f us  %.0f TF algorithmic (%.0f executed)" % (name, m, k, n, us, 2.0 * m * k * n / us / 1e6, 6.0 * m * k * n / us / 1e6), flush=True)
+        rows = torch.cat([torch.arange(0, min(m, 300)), torch.arange(max(0, m - 300), m), torch.randint(0, m, (400,))]).cuda()
+        ref = torch.relu(x[rows].double() @ w.double().T + b.double())
+        scale = (x[rows].double().abs() @ w.double().abs().T).max().item()
+        err = (y[rows].double() - ref).abs().max().item() / scale
+        print("LIN64=%s M=%d K=%d N=%d: %.1f us  %.0f TF algorithmic (%.3f of 2.5 PF executed)  rel err %.1e" % (
+            os.environ.get("ACMIL_LIN64", "auto"), m, k, n, us, 2.0 * m * k * n / us / 1e6, 6.0 * m * k * n / us / 1e6 / 2500.0, err), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "child":
+        child()
+    else:
+        for v in ("0", "1"):
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ACMIL_LIN64=v))
