@@ -80,6 +80,9 @@ SIGNATURES = {
                               C.c_longlong, _vp, _vp, _vp]),
     "acmil_adamw_step_report": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float,
                                      C.c_longlong, _vp, _vp, _vp, _vp]),
+    "acmil_peer_publish": (_i, [_vp, _vp, C.c_longlong, C.POINTER(_vp), _i, _i, C.c_uint, _vp, _vp]),
+    "acmil_adamw_step_peer": (_i, [_vp, _vp, _vp, C.c_longlong, C.POINTER(_vp), _vp, _i, _i, C.c_uint, C.c_double, _vp, C.c_float,
+                                   C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong, _i, _vp, _vp, _vp, _vp]),
     "acmil_ga_loss_workspace_bytes": (_sz, [_i] * 2),
     "acmil_ga_loss": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),

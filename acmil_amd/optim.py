@@ -20,7 +20,8 @@ from . import _lib
 
 class FlatAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2, grad_buffer: Optional[torch.Tensor] = None, on_step: Optional[Callable[[], None]] = None):
+                 weight_decay: float = 1e-2, grad_buffer: Optional[torch.Tensor] = None, on_step: Optional[Callable[[], None]] = None,
+                 peer=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
             raise RuntimeError("acmil_amd.FlatAdamW: CUDA fp32 parameters only")
@@ -53,6 +54,11 @@ class FlatAdamW:
         self.step_count = 0
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps, "weight_decay": weight_decay}]
         self.on_step = on_step
+        # peer.PeerReducer (or None): step() then publishes the bucket and runs the fused wait + reduce + AdamW launch instead of
+        # reading gradients that a collective has already averaged (the caller must NOT all-reduce the bucket as well)
+        self.peer = peer
+        if peer is not None and (grad_buffer is None or peer.n_total != self.grad.numel()):
+            raise RuntimeError("acmil_amd.FlatAdamW: the peer reducer works on the shared gradient bucket (grad_buffer), same size")
         self._frozen = []          # (offset, numel) ranges that receive no gradient this run: skipped like torch skips grad=None
 
     def set_frozen(self, params: Iterable[torch.nn.Parameter]):
@@ -84,13 +90,25 @@ class FlatAdamW:
         if track and len(self._pending) >= 12:
             raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
         slot = self._step_id % 16
-        # tracked: the launch itself stores the flag into pinned host memory (no copy on the stream)
-        rc = lib.acmil_adamw_step_report(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+        if self.peer is not None:
+            # direct data-parallel reduction: bucket -> own slot + flags at the peers, then wait + reduce (rank order) + AdamW in ONE launch
+            self.peer.publish(self.grad)
+            rc = lib.acmil_adamw_step_peer(self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.numel,
+                                           self.peer.slot_ptrs(), self.peer.flags.data_ptr(), self.peer.world, self.peer.rank,
+                                           self.peer.step_id, float(self.peer.timeout_s), self.peer.err.data_ptr(), float(g["lr"]),
+                                           float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._launches,
+                                           0 if self.guard_flag is None else 1, self._skipped_dev.data_ptr(),
+                                           self._host_flags.data_ptr() + 4 * slot if track else None, None,
+                                           torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "acmil_adamw_step_peer")
+        else:
+          # tracked: the launch itself stores the flag into pinned host memory (no copy on the stream)
+          rc = lib.acmil_adamw_step_report(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                                          self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
                                          self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
                                          self._skipped_dev.data_ptr(), self._host_flags.data_ptr() + 4 * slot if track else None,
                                          torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "acmil_adamw_step_report")
+          _lib.check(rc, "acmil_adamw_step_report")
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told

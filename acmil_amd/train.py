@@ -176,6 +176,7 @@ class GradBucket:
         # every rank whether ANY rank's bag left the split-f16 range, and every rank's optimizer launch skips that step
         self.flat = torch.zeros(self.numel + 1, dtype=torch.float32, device=dev)
         self.flag = self.flat[self.numel:]
+        self.peer = None        # peer.PeerReducer once enable_direct() succeeded: the reduction then happens inside the optimizer launch
         off = 0
         for p in self.params:   # gradients become views into the flat buffer: no copy in / out
             p.grad = self.flat[off:off + p.numel()].view_as(p)
@@ -201,7 +202,17 @@ class GradBucket:
                 p.grad = view
             off += n
 
+    def enable_direct(self, rank: int, world: int, group=None) -> bool:
+        """Switch to the one-shot direct reduction (acmil_amd/peer.py: the optimizer launch reads the peers' buckets through IPC-mapped
+        pointers).  Collective; False (on every rank) when the mapping cannot be set up -- torch.distributed stays in charge."""
+        if world > 1 and self.flat.is_cuda:
+            from .peer import PeerReducer
+            self.peer = PeerReducer.try_create(self.flat.numel(), self.flat.device, rank, world, group)
+        return self.peer is not None
+
     def allreduce_mean(self, world: int):
+        if self.peer is not None:       # reduced by FlatAdamW.step itself (acmil_adamw_step_peer)
+            return
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
@@ -382,7 +393,7 @@ def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, l
     if device.type == "cuda" and not getattr(conf, "torch_optimizer", False):
         from .optim import FlatAdamW
         opt = FlatAdamW(params, lr=lr, weight_decay=conf.wd, grad_buffer=None if bucket is None else bucket.flat,
-                        on_step=getattr(model, "invalidate_packed", None))
+                        on_step=getattr(model, "invalidate_packed", None), peer=None if bucket is None else bucket.peer)
         if getattr(conf, "arch", "") == "ga" and getattr(conf, "n_token", 2) == 1:
             # n_token == 1: the branch-head loss is not built (Step3_WSI_classification_ACMIL.py:201-204), its parameters keep
             # grad None in the reference and torch's AdamW leaves them untouched (no weight decay)
@@ -425,6 +436,9 @@ def get_arguments(argv=None):
     p.add_argument("--train_epoch", type=int, default=None)
     p.add_argument("--n_class", type=int, default=None)
     p.add_argument("--out_dir", default="runs/acmil")
+    p.add_argument("--dp-reduce", dest="dp_reduce", default=os.environ.get("ACMIL_DP_REDUCE", "rccl"), choices=["rccl", "direct"],
+                   help="data-parallel gradient reduction: torch.distributed all_reduce (RCCL), or the one-shot direct reduction fused "
+                        "into the optimizer launch (peers' buckets read through IPC-mapped pointers; one node; falls back to rccl)")
     return p.parse_args(argv)
 
 
@@ -456,6 +470,10 @@ def main(argv=None):
     model = build_model(conf).to(device)
     broadcast_parameters(model, world)
     bucket = GradBucket(list(model.parameters())) if world > 1 else None
+    if bucket is not None and getattr(conf, "dp_reduce", "rccl") == "direct" and device.type == "cuda":
+        ok = bucket.enable_direct(rank, world)
+        if rank == 0:
+            print("data-parallel gradient reduction: %s" % ("direct (fused into the optimizer launch)" if ok else "torch.distributed (direct unavailable)"))
     optimizer = make_optimizer(model, conf, device, bucket)
     os.makedirs(conf.out_dir, exist_ok=True)
     best = {"epoch": -1, "val_acc": 0, "val_auc": 0, "val_f1": 0, "test_acc": 0, "test_auc": 0, "test_f1": 0}

@@ -420,6 +420,25 @@ int acmil_adamw_step_report(float* params, const float* grads, float* exp_avg, f
                             double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
                             float* flag_report, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Direct (one-shot) gradient all-reduce fused into the optimizer launch, for slide-level data parallelism on one node
+ * (replaces the torch.distributed all_reduce + AdamW pair of acmil_amd.train; the reference itself is single-GPU:
+ * Step3_WSI_classification_ACMIL.py:139,219).  Every rank owns two gradient slots [n + 1] fp32 (parity of the step; element n = the
+ * range flag) and a flag array [8] uint32 in memory that its peers have mapped (CUDA / HIP IPC: acmil_amd/peer.py).
+ *   acmil_peer_publish: bucket [n_total] -> my_slot with system-scope stores, then `step` into entry `rank` of every rank's flag
+ *     array (flag_arrays[world], own included).  arrive: one zeroed device word of the caller.
+ *   acmil_adamw_step_peer: waits until my_flags[r] >= step for every peer r (at most timeout_s seconds, then *err = 1 and nothing is
+ *     changed), sums slots[0..world) element-wise IN RANK ORDER, divides by world and applies acmil_adamw_step's update to n
+ *     elements; use_flag: element n of the slots is the averaged range flag (non-zero -> step skipped, *skipped += 1, as
+ *     acmil_adamw_step).  reduced_out (may be NULL, [n + 1]): receives the averaged gradients and flag.  step >= 1, increasing.
+ * ------------------------------------------------------------------------------------------- */
+int acmil_peer_publish(const float* bucket, float* my_slot, long long n_total, void* const* flag_arrays, int world, int rank,
+                       unsigned step, unsigned* arrive, void* stream);
+int acmil_adamw_step_peer(float* params, float* exp_avg, float* exp_avg_sq, long long n, const void* const* slots,
+                          const unsigned* my_flags, int world, int rank, unsigned step, double timeout_s, int* err, float lr,
+                          double beta1, double beta2, float eps, float weight_decay, long long launch, int use_flag, int* skipped,
+                          float* flag_report, float* reduced_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

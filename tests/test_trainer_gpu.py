@@ -301,3 +301,20 @@ def test_two_rank_rccl_training_steps():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_two_rank_direct_reduce_on_one_gpu():
+    """The one-shot direct gradient reduction fused into the optimizer launch (acmil_amd/peer.py, csrc/peer.hip): two ranks -- sharing
+    this box's GPU when it has only one -- map each other's gradient slots through CUDA IPC; parameters bit-identical across ranks and
+    equal to one process on the averaged gradients, flagged step skipped on both, 40 unsynchronised steps (tests/dist_worker_peer.py)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker_peer.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "PEER_OK" in r.stdout, r.stdout[-3000:]
+
