@@ -274,14 +274,16 @@ def other_workloads(args, ctx):
     bags = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
 
-    def step(i):      # as train.train_one_epoch: range flag left on the device, looked at two steps late (no host read-back per step)
-        model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag)
-        bucket.sync_from_grads()
-        bucket.allreduce_mean(world)
-        opt.step(track_flag=True)
-        if opt.poll_skipped(2):
-            raise SystemExit("bench: a synthetic bag left the split-f16 range")
-    dt = _timed(step, args, world, dev)
+    def make_step(bucket, opt):
+        def step(i):      # as train.train_one_epoch: range flag left on the device, looked at two steps late (no host read-back per step)
+            model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag)
+            bucket.sync_from_grads()
+            bucket.allreduce_mean(world)
+            opt.step(track_flag=True)
+            if opt.poll_skipped(2):
+                raise SystemExit("bench: a synthetic bag left the split-f16 range")
+        return step
+    dt = _timed(make_step(bucket, opt), args, world, dev)
     # the collective alone (what the step pays for data parallelism): the same flat-bucket all-reduce + mean, back to back, events on
     # the launch stream; None on one GPU (GradBucket.allreduce_mean issues nothing there)
     allreduce_us = None
@@ -299,6 +301,23 @@ def other_workloads(args, ctx):
         import torch.distributed as dist
         dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
         allreduce_us = round(float(t_ar.item()), 2)
+    # the same steps with the DIRECT reduction (acmil_amd/peer.py: the optimizer launch reads the peers' buckets through IPC-mapped
+    # pointers; no collective launch), timed after the RCCL line so that `value` keeps its meaning; never fatal
+    direct = None
+    if world > 1:
+        try:
+            opt.poll_skipped(0)
+            bucket_d = T.GradBucket(list(model.parameters()))
+            if bucket_d.enable_direct(rank, world):
+                opt_d = T.make_optimizer(model, conf, dev, bucket_d, lr=conf.lr)
+                dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)
+                opt_d.peer.check()
+                direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * args.steps / dt_d, 1), "unit": "slides/s",
+                          "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"}
+            else:
+                direct = {"error": "peer mapping unavailable: torch.distributed only"}
+        except (Exception, SystemExit) as e:
+            direct = {"error": "%s: %s" % (type(e).__name__, e)}
     _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
     flops = fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)
     t_step = dt / args.steps
@@ -306,7 +325,7 @@ def other_workloads(args, ctx):
         "metric": "slides/sec (ACMIL-ga training step: fwd + STKIM + losses + bwd + grad all-reduce + AdamW, N=%d D=512 C=7)" % N,
         "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "allreduce_us": allreduce_us, "allreduce_bytes": int(bucket.flat.numel() * 4),
+        "allreduce_us": allreduce_us, "allreduce_bytes": int(bucket.flat.numel() * 4), "direct_reduce": direct,
         "dtype": "f32 (split-f16 / split-bf16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
         "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
                                "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,
