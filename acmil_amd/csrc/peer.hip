@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
                                                         float* __restrict__ flag_report, float* __restrict__ reduced_out) {
     __shared__ int s_ok;
     __shared__ float s_bc[2];
-    if (threadIdx.x == 0) s_ok = 1;
+    // (once a wait has timed out every later launch returns at once: a dead peer costs one timeout, not one per step)
+    if (threadIdx.x == 0) s_ok = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 0;
     __syncthreads();
+    if (!s_ok) return;
     if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(myflags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step) {
