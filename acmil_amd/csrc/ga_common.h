@@ -141,6 +141,13 @@ __device__ __forceinline__ void ga_split_pair_f16(float x0, float x1, unsigned& 
         "v_fma_mixhi_f16 %1, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0"
         : "=&v"(hi_pk), "=&v"(lo_pk) : "v"(x0), "v"(x1));
 }
+// hi only: round-to-nearest packed convert (a bf16 value is f16-exact above the f16 subnormals and rounds by at most 2^-25 inside
+// them -- where the f16 image of the remainder is 0 anyway: the lo half of a bf16 value is identically zero, see ga_forward_kernel_v2.h)
+__device__ __forceinline__ unsigned ga_cvt_pair_f16(float x0, float x1) {
+    unsigned hi_pk;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi_pk) : "v"(x0), "v"(x1));
+    return hi_pk;
+}
 // bf16: hi = rn_bf16(x), lo = rn_bf16(x - hi) with the PACKED hardware convert (the compiler's scalar casts cost one
 // v_cvt_pk_bf16_f32 per element plus pack operations): 6 VALU instructions for two elements
 __device__ __forceinline__ void ga_split_pair_bf16(float x0, float x1, unsigned& hi_pk, unsigned& lo_pk) {

@@ -133,7 +133,12 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Ga2Geom<ND, KP, XDT, WV, Ga2Tri<ND, XDT, POOL, WV, PAIR>::value>;
     constexpr int WAVES = G::WAVES, NTHR = 64 * WAVES;
-    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16);   // fp16 bags are exact in the hi part
+    // fp16 bags are exact in the hi part.  So are bf16 bags (round 4): 8 significant bits fit the 11 of f16 down to 2^-14, and below
+    // that hi = RN_f16(x) is off by at most half an f16 subnormal step (2^-25), a remainder whose own f16 image rounds to ZERO
+    // (ties to even) -- the lo plane of a bf16 bag was identically zero and its product a third of GEMM1's MFMAs spent on zeros.
+    // (Out-of-range values become inf in hi either way and are caught by the range guard.)  Results are bit-identical.
+    constexpr bool XLO = (XDT == ACMIL_DTYPE_F32);
+    constexpr bool XCV = (XDT != ACMIL_DTYPE_F16);   // the operand needs a conversion to f16 at all
     constexpr int Di = G::Di, PD = G::PD, NB = G::NB;
     static_assert(PD == 2 && NB == 3, "the wait counts below are written for a prefetch distance of 2 steps");
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                     else xrw[g] = *(const u32x4*)(slot + xb[g] + xl0);
                 }
             };
-            constexpr int NSP = XLO ? 8 : 0;      // split pieces per step: 2 groups x 4
+            constexpr int NSP = XCV ? 8 : 0;      // split / convert pieces per step: 2 groups x 4
             u32x4 xhw[2], xlw[2];
             auto split_piece = [&](int q) {
                 const int g = q >> 2, j = q & 3;
@@ -340,15 +345,18 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                     v0 = __builtin_bit_cast(float, xrw[g][j] << 16);
                     v1 = __builtin_bit_cast(float, xrw[g][j] & 0xffff0000u);
                 }
-                unsigned h, l;
-                ga2_split_pair(v0, v1, h, l);
-                xhw[g][j] = h; xlw[g][j] = l;
+                if constexpr (XLO) {
+                    unsigned h, l;
+                    ga2_split_pair(v0, v1, h, l);
+                    xhw[g][j] = h; xlw[g][j] = l;
+                } else xhw[g][j] = ga_cvt_pair_f16(v0, v1);
             };
             f16x8 xh[2], xl[2], xhp[2];
             auto split_done = [&]() {
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     if constexpr (XLO) { xh[g] = __builtin_bit_cast(f16x8, xhw[g]); xl[g] = __builtin_bit_cast(f16x8, xlw[g]); }
+                    else if constexpr (XCV) xh[g] = __builtin_bit_cast(f16x8, xhw[g]);
                     else xh[g] = __builtin_bit_cast(f16x8, xrw[g]);
                 }
             };
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                     else xrw = *(const u32x4*)(slot + xrd0);
                 };
                 // split piece j (< NSP) of the raw tile into word j of the hi / lo operands (two K slots per piece)
-                constexpr int NSP = XLO ? 4 : 0;
+                constexpr int NSP = XCV ? 4 : 0;
                 u32x4 xhw, xlw;
                 auto split_piece = [&](int j) {
                     float v0, v1;
@@ -543,12 +551,15 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                         v0 = __builtin_bit_cast(float, xrw[j] << 16);
                         v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
                     }
-                    unsigned h, l;
-                    ga2_split_pair(v0, v1, h, l);
-                    xhw[j] = h; xlw[j] = l;
+                    if constexpr (XLO) {
+                        unsigned h, l;
+                        ga2_split_pair(v0, v1, h, l);
+                        xhw[j] = h; xlw[j] = l;
+                    } else xhw[j] = ga_cvt_pair_f16(v0, v1);
                 };
                 auto split_done = [&](f16x8& h8, f16x8& l8) {
                     if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
+                    else if constexpr (XCV) h8 = __builtin_bit_cast(f16x8, xhw);
                     else h8 = __builtin_bit_cast(f16x8, xrw);
                 };
                 f16x8 WH[ND], WL[ND];

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Lin64Geom<ND, XDT>;
     constexpr int NB = G::NB, PD = G::PD, RW = G::RW, XG = G::XG, NV = G::NV;
-    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16) || (FX & 1);
+    constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);      // (a bf16 operand is f16-exact like an fp16 one: converted, no lo plane)
+    constexpr bool XCV = XLO || (XDT != ACMIL_DTYPE_F16);
     constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0;
     static_assert(NB == 4 && PD == 3, "the K loop is unrolled by 4: slot and register-set indices are compile-time");
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -272,6 +273,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                 unsigned h, l;
                                 ga2_split_pair(v0, v1, h, l);
                                 hw[bb][j] = h; lw[bb][j] = l;
+                            } else if constexpr (XCV) {
+                                hw[bb][j] = ga_cvt_pair_f16(v0, v1);
                             } else {
                                 hw[bb][j] = xrw[bb][j];
                             }

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = Ga2Geom<ND, 1, XDT>;
     constexpr int NTHR = 256, PD = G::PD, NB = G::NB;
-    constexpr bool XLO = (XDT != ACMIL_DTYPE_F16) || (FX & 1);     // (an affine image of an f16 value is not f16-exact)
+    // lo plane: fp32 activations, and any LayerNorm-folded operand (an affine image of a 16-bit value is not f16-exact); a bf16
+    // operand is f16-exact like an fp16 one (ga_forward_kernel_v2.h) and is only converted
+    constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);
+    constexpr bool XCV = XLO || (XDT != ACMIL_DTYPE_F16);
     constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0;
     static_assert(PD == 2 && NB == 3, "wait counts assume a prefetch distance of 2 steps");
     static_assert(G::REGION >= 4608 || !G::SCRATCH_IN_RING, "transposition tile must fit the free slot");
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                 if constexpr (XDT == ACMIL_DTYPE_F32) { xr0 = *(const f32x4*)(slot + xrd0); xr1 = *(const f32x4*)(slot + xrd1); }
                 else xrw = *(const u32x4*)(slot + xrd0);
             };
-            constexpr int NSP = XLO ? 4 : 0;
+            constexpr int NSP = XCV ? 4 : 0;
             u32x4 xhw, xlw;
             auto split_piece = [&](int j) {
                 float v0, v1;
@@ -235,12 +238,15 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                     v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
                 }
                 if constexpr (NORM) { v0 = fmaf(v0, rab[0], rab[1]); v1 = fmaf(v1, rab[0], rab[1]); }
-                unsigned h, l;
-                ga2_split_pair(v0, v1, h, l);
-                xhw[j] = h; xlw[j] = l;
+                if constexpr (XLO) {
+                    unsigned h, l;
+                    ga2_split_pair(v0, v1, h, l);
+                    xhw[j] = h; xlw[j] = l;
+                } else xhw[j] = ga_cvt_pair_f16(v0, v1);
             };
             auto split_done = [&](f16x8& h8, f16x8& l8) {
                 if constexpr (XLO) { h8 = __builtin_bit_cast(f16x8, xhw); l8 = __builtin_bit_cast(f16x8, xlw); }
+                else if constexpr (XCV) h8 = __builtin_bit_cast(f16x8, xhw);
                 else h8 = __builtin_bit_cast(f16x8, xrw);
             };
             f16x8 WH[ND], WL[ND];

@@ -697,10 +697,10 @@ def ga_workload(args, ctx):
     nbytes, flops = nbytes * B, flops * B            # one launch processes B slides
     split = args.precision == "f16x3"
     mfma_peak = 157.3 if args.precision == "fp32" else 2500.0   # TFLOP/s dense: fp32 MFMA / f16 MFMA
-    # MFMA flops actually executed: split-f16 runs 3 products per fp32 product (2 in GEMM1 when the bag is fp16: x_lo = 0)
+    # MFMA flops actually executed: split-f16 runs 3 products per fp32 product (2 in GEMM1 when the bag is fp16 / bf16: x_lo = 0)
     g1 = 2.0 * N_PATCH * D_FEAT * D_INNER * B
     g2 = 2.0 * N_PATCH * 2 * D_INNER * D_ATTN * B
-    p1 = (2.0 if x_dtype == torch.float16 else 3.0) if split else 1.0
+    p1 = (3.0 if x_dtype == torch.float32 else 2.0) if split else 1.0       # 16-bit bags (fp16 and, round 4, bf16) have no x_lo product
     executed = g1 * p1 + g2 * (3.0 if split else 1.0)
     version = 1 if (os.environ.get("ACMIL_GA_KERNEL") == "1" or not split) else 2
     if version == 2:      # csrc/ga_forward.hip::ga_v2_waves: 4 waves unless the opt-in is set

@@ -63,6 +63,34 @@ def test_half_precision_bags_match_oracle_on_the_same_values(precision, xdtype):
     assert (slide.cpu() - ref["slide_pred"]).abs().max() < TOL
 
 
+def test_bf16_bag_has_no_lo_plane_bitwise_and_tiny_values_stay_in_bounds():
+    """Round 4: a bf16 bag is converted to f16 WITHOUT a lo plane (it was identically zero: 8 significant bits are f16-exact down to
+    2^-14 and the remainder below rounds to 0 in f16).  (i) The bf16 launch equals, bit for bit, the fp16 launch of the same values
+    (bf16 -> fp16 is that same rounding, and the fp16 path never had a lo plane); (ii) a bag made of values in and below the f16
+    subnormal range -- the only place the conversion rounds -- stays within 1e-6 of the oracle on the exact bf16 values."""
+    from oracle import ga_oracle as O
+    case, sd = load_golden("ga_eval_n1000_d384_k5_c7")
+    d, di, k, c = case_dims(sd)
+    model = _build(sd, k, c, d, di, "f16x3").eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.from_numpy(case["x"]).clone()
+    x[::7] *= 1e-5                                        # rows in the f16 subnormal range
+    x[::11] *= 1e-8                                       # rows below it (flush to zero in f16: |error| <= 3e-8 each)
+    xb = x.to(torch.bfloat16)
+    with torch.no_grad():
+        sub_b, slide_b, a_b = model(xb.cuda())
+        sub_h, slide_h, a_h = model(xb.to(torch.float16).cuda())
+    assert torch.equal(a_b, a_h) and torch.equal(sub_b, sub_h) and torch.equal(slide_b, slide_h)
+    ref = O.acmil_ga_forward(xb.float(), sd, n_token=k)
+    assert (a_b.cpu() - ref["A_out"]).abs().max() < 2e-6 and (slide_b.cpu() - ref["slide_pred"]).abs().max() < 2e-6
+    tiny = (torch.rand(1000, d, generator=g) - 0.5) * 2e-5      # EVERY value below 2^-16: the worst case of the conversion
+    tb = tiny.to(torch.bfloat16)
+    ref_t = O.acmil_ga_forward(tb.float(), sd, n_token=k)
+    with torch.no_grad():
+        _, slide_t, a_t = model(tb.cuda())
+    assert (a_t.cpu() - ref_t["A_out"]).abs().max() < 2e-6 and (slide_t.cpu() - ref_t["slide_pred"]).abs().max() < 2e-6
+
+
 @pytest.mark.parametrize("precision", PARITY_MODES)
 def test_abmil_matches_reference_golden(precision):
     case, sd = load_golden("abmil_eval_n1000_d512_c2")
