@@ -511,6 +511,52 @@ __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ 
     }
 }
 
+// The same stencil with PACKED fp32 FMAs (round 4): a thread owns a channel PAIR and one row of the 8 x 8 pixel tile, so every
+// operand is a natural 8-byte pair -- the halo values of two adjacent channels (one ds_read_b64), their two weights -- and a tap is one
+// v_pk_fma_f32 for two outputs: half the VALU instructions and half the LDS instructions of the scalar kernel above
+// (1.9 GFMA per slide were 181 us there: VALU issue, not HBM -- 1.7 TB/s).  C % 64 == 0 (else the scalar kernel).
+__global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
+                                                      const float* __restrict__ weff, const float* __restrict__ beff) {
+    __shared__ __attribute__((aligned(16))) float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
+    const int cp = threadIdx.x & 31, py = threadIdx.x >> 5;          // channel pair, tile row
+    const int cb = blockIdx.x * 64;
+    const int tiles_x = (side + TM_PT - 1) / TM_PT;
+    const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < (TM_PT + 6) * (TM_PT + 6) * 16; idx += 256) {
+        const int e = idx >> 4, c4 = idx & 15;
+        const int yy = ty0 + e / (TM_PT + 6) - 3, xx = tx0 + e % (TM_PT + 6) - 3;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (yy >= 0 && yy < side && xx >= 0 && xx < side) v = *(const f32x4*)(in + ((size_t)yy * side + xx) * C + cb + 4 * c4);
+        *(f32x4*)(tile + e * 64 + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int c = cb + 2 * cp, y = ty0 + py;
+    if (y >= side) return;
+    const f32x2 b = *(const f32x2*)(beff + c);
+    f32x2 acc[TM_PT];
+#pragma unroll
+    for (int px = 0; px < TM_PT; ++px) acc[px] = b;
+    // one kernel row at a time: its 7 weight pairs (L1-resident: 49 x C floats per launch) and the 14 halo pairs of that row --
+    // holding all 49 pairs in registers (98) left one wave per SIMD or 556 B of scratch
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        f32x2 w[7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) w[kx] = *(const f32x2*)(weff + (size_t)(ky * 7 + kx) * C + c);
+        f32x2 v[TM_PT + 6];
+#pragma unroll
+        for (int i = 0; i < TM_PT + 6; ++i) v[i] = *(const f32x2*)(tile + ((py + ky) * (TM_PT + 6) + i) * 64 + 2 * cp);
+#pragma unroll
+        for (int px = 0; px < TM_PT; ++px)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) acc[px] = __builtin_elementwise_fma(w[kx], v[px + kx], acc[px]);
+    }
+#pragma unroll
+    for (int px = 0; px < TM_PT; ++px)
+        if (tx0 + px < side) *(f32x2*)(out + ((size_t)y * side + tx0 + px) * C + c) = acc[px];
+}
+
 __global__ void tm_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) dst[e] = src[e];
 }
@@ -832,6 +878,11 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
                        XA + (size_t)g.pad * Di, XB + (size_t)g.pad * Di);
     {
         const int tiles = (g.side + TM_PT - 1) / TM_PT;
+        static const bool ppeg_scalar = getenv("ACMIL_TM_PPEG_SCALAR") != nullptr;       // A/B knob
+        if (Di % 64 == 0 && !ppeg_scalar)
+            hipLaunchKernelGGL(tm_ppeg2_kernel, dim3(Di / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
+                               XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff);
+        else
         hipLaunchKernelGGL(tm_ppeg_kernel, dim3((Di + 63) / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
                            XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff);
     }

@@ -73,9 +73,9 @@ def test_bf16_bag_has_no_lo_plane_bitwise_and_tiny_values_stay_in_bounds():
     d, di, k, c = case_dims(sd)
     model = _build(sd, k, c, d, di, "f16x3").eval()
     g = torch.Generator().manual_seed(3)
-    x = torch.from_numpy(case["x"]).clone()
-    x[::7] *= 1e-5                                        # rows in the f16 subnormal range
-    x[::11] *= 1e-8                                       # rows below it (flush to zero in f16: |error| <= 3e-8 each)
+    x = torch.from_numpy(case["x"]).clone()               # [1, N, D]
+    x[0, ::7] *= 1e-5                                     # rows in the f16 subnormal range
+    x[0, ::11] *= 1e-8                                    # rows below it (flush to zero in f16: |error| <= 3e-8 each)
     xb = x.to(torch.bfloat16)
     with torch.no_grad():
         sub_b, slide_b, a_b = model(xb.cuda())
@@ -83,7 +83,7 @@ def test_bf16_bag_has_no_lo_plane_bitwise_and_tiny_values_stay_in_bounds():
     assert torch.equal(a_b, a_h) and torch.equal(sub_b, sub_h) and torch.equal(slide_b, slide_h)
     ref = O.acmil_ga_forward(xb.float(), sd, n_token=k)
     assert (a_b.cpu() - ref["A_out"]).abs().max() < 2e-6 and (slide_b.cpu() - ref["slide_pred"]).abs().max() < 2e-6
-    tiny = (torch.rand(1000, d, generator=g) - 0.5) * 2e-5      # EVERY value below 2^-16: the worst case of the conversion
+    tiny = (torch.rand(1, 1000, d, generator=g) - 0.5) * 2e-5   # EVERY value below 2^-16: the worst case of the conversion
     tb = tiny.to(torch.bfloat16)
     ref_t = O.acmil_ga_forward(tb.float(), sd, n_token=k)
     with torch.no_grad():
