@@ -587,10 +587,10 @@ static TmGeom tm_geom(int N, int D, int Di, int C) {
 
 static size_t tm_al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, ZB, ZTB, XZ, T1, T2, AV, W2, WEFF, BEFF, SCAL, PART, PKW, LINWS, AB, LMP, WB, GEMM, total; };
+struct TmWs { size_t XA, XB, LN, QKV, S1, S3, OUT, QL, KL, S2, Z, ZT, ZB, ZTB, XZ, T1, T2, LY, WY, AV, W2, WEFF, BEFF, SCAL, PART, PKW, LINWS, AB, LMP, WB, GEMM, total; };
 bool tm_pinv_tiles_supported(int m);
 int tm_pinv_tiles(const float* X, float* Za, float* ZTa, float* Zb, float* ZTb, float* XZ, float* T1T, float* ST, const unsigned* scal,
-                  int m, int iters, float** z_final, hipStream_t st);
+                  int m, int iters, float** z_final, hipStream_t st, float* LY, float* WY);
 
 // transmil_pinv.hip: the whole Moore-Penrose iteration of one layer as ONE launch (one workgroup per head); opt-in, see tm_layer
 bool tm_pinv_fused_supported(int m);
@@ -604,7 +604,7 @@ static TmWs tm_ws(const TmGeom& g) {
     w.S1 = off; off += tm_al((size_t)TM_HEADS * g.npad * g.m * 4);
     w.S3 = off; off += tm_al((size_t)TM_HEADS * g.m * g.npad * 4);
     w.QL = off; off += md; w.KL = off; off += md; w.AV = off; off += md; w.W2 = off; off += md;
-    w.S2 = off; off += mm; w.Z = off; off += mm; w.ZT = off; off += mm; w.ZB = off; off += mm; w.ZTB = off; off += mm; w.XZ = off; off += mm; w.T1 = off; off += mm; w.T2 = off; off += mm;
+    w.S2 = off; off += mm; w.Z = off; off += mm; w.ZT = off; off += mm; w.ZB = off; off += mm; w.ZTB = off; off += mm; w.XZ = off; off += mm; w.T1 = off; off += mm; w.T2 = off; off += mm; w.LY = off; off += mm; w.WY = off; off += mm;
     w.WEFF = off; off += tm_al((size_t)49 * g.Di * 4); w.BEFF = off; off += tm_al((size_t)g.Di * 4);
     w.SCAL = off; off += 256;
     w.PART = off; off += tm_al(tm_attn3_partial_bytes(g.npad, g.Di));   // chunk partials of the fused attn3 leg
@@ -763,7 +763,8 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     bool pinv_fused = tm_pinv_fused_supported(m) && pinv_one;
     if (!pinv_fused && !pinv_chain && tm_pinv_tiles_supported(m)) {
         // default: one wave per 16 x 16 output tile, whole K in registers, exact fp32 MFMA (transmil_pinv.hip): 24 + 1 launches of ~3 us
-        rc = tm_pinv_tiles(S2, Z, (float*)(ws + W.ZT), (float*)(ws + W.ZB), (float*)(ws + W.ZTB), XZ, T1, T2, scal, m, 6, &zc, st);
+        rc = tm_pinv_tiles(S2, Z, (float*)(ws + W.ZT), (float*)(ws + W.ZB), (float*)(ws + W.ZTB), XZ, T1, T2, scal, m, 6, &zc, st,
+                           (float*)(ws + W.LY), (float*)(ws + W.WY));
         if (rc != ACMIL_OK) return rc;
         pinv_fused = true;       // (skips the generic chain below)
     } else if (pinv_fused) {

@@ -245,18 +245,28 @@ int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, fl
 //   P1  y = x z                      -> y (row-major), y^T
 //   P2  a = z y  -> l, w (row-major)        |  b = y y -> b^T          (one launch: first / second half of the grid)
 //   P3  z' = w + 1/4 l b             -> z, z^T (in place: P3 reads neither)
-enum { TQ_Y = 0, TQ_DUAL = 1, TQ_ZF = 2 };
+// Round 4: TWO dependent launches per iteration.  x a = x z y = y y = b, so multiplying the update by x from the left gives the next y
+// from y and b alone:  y' = x z' = 1/4 (13 y - 15 b + (7 y - b) b)  -- the same form as z' with (y, b) in place of (z, a).  P2's second
+// half therefore also leaves ly = 7 y - b and wy = 1/4 (15 ly - 92 y), P3 becomes a dual launch (z' = w + 1/4 l b | y' = wy + 1/4 ly b,
+// both with b^T as the shared B operand) and P1 runs once, before the first iteration: 14 launches per layer instead of 19.
+// (y' is the exact image of the iteration's own map t -> t (13 - 15 t + 7 t^2 - t^3) / 4 on y, whose fixed point 1 is
+//  super-attracting; rounding differs from recomputing x z' by ~1e-7 relative per iteration.  ACMIL_TM_PINV_Y1=1 keeps P1 per iteration.)
+enum { TQ_Y = 0, TQ_DUAL = 1, TQ_ZF = 2, TQ_DUAL2 = 3, TQ_ZF2 = 4 };
 
+// TQ_DUAL2 / TQ_ZF2 (second half of the grid = the y side): aux1 = its elementwise operand, O3 / O4 = its outputs
 template <int M, int EPI>
 __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restrict__ A0_all, const float* __restrict__ BT0_all,
                                                             const float* __restrict__ A1_all, const float* __restrict__ aux_all,
-                                                            float* __restrict__ O0_all, float* __restrict__ O1_all, float* __restrict__ O2_all) {
+                                                            float* __restrict__ O0_all, float* __restrict__ O1_all, float* __restrict__ O2_all,
+                                                            const float* __restrict__ aux1_all = nullptr, float* __restrict__ O3_all = nullptr,
+                                                            float* __restrict__ O4_all = nullptr) {
+    constexpr bool DUAL = (EPI == TQ_DUAL || EPI == TQ_DUAL2 || EPI == TQ_ZF2);
     constexpr int NJ = M / 16, TB = M / 32, NBLK = TB * TB * TP_HEADS;
     // Block -> (head, 32-row band by, 32-column band bx) such that the TB blocks of one (head, by) -- which read the SAME rows of A --
     // sit on one XCD (block b runs on XCD b % 8: used for speed only)
     int L = blockIdx.x;
     bool second = false;                                    // TQ_DUAL: blocks NBLK.. compute b = y y
-    if (EPI == TQ_DUAL && L >= NBLK) { L -= NBLK; second = true; }
+    if (DUAL && L >= NBLK) { L -= NBLK; second = true; }
     const int xcd = L & 7, q = L >> 3;
     const int grp = (q / TB) * 8 + xcd;                     // (head, by) pair, TP_HEADS * TB of them
     const int head = grp / TB, by = grp - head * TB, bx = q - (q / TB) * TB;
@@ -274,8 +284,8 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
     // lane holds C[row0 + i][col], i < 4; the elementwise operands of the epilogue are requested with the panels
     const int row0 = 16 * ti + 4 * kq, col = 16 * tj + r;
     tp_f32x4 ax = {0.f, 0.f, 0.f, 0.f};
-    if ((EPI == TQ_DUAL && !second) || EPI == TQ_ZF) {
-        const float* X = aux_all + hoff;
+    if ((EPI == TQ_DUAL && !second) || EPI == TQ_ZF || EPI == TQ_DUAL2 || EPI == TQ_ZF2) {
+        const float* X = ((second && (EPI == TQ_DUAL2 || EPI == TQ_ZF2)) ? aux1_all : aux_all) + hoff;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ax[i] = X[(size_t)(row0 + i) * M + col];
     }
@@ -294,9 +304,18 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < 4; ++i) O0[(size_t)(row0 + i) * M + col] = v[i];
         *(tp_f32x4*)(O1_all + hoff + (size_t)col * M + row0) = v;
-    } else if constexpr (EPI == TQ_DUAL) {
+    } else if constexpr (EPI == TQ_DUAL || EPI == TQ_DUAL2) {
         if (second) {                                        // b^T (consumed as a B operand)
             *(tp_f32x4*)(O2_all + hoff + (size_t)col * M + row0) = v;
+            if constexpr (EPI == TQ_DUAL2) {                 // + ly = 7 y - b ; wy = 1/4 (15 ly - 92 y)      (ax = y)
+                float* O3 = O3_all + hoff; float* O4 = O4_all + hoff;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float l = 7.0f * ax[i] - v[i];
+                    O3[(size_t)(row0 + i) * M + col] = l;
+                    O4[(size_t)(row0 + i) * M + col] = 0.25f * (15.0f * l - 92.0f * ax[i]);
+                }
+            }
         } else {                                             // l = 7 z - a ; w = 1/4 (15 l - 92 z)      (ax = z)
             float* O0 = O0_all + hoff; float* O1 = O1_all + hoff;
 #pragma unroll
@@ -306,12 +325,13 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
                 O1[(size_t)(row0 + i) * M + col] = 0.25f * (15.0f * l - 92.0f * ax[i]);
             }
         }
-    } else {                                                 // z' = w + 1/4 l b      (ax = w): row-major + transposed
-        float* O0 = O0_all + hoff;
+    } else {                                                 // z' = w + 1/4 l b      (ax = w): row-major + transposed; second half: y'
+        float* O0 = (second ? O3_all : O0_all) + hoff;
+        float* const OT = (second ? O4_all : O1_all);
         tp_f32x4 z;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { z[i] = fmaf(0.25f, v[i], ax[i]); O0[(size_t)(row0 + i) * M + col] = z[i]; }
-        *(tp_f32x4*)(O1_all + hoff + (size_t)col * M + row0) = z;
+        *(tp_f32x4*)(OT + hoff + (size_t)col * M + row0) = z;
     }
 }
 
@@ -332,10 +352,26 @@ bool tm_pinv_tiles_supported(int m) { return m == 64 || m == 128 || m == 192 || 
 
 template <int M>
 static int tm_pinv_tiles_run(const float* X, float* Z, float* ZT, float* Wp, float* BT, float* Y, float* YT, float* Lb,
-                             const unsigned* scal, int iters, float** z_final, hipStream_t st) {
+                             const unsigned* scal, int iters, float** z_final, hipStream_t st, float* LY, float* WY) {
     hipLaunchKernelGGL(tm_pinv_init2_kernel, dim3(256), dim3(256), 0, st, X, M, scal, Z, ZT);
     const unsigned nblk = (M / 32) * (M / 32) * TP_HEADS;
     const dim3 block(256);
+    static const bool y_each = getenv("ACMIL_TM_PINV_Y1") != nullptr;      // A/B knob: recompute y = x z in every iteration (round 3)
+    if (LY && WY && !y_each) {
+        hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_Y>), dim3(nblk), block, 0, st, X, ZT, (const float*)nullptr, (const float*)nullptr, Y, YT, (float*)nullptr,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+        for (int it = 0; it < iters; ++it) {
+            const bool last = it + 1 == iters;
+            // a = z y -> l, w | b = y y -> b^T, ly, wy
+            hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_DUAL2>), dim3(2 * nblk), block, 0, st, Z, YT, Y, Z, Lb, Wp, BT, (const float*)Y, LY, WY);
+            // z' = w + 1/4 l b -> z, z^T | y' = wy + 1/4 ly b -> y, y^T   (the last iteration needs no y')
+            if (last) hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_ZF>), dim3(nblk), block, 0, st, Lb, BT, (const float*)nullptr, Wp, Z, ZT, (float*)nullptr,
+                                         (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+            else hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_ZF2>), dim3(2 * nblk), block, 0, st, Lb, BT, LY, Wp, Z, ZT, (float*)nullptr, (const float*)WY, Y, YT);
+        }
+        *z_final = Z;
+        return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+    }
     for (int it = 0; it < iters; ++it) {
         hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_Y>), dim3(nblk), block, 0, st, X, ZT, (const float*)nullptr, (const float*)nullptr, Y, YT, (float*)nullptr);
         hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_DUAL>), dim3(2 * nblk), block, 0, st, Z, YT, Y, Z, Lb, Wp, BT);
@@ -347,13 +383,13 @@ static int tm_pinv_tiles_run(const float* X, float* Z, float* ZT, float* Wp, flo
 
 // X [H][m][m] -> *z_final = the buffer (Za or Zb) that holds the pseudo-inverse, row-major
 int tm_pinv_tiles(const float* X, float* Za, float* ZTa, float* Zb, float* ZTb, float* XZ, float* T1T, float* ST, const unsigned* scal,
-                  int m, int iters, float** z_final, hipStream_t st) {
+                  int m, int iters, float** z_final, hipStream_t st, float* LY, float* WY) {
     switch (m) {
-        case 64: return tm_pinv_tiles_run<64>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
-        case 128: return tm_pinv_tiles_run<128>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
-        case 192: return tm_pinv_tiles_run<192>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
-        case 256: return tm_pinv_tiles_run<256>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
-        case 384: return tm_pinv_tiles_run<384>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st);
+        case 64: return tm_pinv_tiles_run<64>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st, LY, WY);
+        case 128: return tm_pinv_tiles_run<128>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st, LY, WY);
+        case 192: return tm_pinv_tiles_run<192>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st, LY, WY);
+        case 256: return tm_pinv_tiles_run<256>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st, LY, WY);
+        case 384: return tm_pinv_tiles_run<384>(X, Za, ZTa, Zb, ZTb, XZ, T1T, ST, scal, iters, z_final, st, LY, WY);
     }
     return ACMIL_ERR_UNSUPPORTED;
 }

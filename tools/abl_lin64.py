@@ -34,6 +34,9 @@ if __name__ == "__main__":
             env = dict(os.environ, ACMIL_LIN64="1", ABL_NAME=nm)
             if nm == "lin32":
                 env["ACMIL_LIN64"] = "0"
+            elif nm.startswith("l32_"):      # a variant build of linear.hip run through lin_kernel
+                env["ACMIL_LIN64"] = "0"
+                env["ACMIL_HIP_LIB"] = os.path.join(ROOT, "build", "variants", "libacmil_%s.so" % nm[4:])
             elif nm != "base":
                 env["ACMIL_HIP_LIB"] = os.path.join(ROOT, "build", "variants", "libacmil_%s.so" % nm)
             subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env)
