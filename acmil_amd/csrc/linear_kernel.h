@@ -167,14 +167,6 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
         __syncthreads();
         ntile = (int)__builtin_amdgcn_readfirstlane(*nn_lds);
     }
-#ifdef LIN_STAGGER
-    // experiment: the two workgroups of a CU start half a tile apart (tiles are drawn dynamically: the late one simply takes fewer), so
-    // that one's epilogue stores fall into the other's K loop instead of both storing at once
-    if (blockIdx.x >= gridDim.x / 2) {
-        const int n = (S1 * ND * LIN_STAGGER) >> 13;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     TileInfo T = tile_info(tile);
     // FX & 1: (a, b) of this lane's row of x (row = lane & 31 of the wave tile, clamped like the DMA), one tile ahead
     auto load_ab = [&](const TileInfo& ti) {
