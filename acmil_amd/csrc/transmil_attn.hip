@@ -20,6 +20,7 @@
 #include "ga_common.h"
 
 #define TMA_HEADS 8
+#define TMA_MAX_CHUNKS 128      // key chunks of the attn3 leg (workgroups per head)
 
 __device__ __forceinline__ float tma_xor32(float v) { return __shfl_xor(v, 32); }
 
@@ -215,21 +216,28 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3_kernel(const float* __restri
 // factors, then lane e accumulates its feature over the chunks with the factors read through LDS.
 __global__ __launch_bounds__(256) void tm_attn3_merge_kernel(const float* __restrict__ part_ms, const float* __restrict__ part_o,
                                                             float* __restrict__ AV, int M, int D, int nchunks) {
-    __shared__ float fac[4][64];
+    __shared__ float fac[4][TMA_MAX_CHUNKS];
     const int h = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l = blockIdx.x * 4 + wave;
     if (l >= M) return;
-    float mc = -INFINITY, sc = 0.0f;
-    if (lane < nchunks) {
-        const float* p = part_ms + (((size_t)h * nchunks + lane) * M + l) * 2;
-        mc = p[0]; sc = p[1];
-    }
-    float mx = mc;
+    // lane c holds chunks c and c + 64 (up to TMA_MAX_CHUNKS = 128 chunks)
+    float mc[2] = {-INFINITY, -INFINITY}, sc[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < nchunks) {
+            const float* p = part_ms + (((size_t)h * nchunks + lane + 64 * u) * M + l) * 2;
+            mc[u] = p[0]; sc[u] = p[1];
+        }
+    float mx = fmaxf(mc[0], mc[1]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    const float f = (lane < nchunks) ? __expf(mc - mx) : 0.0f;
-    fac[wave][lane] = f;
-    float den = sc * f;
+    float den = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float f = (lane + 64 * u < nchunks) ? __expf(mc[u] - mx) : 0.0f;
+        fac[wave][lane + 64 * u] = f;
+        den += sc[u] * f;
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) den += __shfl_xor(den, o);       // fixed shuffle tree: deterministic
     const float inv = 1.0f / den;
@@ -583,7 +591,7 @@ int tm_attn_fused_supported(int Di) { return Di == 128 || Di == 256 || Di == 384
 size_t tm_attn3_partial_bytes(int npad, int Di) {
     const int m = Di / 2, d = Di / TMA_HEADS;
     (void)npad;
-    return (size_t)TMA_HEADS * 64 * m * (2 + d) * sizeof(float) + 1024;   // <= 64 chunks (tm_attn3_launch)
+    return (size_t)TMA_HEADS * TMA_MAX_CHUNKS * m * (2 + d) * sizeof(float) + 1024;   // <= TMA_MAX_CHUNKS chunks (tm_attn3_launch)
 }
 
 // ACMIL_TM_ATTN_FP32=1 selects the exact-fp32 MFMA kernels (A/B reference); default = split-f16
@@ -645,7 +653,10 @@ template <int MT>
 static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st) {
     constexpr int M = 32 * MT, D = 8 * MT;
     const int nblk = npad / 32;
-    int nchunks = nblk < 64 ? nblk : 64;
+    // chunks per head: 64 = 512 workgroups = two per CU.  Measured (ACMIL_TM_ATTN3_CHUNKS, whole forward on one box): 64 chunks 2.396 ms,
+    // 96 (three workgroups per CU) 2.414, 128 2.475 -- the leg is not occupancy-limited, more chunks only add partials
+    static const int want = [] { const char* e = getenv("ACMIL_TM_ATTN3_CHUNKS"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > TMA_MAX_CHUNKS ? TMA_MAX_CHUNKS : v); }();
+    int nchunks = nblk < want ? nblk : want;
     const int bpc = (nblk + nchunks - 1) / nchunks;
     nchunks = (nblk + bpc - 1) / bpc;
     float* part_ms = part;
