@@ -22,6 +22,12 @@
 
 #define LIN_CTRL_BYTES 96        // control words of one Linear call (linear.hip::lin_f16x3_run)
 
+// timing-only ablations of lin_kernel (tools/build_lin_variants.sh; WRONG results): 1 no x DMA, 2 no weight DMA, 8 no epilogue stores
+// (accumulators kept alive).  0 in every product build.
+#ifndef LIN_ABL
+#define LIN_ABL 0
+#endif
+
 struct LinArgs {
     const void* x;          // [M, K] row-major, leading dimension ldx (elements), fp32 / fp16 / bf16
     const char* packed;     // fragment stream: chunk c at c * (K/16) * 2 ND KiB
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
     auto dma_piece = [&](auto mc, int u, int slot, unsigned woff, const TileInfo& ti, const unsigned (&xo)[G::XG]) {
         constexpr int m = decltype(mc)::value;
         const unsigned m0v = m0w + slot * G::SLOT;
-        if constexpr (m < G::RW) ga2_dma<-(G::RW - m) * 1024>(woff, ti.wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v);
-        else if constexpr (m < G::NVX) { constexpr int q = m - G::RW; ga2_dma<q * 1024>(xo[q], ti.xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
+        if constexpr (m < G::RW) { if constexpr (!(LIN_ABL & 2)) ga2_dma<-(G::RW - m) * 1024>(woff, ti.wreg0 + (size_t)u * G::WROWS * GA_FRAG_ROW, m0v); }
+        else if constexpr (m < G::NVX) { constexpr int q = m - G::RW; if constexpr (!(LIN_ABL & 1)) ga2_dma<q * 1024>(xo[q], ti.xrow0 + (size_t)u * 16 * G::XE - q * 1024, m0v); }
     };
 #define LIN_DMA_AT(d, ...)                                   \
     do {                                                     \
@@ -351,6 +357,13 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                     }
                 }
             }
+        } else if constexpr (LIN_ABL & 8) {
+            float keep = 0.0f;
+#pragma unroll
+            for (int d = 0; d < ND; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[d][r];
+            if (keep == 123456.789f) a.y[0] = keep;
         } else
         // ======================================================= epilogue: transpose 32 x 32 tiles through the free slot, store rows
         {
