@@ -155,6 +155,9 @@ static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
     return ACMIL_ERR_UNSUPPORTED;
 }
 
+// y stores past the L2 for outputs that exceed the 256 MB Infinity Cache (and are not read back as the residual): see the epilogue
+static int lin_nt_store(int M, int n_out, float beta) { return beta == 0.0f && (size_t)M * n_out * 4 > ((size_t)256 << 20); }
+
 // Control words of a call (32-bit, at `workspace`): 2 range status, 4 / 5 finished-workgroup counters of the main / remainder launch,
 // 8..15 / 16..23 their per-XCD tile queues (LIN_CTRL_BYTES = 96 bytes in all).  init: zero them here (the C entry: any 256-byte scratch will do); !init: the caller zeroed them once
 // and every launch leaves the counters at zero (TransMIL: one memset per forward instead of one per Linear layer; the status word
@@ -173,6 +176,7 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
     a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
+    a.nt_store = lin_nt_store(M, n_out, beta);
     a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
     const LinPlan P = lin_plan(n_out);
     int rc = ACMIL_OK;
@@ -206,6 +210,7 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = 0; a.beta = 0.0f; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0; a.status = nullptr;
     a.rowab = rowab; a.zrows = zrows; a.lm_part = lm_part; a.lm_l = lm_l; a.lm_cols = lm_part ? lm_cols : 0;
+    a.nt_store = lin_nt_store(M, n_out, 0.0f);
     const LinPlan P = lin_plan(n_out);
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
@@ -245,7 +250,7 @@ extern "C" int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int 
     unsigned* ctr = (unsigned*)workspace;
     if (hipMemsetAsync(ctr, 0, LIN_CTRL_BYTES, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
-    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
+    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0; a.nt_store = 0;
     a.x = h; a.ldx = ldh; a.M = N; a.K = L; a.bias = bias_vu; a.act = 2; a.beta = 0.0f; a.y = nullptr; a.ldy = 0;
     a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr + 8; a.done = nullptr;
     a.ww = Ww; a.bw = bw; a.scores = A; a.kb = K; a.status = nullptr;

@@ -385,7 +385,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if (a.act == 1) { v[0] = fmaxf(v[0], 0.0f); v[1] = fmaxf(v[1], 0.0f); v[2] = fmaxf(v[2], 0.0f); v[3] = fmaxf(v[3], 0.0f); }
                         if (a.beta != 0.0f) v = v + old[g] * a.beta;
                         }
-                        if (live) *(f32x4*)(yrow + 32 * c + 8 * g) = v;
+                        if (live) {
+                            if (a.nt_store) __builtin_nontemporal_store(v, (f32x4*)(yrow + 32 * c + 8 * g));
+                            else *(f32x4*)(yrow + 32 * c + 8 * g) = v;
+                        }
                     }
                     if constexpr (LMP) {
                         // landmark column sums: through the wave-private transposed tile, as lin_kernel (q / k columns only)
