@@ -21,6 +21,14 @@
 
 #define TMA_HEADS 8
 #define TMA_MAX_CHUNKS 128      // key chunks of the attn3 leg (workgroups per head)
+// wave priority inside the matrix phases of the split-f16 legs (0 in the softmax / staging phases): the co-resident wave's VALU
+// no longer takes issue slots from a running MFMA chain (attn1 leg 157 -> 149 us; 2 measured the same as 1)
+#ifndef TMA_PRIO
+#define TMA_PRIO 1
+#endif
+#ifndef TMA_PRIO3
+#define TMA_PRIO3 0
+#endif
 
 __device__ __forceinline__ float tma_xor32(float v) { return __shfl_xor(v, 32); }
 
@@ -374,6 +382,9 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         asm volatile("" : "+v"(lbk), "+v"(lbw));
         const char* klh_b = (const char*)KLh + lbk; const char* kll_b = (const char*)KLl + lbk;
         const char* w2h_b = (const char*)W2h + lbw; const char* w2l_b = (const char*)W2l + lbw;
+#if TMA_PRIO
+        __builtin_amdgcn_s_setprio(TMA_PRIO);
+#endif
 #pragma unroll
         for (int st = 0; st < KS; ++st) {
 #pragma unroll
@@ -389,6 +400,9 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         // loop they sat on top of the score accumulators' peak and hipcc parked them in scratch: a store waiting on an HBM load)
         if (rb + stride < nblk) load_q(rb + stride);
         __builtin_amdgcn_sched_barrier(0);
+#if TMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float m2 = -INFINITY;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -410,6 +424,9 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         // the 64-row window of v for the convolution (4 K steps x ET x 8 rows per lane) is fetched INSIDE the product below, two K
         // steps at a time at the points where a third of the softmax accumulators has just died: the loads fly under ~50 MFMAs
         // and the register peak stays where it was (issued after the leg they cost 87 us per layer: 210 vs 123 us per launch)
+#if TMA_PRIO
+        __builtin_amdgcn_s_setprio(TMA_PRIO);
+#endif
         float vw[4][ET][8];
         // addresses: wave-uniform base (block, K step, row j, e tile) + one 32-bit lane offset (K half, feature); features e >= D of
         // the last e tile read a clamped column -- those accumulator rows are never stored.  The first and the last block reach 16
@@ -464,6 +481,9 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
                 }
             }
         }
+#if TMA_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float* op = OUT + (size_t)(rb * 32 + i31) * Di + h * D;
 #pragma unroll
         for (int et = 0; et < ET; ++et)
@@ -530,18 +550,24 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
                 vh[buf][p] = x; vl[buf][p] = (_Float16)(vreg[j] - (float)x);
             }
         }
-        __syncthreads();
+        __syncthreads();      // (an LDS-only barrier with the prefetch issued ahead of it measured the same: 149.3 vs 150.8 us)
         if (kb + 1 < kb1) load_kv(kb + 1);
 
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+#if TMA_PRIO3
+        __builtin_amdgcn_s_setprio(TMA_PRIO3);
+#endif
 #pragma unroll
         for (int st = 0; st < KS; ++st) {
             const int off = i31 * LDK + 16 * st + 8 * hi;
             const tma_h8 ah = *(const tma_h8*)(&kh[buf][off]), al = *(const tma_h8*)(&kl[buf][off]);
             TMA_MFMA3(S, ah, al, qh[st], ql[st]);
         }
+#if TMA_PRIO3
+        __builtin_amdgcn_s_setprio(0);
+#endif
         float bm = S[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) bm = fmaxf(bm, S[r]);
@@ -558,6 +584,9 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
         for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[et][r] *= alpha;
+#if TMA_PRIO3
+        __builtin_amdgcn_s_setprio(TMA_PRIO3);
+#endif
 #pragma unroll
         for (int e2 = 0; e2 < 2; ++e2) {
             float pv[8];
@@ -572,6 +601,9 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
                 TMA_MFMA3(o[et], wh, wl, ph, pl);
             }
         }
+#if TMA_PRIO3
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     const size_t row = ((size_t)h * nchunks + chunk) * M + 32 * wave + i31;
     if (hi == 0) { part_ms[row * 2] = m_run; part_ms[row * 2 + 1] = s_run; }
