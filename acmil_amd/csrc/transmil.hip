@@ -515,10 +515,13 @@ __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ 
 // operand is a natural 8-byte pair -- the halo values of two adjacent channels (one ds_read_b64), their two weights -- and a tap is one
 // v_pk_fma_f32 for two outputs: half the VALU instructions and half the LDS instructions of the scalar kernel above
 // (1.9 GFMA per slide were 181 us there: VALU issue, not HBM -- 1.7 TB/s).  C % 64 == 0 (else the scalar kernel).
+// (In fact a channel QUAD per thread and half a pixel row: see the store note inside.)
 __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
                                                       const float* __restrict__ weff, const float* __restrict__ beff) {
     __shared__ __attribute__((aligned(16))) float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
-    const int cp = threadIdx.x & 31, py = threadIdx.x >> 5;          // channel pair, tile row
+    // thread = (channel QUAD cq, tile row py, half of the row's 8 pixels): 4 channels x 4 pixels, so that an output pixel is ONE
+    // 16-byte store (a store instruction costs the CU ~75 cycles whatever its width: 8-byte stores were 52 us of this kernel)
+    const int cq = threadIdx.x & 15, py = (threadIdx.x >> 4) & 7, ph = threadIdx.x >> 7;
     const int cb = blockIdx.x * 64;
     const int tiles_x = (side + TM_PT - 1) / TM_PT;
     const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
@@ -531,30 +534,33 @@ __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restric
         *(f32x4*)(tile + e * 64 + 4 * c4) = v;
     }
     __syncthreads();
-    const int c = cb + 2 * cp, y = ty0 + py;
+    const int c = cb + 4 * cq, y = ty0 + py, px0 = 4 * ph;
     if (y >= side) return;
-    const f32x2 b = *(const f32x2*)(beff + c);
-    f32x2 acc[TM_PT];
+    const f32x4 b = *(const f32x4*)(beff + c);
+    f32x2 acc[4][2];
 #pragma unroll
-    for (int px = 0; px < TM_PT; ++px) acc[px] = b;
-    // one kernel row at a time: its 7 weight pairs (L1-resident: 49 x C floats per launch) and the 14 halo pairs of that row --
-    // holding all 49 pairs in registers (98) left one wave per SIMD or 556 B of scratch
+    for (int px = 0; px < 4; ++px) { acc[px][0] = f32x2{b[0], b[1]}; acc[px][1] = f32x2{b[2], b[3]}; }
+    // one kernel row at a time: its 7 weight quads (L1-resident: 49 x C floats per launch) and the 10 halo quads this half row needs
 #pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
-        f32x2 w[7];
+        f32x4 w[7];
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) w[kx] = *(const f32x2*)(weff + (size_t)(ky * 7 + kx) * C + c);
-        f32x2 v[TM_PT + 6];
+        for (int kx = 0; kx < 7; ++kx) w[kx] = *(const f32x4*)(weff + (size_t)(ky * 7 + kx) * C + c);
+        f32x4 v[10];
 #pragma unroll
-        for (int i = 0; i < TM_PT + 6; ++i) v[i] = *(const f32x2*)(tile + ((py + ky) * (TM_PT + 6) + i) * 64 + 2 * cp);
+        for (int i = 0; i < 10; ++i) v[i] = *(const f32x4*)(tile + ((py + ky) * (TM_PT + 6) + px0 + i) * 64 + 4 * cq);
 #pragma unroll
-        for (int px = 0; px < TM_PT; ++px)
+        for (int px = 0; px < 4; ++px)
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) acc[px] = __builtin_elementwise_fma(w[kx], v[px + kx], acc[px]);
+            for (int kx = 0; kx < 7; ++kx) {
+                acc[px][0] = __builtin_elementwise_fma(f32x2{w[kx][0], w[kx][1]}, f32x2{v[px + kx][0], v[px + kx][1]}, acc[px][0]);
+                acc[px][1] = __builtin_elementwise_fma(f32x2{w[kx][2], w[kx][3]}, f32x2{v[px + kx][2], v[px + kx][3]}, acc[px][1]);
+            }
     }
 #pragma unroll
-    for (int px = 0; px < TM_PT; ++px)
-        if (tx0 + px < side) *(f32x2*)(out + ((size_t)y * side + tx0 + px) * C + c) = acc[px];
+    for (int px = 0; px < 4; ++px)
+        if (tx0 + px0 + px < side)
+            *(f32x4*)(out + ((size_t)y * side + tx0 + px0 + px) * C + c) = f32x4{acc[px][0][0], acc[px][0][1], acc[px][1][0], acc[px][1][1]};
 }
 
 __global__ void tm_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
