@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         if (a.beta != 0.0f) v = v + old[g] * a.beta;
                         }
                         if (live) {
-                            if (a.nt_store) __builtin_nontemporal_store(v, (f32x4*)(yrow + 32 * c + 8 * g));
+                            if (a.nt_store) lin_store_nt(yrow + 32 * c + 8 * g, v);
                             else *(f32x4*)(yrow + 32 * c + 8 * g) = v;
                         }
                     }

@@ -28,6 +28,13 @@
 #define LIN_ABL 0
 #endif
 
+// 16-byte store past the L2 (`nt`).  Inline asm: under a run-time condition hipcc merges `__builtin_nontemporal_store` with the plain
+// store of the other branch and drops the hint (checked in the ISA: 24 plain stores).  s_nop 1: the data registers must not be
+// overwritten before the store has read them (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void lin_store_nt(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
 struct LinArgs {
     const void* x;          // [M, K] row-major, leading dimension ldx (elements), fp32 / fp16 / bf16
     const char* packed;     // fragment stream: chunk c at c * (K/16) * 2 ND KiB
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
                         // outputs larger than the Infinity Cache are streamed past the L2 (non-temporal): written once, read by a later
                         // kernel from HBM anyway, and kept out of the L2 they no longer evict the x rows the other column chunks of
                         // the row tile are about to re-read (to_qkv: 910 -> 741 MB per launch, 310 -> 302 us)
-                        if (a.nt_store) __builtin_nontemporal_store(v, (f32x4*)(yc + (size_t)row * a.ldy));
+                        if (a.nt_store) lin_store_nt(yc + (size_t)row * a.ldy, v);
                         else *(f32x4*)(yc + (size_t)row * a.ldy) = v;
                     }
                 }
