@@ -5,7 +5,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 32, 128), (2000, 384, 384)])
+@pytest.mark.parametrize("m,k,n_out", [(300, 96, 128), (1, 64, 256), (777, 384, 1152), (5000, 768, 384), (4097, 512, 640), (129, 32, 128), (2000, 384, 384),
+                                      (1536, 64, 512), (70000, 128, 384)])      # 24 tiles on 8 per-XCD queues of unequal length; a long launch (dynamic draws from every queue)
 @pytest.mark.parametrize("xdt", [torch.float32, torch.float16, torch.bfloat16])
 def test_linear_matches_fp64(m, k, n_out, xdt):
     from acmil_amd import ops
