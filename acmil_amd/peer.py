@@ -52,7 +52,8 @@ class PeerReducer:
                 fs, args_s = hs
                 ff, args_f = hf
                 self._peer_slots.append(fs(*args_s)); self._peer_flags.append(ff(*args_f))      # mapped into this process
-        dist.barrier(group=group)                      # nobody leaves before every mapping exists
+        # (no barrier here: a rank whose mapping failed has left through an exception, and a collective it never enters would hang the
+        #  others -- try_create's all-reduce of the outcome is the rendezvous; the slots stay alive as long as this object does)
         self._flag_ptrs = (ctypes.c_void_p * world)(*[t.data_ptr() for t in self._peer_flags])
         self._slot_ptrs = [(ctypes.c_void_p * world)(*[t[par].data_ptr() for t in self._peer_slots]) for par in (0, 1)]
         self.step_id = 0
