@@ -318,3 +318,42 @@ def test_two_rank_direct_reduce_on_one_gpu():
                         "--master-port", str(port), worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "PEER_OK" in r.stdout, r.stdout[-3000:]
 
+
+def test_peer_wait_times_out_cleanly_and_stays_out():
+    """acmil_adamw_step_peer with a peer whose flag never arrives: after timeout_s the launch sets the error word and changes NOTHING;
+    every later launch returns at once (one timeout per dead peer, not one per step); a published peer makes the same call succeed."""
+    import ctypes
+    from acmil_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    n = 1000
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(n, generator=g).to(dev); p0 = p.clone()
+    m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    slots = torch.randn(2, n + 1, generator=g).to(dev)
+    slots[:, n] = 0.0                                         # range flag element
+    flags = torch.zeros(8, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+    sp = (ctypes.c_void_p * 2)(slots[0].data_ptr(), slots[1].data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step(step_id, timeout):
+        rc = lib.acmil_adamw_step_peer(p.data_ptr(), m.data_ptr(), v.data_ptr(), n, sp, flags.data_ptr(), 2, 0, step_id, timeout, err.data_ptr(),
+                                       1e-2, 0.9, 0.999, 1e-8, 0.0, 1, 1, skipped.data_ptr(), None, None, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+    import time
+    t0 = time.time(); step(1, 0.05); t_first = time.time() - t0          # rank 0 waits for rank 1's flag: never raised
+    assert int(err.item()) == 1 and torch.equal(p, p0) and 0.04 < t_first < 2.0
+    t0 = time.time(); step(2, 0.05); t_second = time.time() - t0         # error word set: returns at once
+    assert torch.equal(p, p0) and t_second < 0.03
+    err.zero_(); flags[1] = 1                                            # the peer has published step 1
+    step(1, 0.05)
+    assert int(err.item()) == 0 and not torch.equal(p, p0)
+    gavg = (slots[0, :n] + slots[1, :n]) / 2
+    ref = torch.optim.AdamW([torch.nn.Parameter(p0.clone())], lr=1e-2, weight_decay=0.0)
+    ref.param_groups[0]["params"][0].grad = gavg.clone()
+    ref.step()
+    assert (ref.param_groups[0]["params"][0].data - p).abs().max() < 1e-6
+
