@@ -19,6 +19,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "ga_common.h"
 
 extern "C" int acmil_gemm_f32(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void tm_sim2_softmax_kernel(const float* __res
                                                              int m, int d, float scale) {
     __shared__ float qs[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long r = (long long)blockIdx.x * 4 + wave;      // row index over [H][m]
+    const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + wave;      // row index over [H][m]; 2 or 4 rows per workgroup
     const int h = (int)(r / m);
     const bool live = r < (long long)TM_HEADS * m;
     const float* q = QL + (size_t)(live ? r : 0) * d;
@@ -346,6 +348,47 @@ __global__ __launch_bounds__(1024) void tm_pinv_maxsum_kernel(const float* __res
         float r = 0.0f, c = 0.0f;
         for (int w = 0; w < 16; ++w) { r = fmaxf(r, red[0][w]); c = fmaxf(c, red[1][w]); }
         atomicMax(scal + 0, __float_as_uint(r)); atomicMax(scal + 1, __float_as_uint(c));
+    }
+}
+
+// The same two maxima with short workgroups (round 4: the chain runs beside the attn3 leg on the side stream, where only workgroups
+// of at most two waves find room -- tools/coresident_probe.hip --, and 192 dependent loads per thread made the kernel above 15 us
+// of latency).  grid (ceil(m / 16), H), 128 threads: column sums of 16 columns -- thread (column c = tid & 15, row group g = tid >> 4)
+// adds rows g, g + 8, ... in index order, the 8 partials are added in group order (fixed order: reproducible) --, and the row sums
+// of 16 rows, one wave per eight rows.
+__global__ __launch_bounds__(128) void tm_pinv_maxsum2_kernel(const float* __restrict__ x, int m, unsigned* __restrict__ scal) {
+    __shared__ float part[8][17];
+    __shared__ float rmx[2];
+    const int h = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* X = x + (size_t)h * m * m;
+    {
+        const int c = 16 * b + (tid & 15), g = tid >> 4;
+        float cs = 0.0f;
+        if (c < m) {
+#pragma unroll 8
+            for (int i = g; i < m; i += 8) cs += fabsf(X[(size_t)i * m + c]);
+        }
+        part[g][tid & 15] = cs;
+    }
+    float rmax = 0.0f;
+    for (int q = 0; q < 8; ++q) {
+        const int i = 16 * b + 8 * wave + q;
+        float rs = 0.0f;
+        if (i < m)
+            for (int j = lane; j < m; j += 64) rs += fabsf(X[(size_t)i * m + j]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) rs += __shfl_xor(rs, o);
+        rmax = fmaxf(rmax, rs);
+    }
+    if (lane == 0) rmx[wave] = rmax;
+    __syncthreads();
+    if (tid < 16) {
+        float cs = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) cs += part[g][tid];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) cs = fmaxf(cs, __shfl_xor(cs, o));
+        if (tid == 0) { atomicMax(scal + 0, __float_as_uint(fmaxf(rmx[0], rmx[1]))); atomicMax(scal + 1, __float_as_uint(cs)); }
     }
 }
 
@@ -575,7 +618,7 @@ int tm_attn_fused_supported(int Di);
 size_t tm_attn3_partial_bytes(int npad, int Di);
 int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
                    const float* convw, int* conv_done);
-int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st);
+int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st, bool shared);
 
 struct TmGeom {
     int N, D, Di, C, side, nsq, n, m, npad, pad, l, d;
@@ -645,6 +688,48 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
     return tm_ws(tm_geom(N, D, Di, C)).total;
 }
 
+
+// ------------------------------------------------------------------------------------------------ side stream (round 4)
+// Two chains of a TransLayer are independent between the landmark means and W2 = attn2^+ (attn3 v): the Moore-Penrose chain
+// (sim2 softmax -> max sums -> 14 small launches, each bound by its own latency: ~170 us of a mostly idle GPU) and the attn3 leg
+// (one matrix-pipe-bound launch + merge, ~150 us).  They run side by side: the chain goes to a library-owned non-blocking
+// stream of HIGH priority (its workgroups are short and latency-critical; the attention leg leaves a wave slot per SIMD free),
+// forked from / joined to the caller's stream with events.  One side stream and one event pair per device; the enqueue of a
+// forward holds a lock, so concurrent callers cannot interleave each other's record / wait pairs.  ACMIL_TM_SIDE_STREAM=0: serial.
+struct TmSide { hipStream_t s; hipEvent_t fork, join; int state; };      // state: 0 = untried, 1 = ready, -1 = unavailable
+static std::mutex tm_side_mutex;
+static TmSide* tm_side() {
+    static const bool off = [] { const char* e = getenv("ACMIL_TM_SIDE_STREAM"); return e && e[0] == '0'; }();
+    if (off) return nullptr;
+    static TmSide side[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    TmSide& t = side[dev];
+    if (t.state == 0) {
+        int least = 0, greatest = 0;
+        t.state = -1;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
+        { const char* e = getenv("ACMIL_TM_SIDE_PRIO"); if (e && e[0] == '0') greatest = least; }      // A/B knob: normal priority
+        if (hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, greatest) == hipSuccess &&
+            hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess)
+            t.state = 1;
+        else (void)hipGetLastError();
+    }
+    return t.state == 1 ? &t : nullptr;
+}
+// side stream continues from what `st` holds now
+static bool tm_fork(TmSide* sd, hipStream_t st) {
+    return sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->s, sd->fork, 0) == hipSuccess;
+}
+// the side stream's work so far is marked; the caller waits for sd->join where it needs it
+static int tm_join_later(TmSide* sd) { return hipEventRecord(sd->join, sd->s) == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH; }
+// `st` continues after what the side stream holds now
+static int tm_join(TmSide* sd, hipStream_t st) {
+    if (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(st, sd->join, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    return ACMIL_OK;
+}
+
 #define TM_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH; } while (0)
 #define TM_GEMM(...) do { int rc_ = acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 // nn.Linear products (activations x weights, both K-contiguous): split-f16 MFMA, ~1e-6 relative; ACMIL_TM_FP32_GEMM=1 keeps them exact
@@ -697,7 +782,7 @@ static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) 
 
 // one TransLayer in place on X [npad][Di] (token i at row pad + i):  X[pad:] += to_out(attention(LayerNorm(X[pad:])))
 static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st, char* pk_qkv = nullptr,
-                    char* pk_out = nullptr, const float* wbeta = nullptr) {
+                    char* pk_out = nullptr, const float* wbeta = nullptr, TmSide* side = nullptr) {
     const int Di = g.Di, m = g.m, d = g.d, npad = g.npad, H = TM_HEADS;
     float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV) + (size_t)TM_QKV_GUARD * 3 * g.Di; float* S1 = (float*)(ws + W.S1);
     float* S3 = (float*)(ws + W.S3); float* OUT = (float*)(ws + W.OUT); float* QL = (float*)(ws + W.QL);
@@ -744,19 +829,30 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_GEMM(0, 1, npad, m, d, scale, QKV, 3 * Di, d, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S1, m, (long long)npad * m, nullptr, 0, nullptr, H, gws, st);
     rc = tm_softmax_short(S1, (long long)H * npad, m, st); if (rc != ACMIL_OK) return rc;
     }
-    // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration
+    // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration -- on the side stream beside the attn3 leg where both
+    // run on their own kernels and scratch (the generic-GEMM paths share the split-K workspace: serial)
+    const hipStream_t st_main = st;
+    static const bool pinv_knobs = getenv("ACMIL_TM_PINV_FUSED") != nullptr || getenv("ACMIL_TM_PINV_CHAIN") != nullptr;
+    const bool forked = fused && d % 4 == 0 && d <= 128 && m <= 512 && tm_pinv_tiles_supported(m) && !pinv_knobs && tm_fork(side, st);
+    static const bool side_swap = getenv("ACMIL_TM_SIDE_SWAP") != nullptr;        // A/B knob: the attn3 leg on the side stream instead
+    const hipStream_t st_chain = (forked && !side_swap) ? side->s : st_main, st_leg = (forked && side_swap) ? side->s : st_main;
+    st = st_chain;
     if (d % 4 == 0 && d <= 128 && m <= 512) {
-        const unsigned blocks = (unsigned)(((long long)H * m + 3) / 4);
-        if (m <= 64) hipLaunchKernelGGL(tm_sim2_softmax_kernel<1>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
-        else if (m <= 128) hipLaunchKernelGGL(tm_sim2_softmax_kernel<2>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
-        else if (m <= 256) hipLaunchKernelGGL(tm_sim2_softmax_kernel<4>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
-        else hipLaunchKernelGGL(tm_sim2_softmax_kernel<8>, dim3(blocks), dim3(256), 0, st, QL, KL, S2, m, d, scale);
+        // two-wave workgroups: beside the attn3 leg (two 6-wave workgroups of 128 VGPRs per CU = 4, 4, 2, 2 waves on the four SIMDs) a
+        // workgroup of more than two waves finds no room until that launch retires (tools/coresident_probe.hip)
+        const unsigned blocks = (unsigned)(((long long)H * m + 1) / 2);
+        if (m <= 64) hipLaunchKernelGGL(tm_sim2_softmax_kernel<1>, dim3(blocks), dim3(128), 0, st, QL, KL, S2, m, d, scale);
+        else if (m <= 128) hipLaunchKernelGGL(tm_sim2_softmax_kernel<2>, dim3(blocks), dim3(128), 0, st, QL, KL, S2, m, d, scale);
+        else if (m <= 256) hipLaunchKernelGGL(tm_sim2_softmax_kernel<4>, dim3(blocks), dim3(128), 0, st, QL, KL, S2, m, d, scale);
+        else hipLaunchKernelGGL(tm_sim2_softmax_kernel<8>, dim3(blocks), dim3(128), 0, st, QL, KL, S2, m, d, scale);
         TM_CHECK_LAUNCH();
     } else {
         TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
         rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
     }
-    hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
+    static const bool maxsum_old = getenv("ACMIL_TM_MAXSUM_OLD") != nullptr;       // A/B knob: one 16-wave workgroup per head
+    if (maxsum_old) hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
+    else hipLaunchKernelGGL(tm_pinv_maxsum2_kernel, dim3((m + 15) / 16, H), dim3(128), 0, st, S2, m, scal);
     TM_CHECK_LAUNCH();
     float* zc = Z; float* zn = T2;     // ping-pong z
     // ACMIL_TM_PINV_FUSED=1: ONE launch for the 24 products (transmil_pinv.hip: one 8-wave workgroup per head, operands staged
@@ -789,9 +885,12 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         TM_PINV_GEMM(0, 0, m, m, m, 0.25f, zc, m, mm, T1, ACMIL_DTYPE_F32, m, mm, 0.0f, spare, m, mm, nullptr, 0, nullptr, H, gws, st);
         zn = spare; float* t = zc; zc = zn; zn = t;
     }
+    st = st_main;
     if (fused) {
         // AV = softmax_n(scale q_l k^T) v  [H, m, d]   (chunk partials in their own workspace region)
-        rc = tm_attn3_fused(QKV, QL, AV, (float*)(ws + W.PART), npad, Di, scale, st); if (rc != ACMIL_OK) return rc;
+        rc = tm_attn3_fused(QKV, QL, AV, (float*)(ws + W.PART), npad, Di, scale, st_leg, forked);
+        if (forked) { const int rj = tm_join(side, st); if (rc == ACMIL_OK) rc = rj; }       // (joined even after a failed launch)
+        if (rc != ACMIL_OK) return rc;
     } else {
     // sim3 = scale q_l k^T [H, m, npad] ; softmax over npad
     TM_GEMM(0, 1, m, npad, d, scale, QL, d, md, QKV + Di, ACMIL_DTYPE_F32, 3 * Di, d, 0.0f, S3, npad, (long long)m * npad, nullptr, 0, nullptr, H, gws, st);
@@ -835,6 +934,8 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     const TmGeom g = tm_geom(N, D, Di, C);
     const TmWs W = tm_ws(g);
     char* ws = (char*)workspace;
+    std::lock_guard<std::mutex> side_lock(tm_side_mutex);      // one forward at a time records / waits on the side stream's events
+    TmSide* side = tm_side();
     float* XA = (float*)(ws + W.XA); float* XB = (float*)(ws + W.XB); float* LN = (float*)(ws + W.LN);
     float* weff = (float*)(ws + W.WEFF); float* beff = (float*)(ws + W.BEFF);
     void* gws = ws + W.GEMM;
@@ -843,7 +944,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     if (hipMemsetAsync(ws + W.LINWS, 0, 96, st) != hipSuccess) return ACMIL_ERR_LAUNCH;        // (LIN_CTRL_BYTES)
     // the fragment streams of the five Linear layers in ONE launch (the library keeps no state between calls: packed per forward)
     char* pk1 = nullptr; char* pkq[2] = {nullptr, nullptr}; char* pko[2] = {nullptr, nullptr};
-    bool fold_ln = false;
+    bool fold_ln = false, packs_forked = false;
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};
     TmLayerW l2 = {layer2[0], layer2[1], layer2[2], layer2[3], layer2[4], layer2[5]};
     {
@@ -859,14 +960,19 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
             static const bool ln_pass = getenv("ACMIL_TM_LN_PASS") != nullptr;
             fold_ln = !ln_pass;
             const float* cs[5] = {nullptr, fold_ln ? l1.norm_w : nullptr, nullptr, fold_ln ? l2.norm_w : nullptr, nullptr};
-            const int rp = lin_pack_multi(Wp, ldw, no, Kk, outp, 5, st, cs);
-            if (rp != ACMIL_OK) return rp;
-            if (fold_ln) {
+            // fc1's stream is all the first product needs; the four layer streams and W beta are formed beside it on the side stream
+            packs_forked = tm_fork(side, st);
+            const hipStream_t sp = packs_forked ? side->s : st;
+            int rp = lin_pack_multi(Wp, ldw, no, Kk, outp, packs_forked ? 1 : 5, st, cs);
+            if (rp == ACMIL_OK && packs_forked) rp = lin_pack_multi(Wp + 1, ldw + 1, no + 1, Kk + 1, outp + 1, 4, sp, cs + 1);
+            if (rp == ACMIL_OK && fold_ln) {
                 float* wb = (float*)(ws + W.WB);
                 TmWbJobs J = {{l1.qkv_w, l2.qkv_w}, {l1.norm_b, l2.norm_b}, {wb, wb + 3 * Di}};
-                hipLaunchKernelGGL(tm_wbeta_kernel, dim3((3 * Di + 3) / 4, 2), dim3(256), 0, st, J, 3 * Di, Di);
-                TM_CHECK_LAUNCH();
+                hipLaunchKernelGGL(tm_wbeta_kernel, dim3((3 * Di + 3) / 4, 2), dim3(256), 0, sp, J, 3 * Di, Di);
+                if (hipGetLastError() != hipSuccess) rp = ACMIL_ERR_LAUNCH;
             }
+            if (packs_forked) { const int rj = tm_join_later(side); if (rp == ACMIL_OK) rp = rj; }
+            if (rp != ACMIL_OK) return rp;
         }
     }
     // fc1 + relu straight into the token rows, then cls / wrap-around / front padding
@@ -878,7 +984,8 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     TM_CHECK_LAUNCH();
     const float* wb = (const float*)(ws + W.WB);
-    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr); if (rc != ACMIL_OK) return rc;
+    if (packs_forked && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;      // the layer streams are packed
+    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr, side); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
     // PPEG: cls passthrough + combined depth-wise 7x7
     hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
@@ -895,7 +1002,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     TM_CHECK_LAUNCH();
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
-    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1], fold_ln ? wb + 3 * Di : nullptr); if (rc != ACMIL_OK) return rc;
+    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1], fold_ln ? wb + 3 * Di : nullptr, side); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
     // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
     hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);

@@ -682,12 +682,15 @@ int tm_attn1_fused(const float* QKV, const float* KL, const float* W2, float* OU
 }
 
 template <int MT>
-static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st) {
+static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st, bool shared) {
     constexpr int M = 32 * MT, D = 8 * MT;
     const int nblk = npad / 32;
     // chunks per head: 64 = 512 workgroups = two per CU.  Measured (ACMIL_TM_ATTN3_CHUNKS, whole forward on one box): 64 chunks 2.396 ms,
-    // 96 (three workgroups per CU) 2.414, 128 2.475 -- the leg is not occupancy-limited, more chunks only add partials
-    static const int want = [] { const char* e = getenv("ACMIL_TM_ATTN3_CHUNKS"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > TMA_MAX_CHUNKS ? TMA_MAX_CHUNKS : v); }();
+    // 96 (three workgroups per CU) 2.414, 128 2.475 -- the leg is not occupancy-limited, more chunks only add partials.
+    // shared = the Moore-Penrose chain runs beside this launch on the side stream (transmil.hip): 32 chunks = ONE workgroup per CU leave
+    // that chain room on every SIMD -- the leg alone takes 173 instead of 150 us, the pair 234 us instead of 266 (forward 2.18 vs 2.21 ms)
+    static const int forced = [] { const char* e = getenv("ACMIL_TM_ATTN3_CHUNKS"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > TMA_MAX_CHUNKS ? TMA_MAX_CHUNKS : v); }();
+    const int want = forced ? forced : (shared ? 32 : 64);
     int nchunks = nblk < want ? nblk : want;
     const int bpc = (nblk + nchunks - 1) / nchunks;
     nchunks = (nblk + bpc - 1) / bpc;
@@ -700,12 +703,12 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
-int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st) {
+int tm_attn3_fused(const float* QKV, const float* QL, float* AV, float* part, int npad, int Di, float scale, hipStream_t st, bool shared) {
     switch (Di) {
-        case 128: return tm_attn3_launch<2>(QKV, QL, AV, part, npad, Di, scale, st);
-        case 256: return tm_attn3_launch<4>(QKV, QL, AV, part, npad, Di, scale, st);
-        case 384: return tm_attn3_launch<6>(QKV, QL, AV, part, npad, Di, scale, st);
-        case 512: return tm_attn3_launch<8>(QKV, QL, AV, part, npad, Di, scale, st);
+        case 128: return tm_attn3_launch<2>(QKV, QL, AV, part, npad, Di, scale, st, shared);
+        case 256: return tm_attn3_launch<4>(QKV, QL, AV, part, npad, Di, scale, st, shared);
+        case 384: return tm_attn3_launch<6>(QKV, QL, AV, part, npad, Di, scale, st, shared);
+        case 512: return tm_attn3_launch<8>(QKV, QL, AV, part, npad, Di, scale, st, shared);
     }
     return ACMIL_ERR_UNSUPPORTED;
 }

@@ -254,6 +254,10 @@ int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, fl
 enum { TQ_Y = 0, TQ_DUAL = 1, TQ_ZF = 2, TQ_DUAL2 = 3, TQ_ZF2 = 4 };
 
 // TQ_DUAL2 / TQ_ZF2 (second half of the grid = the y side): aux1 = its elementwise operand, O3 / O4 = its outputs
+// Workgroups of TWO waves (round 4): the chain runs on a side stream beside the attn3 leg, whose two 6-wave workgroups of 128 VGPRs
+// leave room on two of a CU's four SIMDs only -- a four-wave workgroup waited for that launch to retire (tools/coresident_probe.hip).
+// A 32 x 32 block is two workgroups (tile rows).  The launch bound stays 256 (launched with 128 threads): under it hipcc keeps the
+// m = 192 instances at 128 registers per wave -- two of them fit a half-free SIMD -- and the wider ones free of scratch.
 template <int M, int EPI>
 __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restrict__ A0_all, const float* __restrict__ BT0_all,
                                                             const float* __restrict__ A1_all, const float* __restrict__ aux_all,
@@ -265,15 +269,15 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
     // Block -> (head, 32-row band by, 32-column band bx) such that the TB blocks of one (head, by) -- which read the SAME rows of A --
     // sit on one XCD (block b runs on XCD b % 8: used for speed only)
     int L = blockIdx.x;
-    bool second = false;                                    // TQ_DUAL: blocks NBLK.. compute b = y y
-    if (DUAL && L >= NBLK) { L -= NBLK; second = true; }
-    const int xcd = L & 7, q = L >> 3;
+    bool second = false;                                    // TQ_DUAL: blocks 2 NBLK.. compute b = y y
+    if (DUAL && L >= 2 * NBLK) { L -= 2 * NBLK; second = true; }
+    const int xcd = L & 7, half = (L >> 3) & 1, q = L >> 4;
     const int grp = (q / TB) * 8 + xcd;                     // (head, by) pair, TP_HEADS * TB of them
     const int head = grp / TB, by = grp - head * TB, bx = q - (q / TB) * TB;
     const size_t hoff = (size_t)head * M * M;
     const float* A = (second ? A1_all : A0_all) + hoff;
     const float* BT = BT0_all + hoff;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = 2 * half + (threadIdx.x >> 6);
     const int ti = 2 * by + (wave >> 1), tj = 2 * bx + (wave & 1);
     const int r = lane & 15, kq = lane >> 4;
     const tp_f32x4* ap = (const tp_f32x4*)(A + (size_t)(16 * ti + r) * M + 4 * kq);
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
 }
 
 // z0 = x^T / (scal0 * scal1) in both layouts
-__global__ __launch_bounds__(256) void tm_pinv_init2_kernel(const float* __restrict__ x, int m, const unsigned* __restrict__ scal,
+__global__ __launch_bounds__(128) void tm_pinv_init2_kernel(const float* __restrict__ x, int m, const unsigned* __restrict__ scal,
                                                              float* __restrict__ z, float* __restrict__ zt) {
     const float inv = 1.0f / (__uint_as_float(scal[0]) * __uint_as_float(scal[1]));
     const size_t per = (size_t)m * m, total = per * TP_HEADS;
@@ -353,9 +357,9 @@ bool tm_pinv_tiles_supported(int m) { return m == 64 || m == 128 || m == 192 || 
 template <int M>
 static int tm_pinv_tiles_run(const float* X, float* Z, float* ZT, float* Wp, float* BT, float* Y, float* YT, float* Lb,
                              const unsigned* scal, int iters, float** z_final, hipStream_t st, float* LY, float* WY) {
-    hipLaunchKernelGGL(tm_pinv_init2_kernel, dim3(256), dim3(256), 0, st, X, M, scal, Z, ZT);
-    const unsigned nblk = (M / 32) * (M / 32) * TP_HEADS;
-    const dim3 block(256);
+    hipLaunchKernelGGL(tm_pinv_init2_kernel, dim3(512), dim3(128), 0, st, X, M, scal, Z, ZT);
+    const unsigned nblk = 2 * (M / 32) * (M / 32) * TP_HEADS;      // two-wave workgroups: two per 32 x 32 block
+    const dim3 block(128);
     static const bool y_each = getenv("ACMIL_TM_PINV_Y1") != nullptr;      // A/B knob: recompute y = x z in every iteration (round 3)
     if (LY && WY && !y_each) {
         hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_Y>), dim3(nblk), block, 0, st, X, ZT, (const float*)nullptr, (const float*)nullptr, Y, YT, (float*)nullptr,

@@ -171,3 +171,68 @@ def test_one_launch_pinv_kernel_matches_the_product_chain():
             out[tag] = torch.load(path)
     for a, b in zip(out["chain"], out["one"]):
         assert torch.isfinite(b).all() and (a - b).abs().max().item() < 1e-5, (a, b)
+
+
+def test_side_stream_pipeline_matches_the_serial_one():
+    """Round 4: the Moore-Penrose chain of a layer runs on a library-owned side stream beside the attn3 leg (csrc/transmil.hip:
+    tm_side / tm_fork / tm_join; nystrom_attention.py:12-27 beside :113-127).  ACMIL_TM_SIDE_STREAM=0 is the serial pipeline:
+    logits agree to 1e-5 (the leg merges 32 instead of 64 key chunks when it shares the GPU: another summation order), the
+    intermediates h1 / hp / h2 to 2e-5 relative, and ten back-to-back forwards on one workspace (fork / join events re-recorded
+    every layer, no host synchronisation between them) are bit-identical.  Own processes: the library reads the knob once."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from acmil_amd import ops; from acmil_amd import synthetic as S\n"
+        "res = []\n"
+        "for n, d, di in ((700, 384, 128), (5000, 512, 256), (40000, 768, 384)):\n"
+        "    sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=3).items()}\n"
+        "    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda()\n"
+        "    outs = [ops.transmil_forward(x, sd, 2, debug=True) for _ in range(10)]\n"
+        "    torch.cuda.synchronize()\n"
+        "    for o in outs[1:]:\n"
+        "        assert torch.equal(o['logits'], outs[0]['logits']) and torch.equal(o['h2'], outs[0]['h2'])\n"
+        "    res.append({k: outs[0][k].cpu() for k in ('logits', 'h1', 'hp', 'h2')})\n"
+        "torch.save(res, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("side", {}), ("serial", {"ACMIL_TM_SIDE_STREAM": "0"})):
+            e = dict(os.environ); e.pop("ACMIL_TM_SIDE_STREAM", None); e.pop("ACMIL_TM_ATTN3_CHUNKS", None); e.update(env)
+            path = os.path.join(d, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:]
+            out[tag] = torch.load(path)
+    for a, b in zip(out["side"], out["serial"]):
+        assert torch.isfinite(a["logits"]).all() and (a["logits"] - b["logits"]).abs().max().item() < 1e-5, (a["logits"], b["logits"])
+        for k in ("h1", "hp", "h2"):
+            assert (a[k] - b[k]).abs().max().item() <= 2e-5 * max(1.0, b[k].abs().max().item()), k
+
+
+def test_forward_with_the_side_stream_captures_into_a_hip_graph():
+    """The fork / join of the side stream is event record + stream wait only, so a caller may capture the forward
+    (transMIL.py:60-91) into a HIP graph: replay on new input == eager, bit for bit."""
+    from acmil_amd import ops
+    from acmil_amd import synthetic as S
+    n, d, di = 6000, 768, 384
+    sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=5).items()}
+    xs = [torch.randn(n, d, generator=torch.Generator().manual_seed(s)).cuda() for s in (1, 2)]
+    eager = [ops.transmil_forward(x, sd, 2)["logits"].clone() for x in xs]
+    torch.cuda.synchronize()
+    x_static = xs[0].clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ops.transmil_forward(x_static, sd, 2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.transmil_forward(x_static, sd, 2)["logits"]
+    for x, ref in zip(xs, eager):
+        x_static.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (out, ref)
