@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void tm_ppeg_pack_kernel(const float* w7, cons
     if (ky >= 2 && ky <= 4 && kx >= 2 && kx <= 4) v += w3[(size_t)c * 9 + (ky - 2) * 3 + (kx - 2)];
     if (tap == 24) v += 1.0f;
     weff[(size_t)tap * C + c] = v;
-    if (tap == 0) { beff[c] = b7[c] + b5[c] + b3[c]; cls_out[c] = cls_in[c]; }
+    if (tap == 0) { beff[c] = b7[c] + b5[c] + b3[c]; if (cls_in) cls_out[c] = cls_in[c]; }
 }
 
 // the end of the forward: LayerNorm of the cls row and the class logits in ONE launch (were a LayerNorm launch + a 1 x C GEMM: 19 us)
@@ -502,11 +502,14 @@ __global__ __launch_bounds__(256) void tm_cls_head_kernel(const float* __restric
 // every LDS access is conflict-free and every global row read is a coalesced 256-B segment); thread (c, g)
 // computes rows 2g, 2g+1 of the tile with its 49 taps in registers.
 #define TM_PT 8
+// cls_in / cls_out (or null): the cls row the stencil passes through (transMIL.py:39-44), copied by the first tile's workgroups
 __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
-                                                     const float* __restrict__ weff, const float* __restrict__ beff) {
+                                                     const float* __restrict__ weff, const float* __restrict__ beff,
+                                                     const float* __restrict__ cls_in, float* __restrict__ cls_out) {
     __shared__ __attribute__((aligned(16))) float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
     const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
+    if (cls_in && blockIdx.y == 0 && grp == 0 && c < C) cls_out[c] = cls_in[c];
     const int tiles_x = (side + TM_PT - 1) / TM_PT;
     const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
     // halo tile -> LDS: thread = (pixel e, float4 of channels); 16 lanes cover the 64 channels of a pixel, so one wave
@@ -560,8 +563,10 @@ __global__ __launch_bounds__(256) void tm_ppeg_kernel(const float* __restrict__ 
 // (1.9 GFMA per slide were 181 us there: VALU issue, not HBM -- 1.7 TB/s).  C % 64 == 0 (else the scalar kernel).
 // (In fact a channel QUAD per thread and half a pixel row: see the store note inside.)
 __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restrict__ in, float* __restrict__ out, int side, int C,
-                                                      const float* __restrict__ weff, const float* __restrict__ beff) {
+                                                      const float* __restrict__ weff, const float* __restrict__ beff,
+                                                      const float* __restrict__ cls_in, float* __restrict__ cls_out) {
     __shared__ __attribute__((aligned(16))) float tile[(TM_PT + 6) * (TM_PT + 6) * 64];
+    if (cls_in && blockIdx.y == 0 && threadIdx.x < 64) cls_out[blockIdx.x * 64 + threadIdx.x] = cls_in[blockIdx.x * 64 + threadIdx.x];
     // thread = (channel QUAD cq, tile row py, half of the row's 8 pixels): 4 channels x 4 pixels, so that an output pixel is ONE
     // 16-byte store (a store instruction costs the CU ~75 cycles whatever its width: 8-byte stores were 52 us of this kernel)
     const int cq = threadIdx.x & 15, py = (threadIdx.x >> 4) & 7, ph = threadIdx.x >> 7;
@@ -971,6 +976,11 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
                 hipLaunchKernelGGL(tm_wbeta_kernel, dim3((3 * Di + 3) / 4, 2), dim3(256), 0, sp, J, 3 * Di, Di);
                 if (hipGetLastError() != hipSuccess) rp = ACMIL_ERR_LAUNCH;
             }
+            if (rp == ACMIL_OK && packs_forked) {       // the folded PPEG stencil as well (weights only; the cls row is copied by the stencil launch)
+                hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, sp, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di,
+                                   weff, beff, (const float*)nullptr, (float*)nullptr);
+                if (hipGetLastError() != hipSuccess) rp = ACMIL_ERR_LAUNCH;
+            }
             if (packs_forked) { const int rj = tm_join_later(side); if (rp == ACMIL_OK) rp = rj; }
             if (rp != ACMIL_OK) return rp;
         }
@@ -987,18 +997,22 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     if (packs_forked && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;      // the layer streams are packed
     int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr, side); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
-    // PPEG: cls passthrough + combined depth-wise 7x7
-    hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
-                       XA + (size_t)g.pad * Di, XB + (size_t)g.pad * Di);
+    // PPEG: cls passthrough + combined depth-wise 7x7 (the folded stencil was packed beside fc1 when the side stream is in use)
+    const float* cls_in = XA + (size_t)g.pad * Di; float* cls_out = XB + (size_t)g.pad * Di;
+    if (!packs_forked) {
+        hipLaunchKernelGGL(tm_ppeg_pack_kernel, dim3((49 * Di + 255) / 256), dim3(256), 0, st, ppeg[0], ppeg[1], ppeg[2], ppeg[3], ppeg[4], ppeg[5], Di, weff, beff,
+                           (const float*)nullptr, (float*)nullptr);
+        TM_CHECK_LAUNCH();
+    }
     {
         const int tiles = (g.side + TM_PT - 1) / TM_PT;
         static const bool ppeg_scalar = getenv("ACMIL_TM_PPEG_SCALAR") != nullptr;       // A/B knob
         if (Di % 64 == 0 && !ppeg_scalar)
             hipLaunchKernelGGL(tm_ppeg2_kernel, dim3(Di / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
-                               XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff);
+                               XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff, cls_in, cls_out);
         else
         hipLaunchKernelGGL(tm_ppeg_kernel, dim3((Di + 63) / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
-                           XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff);
+                           XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff, cls_in, cls_out);
     }
     TM_CHECK_LAUNCH();
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
