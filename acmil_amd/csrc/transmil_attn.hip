@@ -495,17 +495,25 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
     }
 }
 
-template <int MT>
-__global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restrict__ QKV, const float* __restrict__ QL,
+// GRP key chunks per workgroup (round 4): MT = 6 waves do not divide over a CU's four SIMDs -- two such workgroups sit as 4, 4, 2, 2
+// waves, the leg runs at the pace of the SIMDs that carry four, and nothing else finds room on those (tools/coresident_probe.hip).
+// GRP = 2 puts two chunks -- two independent 6-wave groups, each with its own staging buffers and online-softmax state, sharing only
+// the step barrier -- into ONE 12-wave workgroup: 3 waves on every SIMD.  Same chunk partition, same partials, same merge.
+template <int MT, int GRP>
+__global__ __launch_bounds__(64 * MT * GRP) void tm_attn3x_kernel(const float* __restrict__ QKV, const float* __restrict__ QL,
                                                            float* __restrict__ part_ms, float* __restrict__ part_o, int npad, int Di,
-                                                           float scale, int blocks_per_chunk) {
+                                                           float scale, int blocks_per_chunk, int nchunks) {
     constexpr int M = 32 * MT, D = 8 * MT, KS = D / 16, ET = (D + 31) / 32, EP = 32 * ET, LDK = D + 8, VN = 2 * EP * 16;
-    __shared__ __attribute__((aligned(16))) _Float16 kh[2][32 * LDK], kl[2][32 * LDK];   // [key][d]       A operand of GEMM-S
-    __shared__ __attribute__((aligned(16))) _Float16 vh[2][VN], vl[2][VN];                // permuted v^T  A operand of GEMM-PV
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+    __shared__ __attribute__((aligned(16))) _Float16 kh_[GRP][2][32 * LDK], kl_[GRP][2][32 * LDK];   // [key][d]       A operand of GEMM-S
+    __shared__ __attribute__((aligned(16))) _Float16 vh_[GRP][2][VN], vl_[GRP][2][VN];                // permuted v^T  A operand of GEMM-PV
+    const int grp = (GRP > 1) ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / (64 * MT)) : 0;
+    const int tid = threadIdx.x - grp * 64 * MT, lane = tid & 63, wave = tid >> 6, i31 = lane & 31, hi = lane >> 5;
+    _Float16 (*kh)[32 * LDK] = kh_[grp]; _Float16 (*kl)[32 * LDK] = kl_[grp];
+    _Float16 (*vh)[VN] = vh_[grp]; _Float16 (*vl)[VN] = vl_[grp];
+    const int h = blockIdx.y, chunk = blockIdx.x * GRP + grp;
     const int nblk = npad / 32;
-    const int kb0 = chunk * blocks_per_chunk, kb1 = min(nblk, kb0 + blocks_per_chunk);
+    const bool live = chunk < nchunks;                               // (an odd chunk count leaves the last workgroup's second group idle)
+    const int kb0 = chunk * blocks_per_chunk, kb1 = live ? min(nblk, kb0 + blocks_per_chunk) : kb0;
 
     tma_h8 qh[KS], ql[KS];            // B operand of GEMM-S: scale * q_l[l = 32 wave + i31][16 st + 8 hi + j]
     {
@@ -535,9 +543,13 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) o[et][r] = 0.0f;
 
     if (kb0 < kb1) load_kv(kb0);
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const int buf = (kb - kb0) & 1;
-        {
+    // (GRP > 1: the groups share the barrier, so every group runs blocks_per_chunk steps; steps past its own range do nothing)
+    for (int it = 0; it < blocks_per_chunk; ++it) {
+        const int kb = kb0 + it;
+        const bool on = kb < kb1;
+        if (GRP == 1 && !on) break;
+        const int buf = it & 1;
+        if (on) {
             tma_h4 h4, l4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const _Float16 x = (_Float16)kreg[j]; h4[j] = x; l4[j] = (_Float16)(kreg[j] - (float)x); }
@@ -551,6 +563,7 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
             }
         }
         __syncthreads();      // (an LDS-only barrier with the prefetch issued ahead of it measured the same: 149.3 vs 150.8 us)
+        if (!on) continue;
         if (kb + 1 < kb1) load_kv(kb + 1);
 
         f32x16 S;
@@ -605,6 +618,7 @@ __global__ __launch_bounds__(64 * MT) void tm_attn3x_kernel(const float* __restr
         __builtin_amdgcn_s_setprio(0);
 #endif
     }
+    if (!live) return;
     const size_t row = ((size_t)h * nchunks + chunk) * M + 32 * wave + i31;
     if (hi == 0) { part_ms[row * 2] = m_run; part_ms[row * 2 + 1] = s_run; }
 #pragma unroll
@@ -696,8 +710,15 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     nchunks = (nblk + bpc - 1) / bpc;
     float* part_ms = part;
     float* part_o = part + (((size_t)TMA_HEADS * nchunks * M * 2 + 63) & ~(size_t)63);
+    // MT = 6 alone on the GPU: two chunks per 12-wave workgroup (3 waves on every SIMD instead of 4, 4, 2, 2: 2.21 vs 2.23 ms per forward);
+    // beside the Moore-Penrose chain the 6-wave workgroups stay, one per CU (32 chunks): measured 2.07 ms against 2.12 with the 12-wave
+    // form, whose three waves per SIMD leave the chain's waves too few issue slots.  ACMIL_TM_ATTN3_GRP=1 / 2 forces one form (A/B).
+    static const int grp_forced = [] { const char* e = getenv("ACMIL_TM_ATTN3_GRP"); return e ? atoi(e) : 0; }();
+    constexpr int GRP = (MT == 6) ? 2 : 1;
+    const bool grp1 = grp_forced == 1 || (grp_forced != 2 && shared);
     if (tm_attn_exact()) hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
-    else hipLaunchKernelGGL(tm_attn3x_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);
+    else if (GRP == 1 || grp1) hipLaunchKernelGGL((tm_attn3x_kernel<MT, 1>), dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc, nchunks);
+    else hipLaunchKernelGGL((tm_attn3x_kernel<MT, GRP>), dim3((nchunks + GRP - 1) / GRP, TMA_HEADS), dim3(64 * MT * GRP), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc, nchunks);
     if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
     hipLaunchKernelGGL(tm_attn3_merge_kernel, dim3((M + 3) / 4, TMA_HEADS), dim3(256), 0, st, part_ms, part_o, AV, M, D, nchunks);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
