@@ -107,6 +107,12 @@ __device__ static inline float stkim_uniform(unsigned long long seed, unsigned l
 }
 
 #define STKIM_MERGE_E 32      // candidates per lane in the merge: nchunks * k <= 64 * 32
+// timing-only stamps (tools/stkim_probe.py builds a variant with -DSTKIM_PROF): 100 MHz wall clock into the control block, bytes 64..
+#ifdef STKIM_PROF
+#define STKIM_STAMP(slot, cond) do { if ((cond) && threadIdx.x == 0) ((unsigned long long*)arrive)[8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define STKIM_STAMP(slot, cond) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, int N, int K,
                                                           int k, int m, const float* __restrict__ uniforms,
                                                           unsigned long long rng_seed, unsigned long long rng_offset,
@@ -117,6 +123,8 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     __shared__ int is_last;
     const int chunk = blockIdx.x, br = blockIdx.y, nch = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+    STKIM_STAMP(0, first);
     {
         const float* row = scores + (size_t)br * N;
         unsigned long long keys[STKIM_EPT];
@@ -126,6 +134,10 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
             keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
         }
         unsigned long long* out = cand + ((size_t)br * nch + chunk) * k;
+#ifdef STKIM_PROF
+        if (first && keys[0] == 1ull) out[0] = 0ull;      // (the stamp below waits for the loads)
+#endif
+        STKIM_STAMP(1, first);
         for (int j = 0; j < k; ++j) {
             unsigned long long best = 0ull;
 #pragma unroll
@@ -140,6 +152,7 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     // publish the candidates: they were stored write-through (sc1) by this lane, so draining its stores is the release (an
     // agent release fence would write back every dirty L2 line -- here the scores and the saved h of the score pass);
     // count this block; the last one reads everybody's candidates with sc1 loads
+    STKIM_STAMP(2, first);
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = atomicAdd(arrive, 1u);
@@ -147,7 +160,9 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
         if (is_last) atomicExch(arrive, 0u);
     }
     __syncthreads();
+    STKIM_STAMP(3, first);
     if (!is_last) return;
+    STKIM_STAMP(4, true);
     const int ncand = nch * k;
     for (int b = wave; b < K; b += 4) {
         const unsigned long long* c = cand + (size_t)b * ncand;
@@ -159,6 +174,7 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
         else stkim_merge_wave<STKIM_MERGE_E>(c, ncand, k, lane, sel[wave], trow);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // sel[] written by lane 0 is visible to the wave
+        STKIM_STAMP(5, b == 0);
         if (m > 0) {
             // this lane's uniform: injected (parity tests) or drawn here (uniforms == null); rank = position in argsort ascending
             const float mine = lane < k ? (uniforms ? uniforms[(size_t)b * k + lane] : stkim_uniform(rng_seed, rng_offset, (unsigned)b, (unsigned)lane)) : 2.0f;
@@ -173,6 +189,7 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
                 if (A_mask && n < (unsigned)N) A_mask[(size_t)b * N + n] = -1e9f;
             }
         }
+        STKIM_STAMP(6, b == 0);
     }
 }
 
