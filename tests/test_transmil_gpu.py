@@ -236,3 +236,40 @@ def test_forward_with_the_side_stream_captures_into_a_hip_graph():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref), (out, ref)
+
+
+def test_two_host_threads_share_the_side_stream():
+    """Two host threads enqueue forwards on their own streams at the same time (ctypes releases the GIL inside the library call):
+    the library's one side stream and event pair per device are used under a lock, so each thread's logits equal the ones it gets
+    alone (transMIL.py:60-91)."""
+    import threading
+    from acmil_amd import ops
+    from acmil_amd import synthetic as S
+    d, di = 768, 384
+    sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=7).items()}
+    bags = [torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda() for n in (3000, 9000)]
+    alone = [ops.transmil_forward(x, sd, 2)["logits"].clone() for x in bags]
+    torch.cuda.synchronize()
+    got = [[], []]
+    err = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    got[i].append(ops.transmil_forward(bags[i], sd, 2)["logits"])
+            st.synchronize()
+        except Exception as e:      # pragma: no cover
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not err, err
+    for i in range(2):
+        for o in got[i]:
+            assert torch.equal(o, alone[i]), (i, o, alone[i])
