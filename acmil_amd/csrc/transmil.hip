@@ -703,7 +703,7 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
 // forward holds a lock, so concurrent callers cannot interleave each other's record / wait pairs.  ACMIL_TM_SIDE_STREAM=0: serial.
 struct TmSide { hipStream_t s; hipEvent_t fork, join; int state; };      // state: 0 = untried, 1 = ready, -1 = unavailable
 static std::mutex tm_side_mutex;
-static TmSide* tm_side() {
+static TmSide* tm_side(hipStream_t st) {
     static const bool off = [] { const char* e = getenv("ACMIL_TM_SIDE_STREAM"); return e && e[0] == '0'; }();
     if (off) return nullptr;
     static TmSide side[64];
@@ -711,6 +711,11 @@ static TmSide* tm_side() {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     TmSide& t = side[dev];
     if (t.state == 0) {
+        // never create the stream / events while the caller is CAPTURING (a first call inside a graph capture: creation calls may be
+        // refused there and would invalidate the capture): that forward runs serially, a later eager call creates them
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (cs != hipStreamCaptureStatusNone) return nullptr;
         int least = 0, greatest = 0;
         t.state = -1;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
@@ -940,7 +945,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     const TmWs W = tm_ws(g);
     char* ws = (char*)workspace;
     std::lock_guard<std::mutex> side_lock(tm_side_mutex);      // one forward at a time records / waits on the side stream's events
-    TmSide* side = tm_side();
+    TmSide* side = tm_side(st);
     float* XA = (float*)(ws + W.XA); float* XB = (float*)(ws + W.XB); float* LN = (float*)(ws + W.LN);
     float* weff = (float*)(ws + W.WEFF); float* beff = (float*)(ws + W.BEFF);
     void* gws = ws + W.GEMM;

@@ -273,3 +273,26 @@ def test_two_host_threads_share_the_side_stream():
     for i in range(2):
         for o in got[i]:
             assert torch.equal(o, alone[i]), (i, o, alone[i])
+
+
+def test_first_forward_of_a_process_inside_a_graph_capture():
+    """The side stream and its events are never CREATED under a capture (csrc/transmil.hip::tm_side): a process whose first forward
+    is captured gets the serial pipeline in that graph, the next eager call creates the stream; both agree to rounding."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from acmil_amd import ops; from acmil_amd import synthetic as S\n"
+        "sd = {k: v.cuda() for k, v in S.transmil_state_dict(768, 384, 2, seed=5).items()}\n"
+        "x = torch.randn(4000, 768, generator=torch.Generator().manual_seed(1)).cuda()\n"
+        "torch.cuda.synchronize()\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(g):\n"
+        "    out = ops.transmil_forward(x, sd, 2)['logits']\n"
+        "g.replay(); torch.cuda.synchronize()\n"
+        "a = out.clone(); b = ops.transmil_forward(x, sd, 2)['logits']; torch.cuda.synchronize()\n"
+        "assert torch.isfinite(a).all() and (a - b).abs().max().item() < 1e-5, (a, b)\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:]
