@@ -280,6 +280,10 @@ int acmil_ga_loss(const float* sub_preds, const float* slide_pred, const float* 
  *         proj2.weight [Di,3,3], proj2.bias};  norm_w/norm_b [Di]; fc2_w [C,Di], fc2_b [C].
  * Output logits [C].  dbg_h1 / dbg_hp / dbg_h2: NULL, or [(side^2+1), Di] buffers receiving the token matrix
  * after layer1 / PPEG / layer2 (parity tests).  Dropout (train mode) is not implemented: eval forward only.
+ * Streams: everything is ordered on `stream` as far as the caller can tell -- but inside a layer the Moore-Penrose chain runs on ONE
+ * library-owned non-blocking stream per device beside the attn3 leg, forked from and joined back into `stream` with events before the
+ * call's last launches are enqueued (so `stream` alone orders the outputs; HIP-graph capture of the call works; concurrent callers are
+ * serialised over the enqueue by a lock).  ACMIL_TM_SIDE_STREAM=0 keeps every launch on `stream`.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C);
 
