@@ -152,14 +152,17 @@ __global__ __launch_bounds__(256) void tm_landmark_reduce_kernel(const float* __
 }
 
 // token assembly after fc1: cls row, wrap-around rows (repeat the first tokens), zero front padding
-__global__ void tm_assemble_kernel(float* __restrict__ X, int pad, int N, int nsq, int dim, const float* __restrict__ cls,
+// X2: the second token buffer (PPEG output = layer 2's input): its front padding rows are zeroed here too -- nothing else ever writes
+// them, and the LayerNorm-folded to_qkv reads them as x * 0 + 0, which is NaN for whatever NaN / inf bit patterns a recycled
+// workspace holds (found in round 4 by running the forward on a workspace pre-filled with 0xFF bytes: layer 2 and the logits were NaN)
+__global__ void tm_assemble_kernel(float* __restrict__ X, float* __restrict__ X2, int pad, int N, int nsq, int dim, const float* __restrict__ cls,
                                    float* __restrict__ guard_lo, float* __restrict__ guard_hi, int guard_n) {
     // the zero guard rows of QKV (once per forward: nothing else writes them)
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < guard_n; e += gridDim.x * blockDim.x) { guard_lo[e] = 0.0f; guard_hi[e] = 0.0f; }
     const long long total = (long long)(pad + 1 + (nsq - N)) * dim;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long r = e / dim; const int c = e % dim;
-        if (r < pad) X[r * dim + c] = 0.0f;
+        if (r < pad) { X[r * dim + c] = 0.0f; X2[r * dim + c] = 0.0f; }
         else if (r == pad) X[r * dim + c] = cls[c];
         else { const long long j = r - pad - 1; X[((long long)pad + 1 + N + j) * dim + c] = X[((long long)pad + 1 + j) * dim + c]; }
     }
@@ -728,6 +731,30 @@ static TmSide* tm_side(hipStream_t st) {
     }
     return t.state == 1 ? &t : nullptr;
 }
+// One forward at a time ON THE GPU as well (round 4).  Two forwards enqueued on DIFFERENT caller streams ran side by side and, although
+// they share no memory (own workspaces, read-only parameters), corrupted each other: stale or garbage 32-row x 96-column blocks in the
+// to_out outputs, logits off by 1e-3 or NaN, in 20 - 50 % of the forwards of a two-thread loop -- with the round-3 pipeline as much as
+// with this one, never with one stream, never beside foreign kernels (torch copies / GEMMs / reductions, this library's own Linear or
+// GA launches), and not cured by fully drained LDS-DMA waits or device-scope tile draws in the Linear kernel (variant builds); the
+// disturbing stages are the attention legs and the Moore-Penrose chain of the OTHER forward.  Root cause open.  Until it
+// is found a forward waits for the previous forward of the process on this device, whichever stream that used: one event record per
+// forward, one wait when the stream changed.  Never under a capture (a graph replays on its own stream).
+struct TmSerial { hipEvent_t done; hipStream_t last; int state; };      // state: 0 = no event yet, 1 = event exists, 2 = recorded
+static TmSerial* tm_serial(hipStream_t st, bool* capturing) {
+    static TmSerial ser[64];
+    int dev = 0;
+    *capturing = false;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) { *capturing = true; return nullptr; }
+    TmSerial& t = ser[dev];
+    if (t.state == 0) {
+        if (hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        t.state = 1;
+    }
+    return &t;
+}
 // side stream continues from what `st` holds now
 static bool tm_fork(TmSide* sd, hipStream_t st) {
     return sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->s, sd->fork, 0) == hipSuccess;
@@ -946,6 +973,13 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     char* ws = (char*)workspace;
     std::lock_guard<std::mutex> side_lock(tm_side_mutex);      // one forward at a time records / waits on the side stream's events
     TmSide* side = tm_side(st);
+    bool capturing = false;
+    TmSerial* ser = tm_serial(st, &capturing);
+    if (ser && ser->state == 2 && ser->last != st && hipStreamWaitEvent(st, ser->done, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    struct SerialMark {      // the end of this forward, recorded on every return path
+        TmSerial* s; hipStream_t st;
+        ~SerialMark() { if (s && hipEventRecord(s->done, st) == hipSuccess) { s->state = 2; s->last = st; } else if (s) (void)hipGetLastError(); }
+    } serial_mark{ser, st};
     float* XA = (float*)(ws + W.XA); float* XB = (float*)(ws + W.XB); float* LN = (float*)(ws + W.LN);
     float* weff = (float*)(ws + W.WEFF); float* beff = (float*)(ws + W.BEFF);
     void* gws = ws + W.GEMM;
@@ -994,7 +1028,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     { const int r1 = tm_linear(x, N, D, D, fc1_w, Di, fc1_b, 1, 0.0f, XA + (size_t)(g.pad + 1) * Di, Di, pk1 ? pk1 : ws + W.PKW, ws + W.LINWS, gws, st, pk1 != nullptr); if (r1 != ACMIL_OK) return r1; }
     {
         float* qkv0 = (float*)(ws + W.QKV);
-        hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, g.pad, N, g.nsq, Di, cls_token, qkv0,
+        hipLaunchKernelGGL(tm_assemble_kernel, dim3(512), dim3(256), 0, st, XA, XB, g.pad, N, g.nsq, Di, cls_token, qkv0,
                            qkv0 + (size_t)(TM_QKV_GUARD + g.npad) * 3 * Di, TM_QKV_GUARD * 3 * Di);
     }
     TM_CHECK_LAUNCH();

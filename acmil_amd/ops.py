@@ -439,9 +439,11 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 
 
-def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int, debug: bool = False) -> Dict[str, torch.Tensor]:
+def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int, debug: bool = False,
+                     workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """acmil_transmil_forward.  x [N,D] fp32 CUDA; sd: parameters under the reference's state_dict names
-    (fp32, CUDA, contiguous).  Returns {'logits': [C]} plus 'h1','hp','h2' [(side^2+1), Di] when debug."""
+    (fp32, CUDA, contiguous).  Returns {'logits': [C]} plus 'h1','hp','h2' [(side^2+1), Di] when debug.
+    workspace: a caller-owned uint8 CUDA buffer of at least acmil_transmil_workspace_bytes (tests: pre-filled scratch, canaries)."""
     lib = _lib.load()
     _need_cuda(x)
     if x.dtype != torch.float32:
@@ -466,7 +468,12 @@ def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int,
     nbytes = lib.acmil_transmil_workspace_bytes(N, D, Di, n_class)
     if nbytes == 0:
         raise RuntimeError("acmil_amd: unsupported TransMIL dimensions")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    if workspace is not None:
+        if not workspace.is_cuda or workspace.dtype != torch.uint8 or workspace.numel() < nbytes or workspace.data_ptr() % 256 != 0:
+            raise RuntimeError("acmil_amd: workspace must be a 256-byte aligned uint8 CUDA buffer of >= %d bytes" % nbytes)
+        ws = workspace
+    else:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     logits = torch.empty(n_class, dtype=torch.float32, device=x.device)
     import math
     side = int(math.ceil(math.sqrt(N)))

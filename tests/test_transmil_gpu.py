@@ -240,8 +240,10 @@ def test_forward_with_the_side_stream_captures_into_a_hip_graph():
 
 def test_two_host_threads_share_the_side_stream():
     """Two host threads enqueue forwards on their own streams at the same time (ctypes releases the GIL inside the library call):
-    the library's one side stream and event pair per device are used under a lock, so each thread's logits equal the ones it gets
-    alone (transMIL.py:60-91)."""
+    the library's one side stream and event pair per device are used under a lock, and a forward waits for the previous forward of
+    the process whichever stream that ran on (csrc/transmil.hip::tm_serial -- two forwards side by side on the GPU corrupted each
+    other in 20 - 50 % of the runs, in every pipeline since round 3; this test found it), so each thread's logits equal the ones it
+    gets alone (transMIL.py:60-91).  tools/stress_transmil.py is the long form."""
     import threading
     from acmil_amd import ops
     from acmil_amd import synthetic as S
@@ -296,3 +298,30 @@ def test_first_forward_of_a_process_inside_a_graph_capture():
         "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:]
+
+
+def test_forward_does_not_depend_on_what_the_workspace_held():
+    """The workspace is scratch: whatever bit patterns a recycled buffer holds (NaN / inf patterns of 0xFF bytes, random bytes, large
+    floats), logits and intermediates are bit-identical to the ones on a zeroed buffer.  Round 4 found layer 2 and the logits NaN on a
+    0xFF-filled workspace: the front padding rows of the PPEG output were never written and the LayerNorm-folded to_qkv reads them
+    as x * 0 + 0 (csrc/transmil.hip::tm_assemble_kernel zeroes them now; transMIL.py:25-28, nystrom_attention.py:87-93)."""
+    from acmil_amd import ops, _lib
+    from acmil_amd import synthetic as S
+    lib = _lib.load()
+    for n, d, di in ((3000, 768, 384), (1500, 512, 256), (700, 384, 128)):
+        sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=7).items()}
+        x = torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda()
+        nb = lib.acmil_transmil_workspace_bytes(n, d, di, 2)
+        ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
+        ref = {k: v.clone() for k, v in ops.transmil_forward(x, sd, 2, debug=True, workspace=ws).items()}
+        for fill in ("ff", "rand", "big"):
+            if fill == "ff":
+                ws.fill_(255)
+            elif fill == "rand":
+                ws.random_(0, 256)
+            else:
+                ws[: nb // 4 * 4].view(torch.float32).normal_().mul_(1e30)
+            out = ops.transmil_forward(x, sd, 2, debug=True, workspace=ws)
+            torch.cuda.synchronize()
+            for k in ("logits", "h1", "hp", "h2"):
+                assert torch.equal(out[k], ref[k]), (n, di, fill, k)
