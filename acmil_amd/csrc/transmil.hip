@@ -741,10 +741,11 @@ static TmSide* tm_side(hipStream_t st) {
 // forward, one wait when the stream changed.  Never under a capture (a graph replays on its own stream).
 struct TmSerial { hipEvent_t done; hipStream_t last; int state; };      // state: 0 = no event yet, 1 = event exists, 2 = recorded
 static TmSerial* tm_serial(hipStream_t st, bool* capturing) {
+    static const bool off = [] { const char* e = getenv("ACMIL_TM_SERIAL"); return e && e[0] == '0'; }();      // (reproduces the corruption: tools/stress_transmil.py)
     static TmSerial ser[64];
     int dev = 0;
     *capturing = false;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (cs != hipStreamCaptureStatusNone) { *capturing = true; return nullptr; }
