@@ -845,6 +845,17 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
         // region.  No vmcnt / __syncthreads here: the DMA ring stays in flight.
         const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
         char* const scr = G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW;
+        // Every wave read ALL fragment rows of that slot in the last GEMM2 step, so nobody may write its scratch there before the slowest
+        // wave's reads have returned.  The gate / softmax arithmetic in between (thousands of cycles) kept that true in every run so far,
+        // but it is a property of timing, not of the code: lin_kernel, which goes from its last step straight to the same kind of scratch,
+        // was caught with one wave a K step behind (linear_kernel.h, round 4).  One barrier per tile; the waves re-align here instead of
+        // at the next tile's first step barrier.  (-DGA2_NO_SCRATCH_BARRIER: A/B build without it.)
+#ifndef GA2_NO_SCRATCH_BARRIER
+        if constexpr (G::SCRATCH_IN_RING) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+        }
+#endif
         float* pl = (float*)(smem + G::PL_OFF) + (size_t)wave * KP * 32;   // softmax numerators [KP][32 patches]
         if constexpr (POOL) {
             // On the matrix pipe: D[k][f] = sum_n P[k][n] h[n][f] per 32-feature tile d, A = P (rows = branches, K = the wave's

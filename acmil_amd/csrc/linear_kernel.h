@@ -379,6 +379,16 @@ __global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
             const int i31 = lane & 31, hi = lane >> 5;
             const int fslot = (rslot == 0) ? NB - 1 : rslot - 1;
             float* pool = (float*)(G::SCRATCH_IN_RING ? smem + fslot * G::SLOT + wave * G::REGION : smem + G::SCR_OFF + wave * G::PW);
+            // The transposition tile lives in the ring slot the LAST K step read, and every wave reads ALL fragment rows of that slot:
+            // a wave that is done with its last step must not write its tile while a slower wave still reads fragments there.  Round 4
+            // found exactly that (one wave's accumulators of the three column blocks whose fragment rows another wave had already
+            // overwritten with fp32 values: 1e5 / NaN blocks in to_qkv / to_out outputs) -- only with a second TransMIL forward on another
+            // stream, whose short Moore-Penrose workgroups share a SIMD with ONE wave of this workgroup and hold it back by more than
+            // a K step; the barrier closes it for any skew (all fragment reads of the last step are retired before anyone writes).
+            if constexpr (G::SCRATCH_IN_RING) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): this wave's fragment reads have returned
+                __builtin_amdgcn_s_barrier();
+            }
             const int m0 = T.m0;
             if (a.status) {      // largest |pre-activation| of this lane's row as a bit pattern (finite < inf < NaN), sign shifted out
                 unsigned hm = 0u;

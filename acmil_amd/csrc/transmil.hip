@@ -731,17 +731,15 @@ static TmSide* tm_side(hipStream_t st) {
     }
     return t.state == 1 ? &t : nullptr;
 }
-// One forward at a time ON THE GPU as well (round 4).  Two forwards enqueued on DIFFERENT caller streams ran side by side and, although
-// they share no memory (own workspaces, read-only parameters), corrupted each other: stale or garbage 32-row x 96-column blocks in the
-// to_out outputs, logits off by 1e-3 or NaN, in 20 - 50 % of the forwards of a two-thread loop -- with the round-3 pipeline as much as
-// with this one, never with one stream, never beside foreign kernels (torch copies / GEMMs / reductions, this library's own Linear or
-// GA launches), and not cured by fully drained LDS-DMA waits or device-scope tile draws in the Linear kernel (variant builds); the
-// disturbing stages are the attention legs and the Moore-Penrose chain of the OTHER forward.  Root cause open.  Until it
-// is found a forward waits for the previous forward of the process on this device, whichever stream that used: one event record per
-// forward, one wait when the stream changed.  Never under a capture (a graph replays on its own stream).
+// Opt-in (ACMIL_TM_SERIAL=1): one forward at a time ON THE GPU as well -- a forward waits for the previous forward of the process on
+// this device, whichever stream that used (one event record per forward, one wait when the stream changed; never under a capture).
+// This was the stop-gap while two forwards on different streams corrupted each other; the cause turned out to be a missing barrier in
+// lin_kernel (linear_kernel.h: a wave wrote its epilogue scratch into the ring slot a slower wave was still reading fragments from --
+// only a second forward's short Moore-Penrose workgroups ever held a wave back that far) and is fixed there, so forwards overlap
+// again by default; tests/test_transmil_gpu.py and tools/stress_transmil.py run the two-stream case.
 struct TmSerial { hipEvent_t done; hipStream_t last; int state; };      // state: 0 = no event yet, 1 = event exists, 2 = recorded
 static TmSerial* tm_serial(hipStream_t st, bool* capturing) {
-    static const bool off = [] { const char* e = getenv("ACMIL_TM_SERIAL"); return e && e[0] == '0'; }();      // (reproduces the corruption: tools/stress_transmil.py)
+    static const bool off = [] { const char* e = getenv("ACMIL_TM_SERIAL"); return !(e && e[0] == '1'); }();
     static TmSerial ser[64];
     int dev = 0;
     *capturing = false;

@@ -283,9 +283,9 @@ int acmil_ga_loss(const float* sub_preds, const float* slide_pred, const float* 
  * Streams: everything is ordered on `stream` as far as the caller can tell -- but inside a layer the Moore-Penrose chain runs on ONE
  * library-owned non-blocking stream per device beside the attn3 leg, forked from and joined back into `stream` with events before the
  * call's last launches are enqueued (so `stream` alone orders the outputs; HIP-graph capture of the call works; concurrent callers are
- * serialised over the enqueue by a lock).  ACMIL_TM_SIDE_STREAM=0 keeps every launch on `stream`.  Forwards of one process never overlap
- * on a device: a call on another stream than the previous call first waits (on the GPU) for that one's end -- two forwards side by side
- * corrupted each other (open root cause); the workspace may hold anything on entry.
+ * serialised over the enqueue by a lock).  ACMIL_TM_SIDE_STREAM=0 keeps every launch on `stream`.  Forwards on different streams may
+ * overlap on the GPU (tested: tools/stress_transmil.py; ACMIL_TM_SERIAL=1 makes each wait for the previous one); the workspace may hold
+ * anything on entry.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C);
 

@@ -240,10 +240,10 @@ def test_forward_with_the_side_stream_captures_into_a_hip_graph():
 
 def test_two_host_threads_share_the_side_stream():
     """Two host threads enqueue forwards on their own streams at the same time (ctypes releases the GIL inside the library call):
-    the library's one side stream and event pair per device are used under a lock, and a forward waits for the previous forward of
-    the process whichever stream that ran on (csrc/transmil.hip::tm_serial -- two forwards side by side on the GPU corrupted each
-    other in 20 - 50 % of the runs, in every pipeline since round 3; this test found it), so each thread's logits equal the ones it
-    gets alone (transMIL.py:60-91).  tools/stress_transmil.py is the long form."""
+    the library's one side stream and event pair per device are used under a lock, the forwards themselves overlap on the GPU, and
+    each thread's logits equal the ones it gets alone (transMIL.py:60-91).  This test found the write-after-read race of lin_kernel
+    (csrc/linear_kernel.h: epilogue scratch in the ring slot a slower wave still read; 20 - 65 % of such forwards were wrong in every
+    pipeline since round 3).  tools/stress_transmil.py is the long form."""
     import threading
     from acmil_amd import ops
     from acmil_amd import synthetic as S
