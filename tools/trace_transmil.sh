@@ -1,4 +1,4 @@
-# usage: tools/_trace_tm.sh tag [ENV=VAL ...]   -> gpurun_out/s2/trace_<tag>.txt (one forward's kernels with start / end in us)
+# usage: tools/trace_transmil.sh tag [ENV=VAL ...]   -> gpurun_out/s2/trace_<tag>.txt (one forward's kernels with start / end in us)
 export TMPDIR=/tmp
 tag=$1; shift
 mkdir -p /root/repo/gpurun_out/s2
