@@ -210,15 +210,23 @@ class _GatedBase(nn.Module):
         self._gate_cache = None
         self.__dict__.pop("_pack_cache_alt", None)
 
-    # D_inner with a fully fused forward kernel (csrc/ga_families.inc); the reference's other feature extractors
-    # (Step3_WSI_classification_ACMIL.py:78-87: CLIP-L 768/384, UNI 1024/512, GigaPath 1536/768) take the composed path
+    # D_inner with a fully fused forward kernel in every arithmetic mode AND a one-call training step (csrc/ga_families.inc)
     FUSED_D_INNER = (128, 256)
+    # Wide families of the reference's newer feature extractors (Step3_WSI_classification_ACMIL.py:78-87: CLIP-L 768/384, UNI
+    # 1024/512): fully fused in split-f16 arithmetic (csrc/ga_forward_kernel_v3.h, one 512-register wave per SIMD; round 5) -- eval
+    # forward and the score pass of a training step.  Their fp32 mode, GigaPath (1536/768) and n_token > 5 take the composed path.
+    FUSED_WIDE_D_INNER = (384, 512)
 
     FUSED_MAX_TOKENS = 5      # n_token above (Step3_WSI_classification_ACMIL.py:39 takes any) runs the composed kernels, K <= 16
 
     def _is_fused(self) -> bool:
         return (self.dimreduction.fc1.weight.shape[0] in self.FUSED_D_INNER
                 and self.attention.attention_weights.weight.shape[0] <= self.FUSED_MAX_TOKENS)
+
+    def _is_wide_fused(self) -> bool:
+        return (self.precision == "f16x3" and self.dimreduction.fc1.weight.shape[0] in self.FUSED_WIDE_D_INNER
+                and self.attention.attention_weights.weight.shape[0] <= self.FUSED_MAX_TOKENS
+                and self.attention.attention_V[0].weight.shape[0] == 128)
 
     def _score_pass(self, xb, packed, dims):
         """Raw scores A [K,N] and h [N,Di].  Fused widths: one kernel (GEMM chain in registers).  Other widths: the projection
@@ -233,8 +241,17 @@ class _GatedBase(nn.Module):
                 self._bwd_dims = d32               # the backward of this step follows in exact fp32 as well
                 return ops.ga_scores(xb, p32, d32, "fp32")
             return A, h
+        if self._is_wide_fused():
+            # one kernel as at the fused widths (h leaves the GEMM1 accumulators once, as fp32 rows; the gate runs on registers)
+            A, h, status = ops.ga_scores(xb, packed, dims, "f16x3", with_status=True)
+            if not self._out_of_range(status):
+                return A, h
+            self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
+            return self._score_pass_composed(xb, dims, "fp32")
+        return self._score_pass_composed(xb, dims, "fp32" if self.precision == "fp32" else "f16x3")
+
+    def _score_pass_composed(self, xb, dims, prec):
         base = self._raw_params()[0]
-        prec = "fp32" if self.precision == "fp32" else "f16x3"
 
         status = None
 
@@ -315,6 +332,16 @@ class _GatedBase(nn.Module):
                 out = ops.ga_forward(xb, p32, d32, "fp32", want_scores=want_scores, want_preds=want_preds,
                                      want_bag_feat=want_bag_feat)
                 out["range_fallback"] = True
+            return out
+        if self._is_wide_fused():
+            # ONE fused launch + merge + heads; the range word is read after the call (one synchronisation per slide, as the composed
+            # path had in the middle of its forward); a flagged bag (never seen on real features) is redone op by op in fp32
+            out = ops.ga_forward(xb, packed, dims, "f16x3", want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
+            if not self._out_of_range(out["range_status"]):
+                return out
+            A, h = self._score_pass_composed(xb, dims, "fp32")
+            out = ops.ga_pool(h, A, packed, dims, self.precision, None, want_bag_feat=want_bag_feat)
+            out["range_fallback"] = True
             return out
         out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False)
         out.pop("h", None)
@@ -514,8 +541,14 @@ class ACMIL_GA(_GatedBase):
         bags = [b if b.is_contiguous() else b.contiguous() for b in bags]
         if any(b.dtype != bags[0].dtype for b in bags):      # one launch reads one storage format: widen (exactly) to fp32
             bags = [b.float() for b in bags]
-        if not self._is_fused():
-            outs = [self._eval_forward(b, packed, dims) for b in bags]
+        wide = self._is_wide_fused() and prec == "f16x3"
+        if not self._is_fused() and not wide:
+            save = self.precision
+            try:
+                self.precision = prec           # (an fp32 repeat of a wide-family batch: the composed path in that arithmetic)
+                outs = [self._eval_forward(b, packed, dims) for b in bags]
+            finally:
+                self.precision = save
             triples = [(o["sub_preds"], o["slide_pred"].unsqueeze(0), o["A_out"].unsqueeze(0)) for o in outs]
             return (triples, None) if defer_guard else triples
         out = ops.ga_forward_batch(bags, packed, dims, prec)
@@ -524,6 +557,8 @@ class ACMIL_GA(_GatedBase):
             if defer_guard:
                 status = RangeTicket(out["range_status"])      # async copy now: the next launch on this workspace overwrites the word
             elif self._out_of_range(out["range_status"]):      # some bag left the f16 range: redo in fp32
+                if wide:
+                    return self.forward_batch(bags, precision="fp32")
                 p32, d32 = self._packed_cached("fp32")
                 out = ops.ga_forward_batch(bags, p32, d32, "fp32")
         triples = [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]

@@ -255,7 +255,7 @@ extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K,
 // GEMM arithmetic follows the forward mode: exact fp32 MFMA, or split products -- f16 halves for the recomputed
 // pre-activations (forward-sized values), bf16 halves wherever an operand is a gradient (values down to 1e-8).
 // ACMIL_GA_BWD_TILE=0 keeps launches 3-5 separate (A/B measurements); read once
-static bool gb_use_tile() { static const bool v = [] { const char* e = getenv("ACMIL_GA_BWD_TILE"); return !(e && e[0] == '0'); }(); return v; }
+static bool gb_use_tile() { static const bool v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_BWD_TILE"); return !(e && e[0] == '0'); }(); return v; }
 
 int gb_run(const GbRun& r) {
     const int N = r.N, D = r.D, Di = r.Di, K = r.K;

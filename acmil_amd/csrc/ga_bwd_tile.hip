@@ -378,7 +378,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
 // tile height for a bag: 64 rows, or 32 when 64-row tiles would leave CUs without one (two workgroups fit a CU either way)
 static int bt_rows(int N) {
-    static const int forced = [] { const char* e = getenv("ACMIL_GA_BWD_ROWS"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_BWD_ROWS"); return e ? atoi(e) : 0; }();
     if (forced == 32 || forced == 64) return forced;
     return (N + 63) / 64 <= 320 ? 32 : 64;
 }

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "acmil_hip.h"
+#include "ab_knobs.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -119,11 +119,14 @@ __global__ __launch_bounds__(1024) void ga_heads_kernel(const float* __restrict_
 #define GA_FAMILY(ND, KP, MODE) int ga_fwd_family_##ND##_##KP##_##MODE(const GaFwdArgs&, int, bool, int, hipStream_t);
 #include "ga_families.inc"
 #undef GA_FAMILY
+#define GA3_FAMILY(ND, PB, KP) int ga_fwd3_family_##ND##_##PB##_##KP(const GaFwdArgs&, int, bool, hipStream_t);
+#include "ga_families3.inc"
+#undef GA3_FAMILY
 
 // kernel generation of the split-f16 families: 2 = software-pipelined loops (default), 1 = the first-generation kernel.
 // ACMIL_GA_KERNEL=1|2 overrides (A/B measurements); read once.
 static int ga_kernel_version() {
-    static const int v = [] { const char* e = getenv("ACMIL_GA_KERNEL"); return (e && atoi(e) == 1) ? 1 : 2; }();
+    static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_KERNEL"); return (e && atoi(e) == 1) ? 1 : 2; }();
     return v;
 }
 
@@ -134,13 +137,13 @@ static bool ga_use_v2(int mode) { return mode == ACMIL_MODE_F16X3 && ga_kernel_v
 // to a full tile change nothing (the two workgroups of a CU drift through every relative phase anyway, the second one
 // being ~25 % slower), so the default is 0; ACMIL_GA_DEPHASE keeps the knob for experiments.
 static int ga_dephase() {
-    static const int env = [] { const char* e = getenv("ACMIL_GA_DEPHASE"); return e ? atoi(e) : 0; }();
+    static const int env = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_DEPHASE"); return e ? atoi(e) : 0; }();
     return env > 0 ? env : 0;
 }
 
 // A/B knob (timing experiments): ACMIL_GA_MEMSET=1 zeroes the control block with a memset ahead of every launch and the
 // kernel skips its end-of-kernel counter reset (the round-2 scheme before the self-resetting block)
-static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") != nullptr; return v; }
+static bool ga_memset_mode() { static const bool v = ACMIL_AB_ENV("ACMIL_GA_MEMSET") != nullptr; return v; }
 
 // tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
 // workgroup per CU: the weight stream is staged once per 256 patches).  4 waves is the default for every launch, so the pooled results
@@ -149,19 +152,46 @@ static bool ga_memset_mode() { static const bool v = getenv("ACMIL_GA_MEMSET") !
 // one bag of 313 tiles 78.3 / 72.6, 391 (N = 50 000): 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- but 256 tiles:
 // 57.1 / 68.7, a single tile: 43.8 / 62.5, and the batched launches (6 256 tiles): 872 / 896.
 static int ga_v2_waves() {
-    static const int v = [] { const char* e = getenv("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
+    static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
     return v;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
 static int ga_pair_split() {
-    static const int v = [] { const char* e = getenv("ACMIL_GA2_PAIR"); return e ? (atoi(e) != 0) : 0; }();
+    static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA2_PAIR"); return e ? (atoi(e) != 0) : 0; }();
     return v;
+}
+
+// A/B builds: two workgroups per CU for the D_inner = 128 family on 16-bit bags (default three)
+static int ga_no_tri() { static const int v = ACMIL_AB_ENV("ACMIL_GA2_NO_TRI") != nullptr; return v; }
+
+// The one-wave-per-SIMD kernel (ga_forward_kernel_v3.h, split-f16 arithmetic only): the only fused kernel of the wide families
+// (D_inner 384 / 512: 32 patches per wave); at D_inner = 256 its 64-patch wave tile is chosen per launch by ga_pick_geometry().
+static bool ga_is_wide(int Di) { return Di == 384 || Di == 512; }
+static bool ga_has_v3(int Di, int K, int mode) { return mode == ACMIL_MODE_F16X3 && K <= 5 && (ga_is_wide(Di) || Di == 256); }
+
+// Geometry of a pooled (eval) launch.  Wide families: always v3.  D_inner = 256: ACMIL_GA3=0|1 forces (A/B builds); default below.
+static int ga_pick_v3(int Di, int K, int mode, int nbags, long long total_patches) {
+    if (!ga_has_v3(Di, K, mode)) return 0;
+    if (ga_is_wide(Di)) return 1;
+    static const int env = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA3"); return e ? atoi(e) : -1; }();
+    if (env == 0 || env == 1) return env;
+    (void)nbags; (void)total_patches;
+    return 0;
 }
 
 static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hipStream_t st) {
     const int ND = a.L.ND, K = a.L.K;
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
+    if (a.v3) {
+        if (mode != ACMIL_MODE_F16X3) return ACMIL_ERR_UNSUPPORTED;
+        const int PB = ND == 8 ? 2 : 1;
+#define GA3_FAMILY(ND_, PB_, KP_) \
+        if (ND == ND_ && PB == PB_ && KP == KP_) return ga_fwd3_family_##ND_##_##PB_##_##KP_(a, x_dtype, pool, st);
+#include "ga_families3.inc"
+#undef GA3_FAMILY
+        return ACMIL_ERR_UNSUPPORTED;
+    }
 #define GA_FAMILY(ND_, KP_, MODE_) \
     if (ND == ND_ && KP == KP_ && mode == MODE_) return ga_fwd_family_##ND_##_##KP_##_##MODE_(a, x_dtype, pool, ga_kernel_version(), st);
 #include "ga_families.inc"
@@ -220,7 +250,7 @@ static int ga_pick_waves(int maxN, long long total_patches = 0) {
     // one large bag; 4-wave (128-patch) workgroups, two per CU, spread small bags over more CUs and -- measured, 8 x 50 000
     // patches per launch: 524 vs 548 us -- balance better once a launch holds several rounds of tiles (>= 1024 of them).
     // ACMIL_GA_WAVES=4|8 overrides (tuning).
-    static const int env = [] { const char* e = getenv("ACMIL_GA_WAVES"); return e ? atoi(e) : 0; }();   // read once
+    static const int env = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_WAVES"); return e ? atoi(e) : 0; }();   // read once
     if (env == 4 || env == 8) return env;
     return (maxN >= 32768 && total_patches < 1024LL * 128) ? 8 : 4;
 }
@@ -257,7 +287,10 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
     a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(maxN, total_patches);
-    a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
+    a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
+    a.v3 = ga_pick_v3(Di, K, mode, nbags, total_patches);
+    if (a.v3) a.waves = ga_is_wide(Di) ? 4 : 8;        // tile rows = 32 * waves: 128 (32 patches per wave) / 256 (64 per wave)
+    if (a.v3 && !ga_use_v2(mode)) return ACMIL_ERR_UNSUPPORTED;
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
         a.xs[b] = b < nbags ? xs[b] : nullptr;
@@ -277,7 +310,7 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
         if (!a.status) return ACMIL_ERR_UNSUPPORTED;          // only the persistent split-f16 kernel publishes a status word
         GaFwdArgs b = a;                                       // same bags, same 128-patch tiles, same partial slots
         b.packed = (const char*)packed_fp32; b.L = ga_layout(D, Di, K, C, ACMIL_MODE_F32);
-        b.tile_counter = nullptr; b.status = nullptr; b.cond = a.status; b.cond_count = fallback_count;
+        b.tile_counter = nullptr; b.status = nullptr; b.cond = a.status; b.cond_count = fallback_count; b.v3 = 0;
         rc = ga_dispatch(b, ACMIL_MODE_F32, x_dtype, true, st);
         if (rc != ACMIL_OK) return rc;
     }
@@ -286,7 +319,7 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     // (measured: the single-launch finish of ga_step.hip -- ga_tail_eval -- costs 26 us against 12 us for these two launches at one
     // bag: its release / acquire fences and the one-workgroup heads outweigh the saved launch; it pays off only where it
     // replaces the six further launches of a training step.  ACMIL_GA_TAIL_EVAL=1 selects it for experiments.)
-    static const bool tail_eval = getenv("ACMIL_GA_TAIL_EVAL") != nullptr;
+    static const bool tail_eval = ACMIL_AB_ENV("ACMIL_GA_TAIL_EVAL") != nullptr;
     if (tail_eval && K <= 5)
         return ga_tail_eval(a.part, a.tile_start, nbags, packed, a.L, sub_preds, slide_pred, afeat ? afeat : (float*)((char*)a.part + poff),
                             bag_feat, has_bag_head, (unsigned*)workspace + 8, st);
@@ -334,7 +367,9 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
     a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(N);
-    a.dephase = ga_dephase(); a.pair_split = ga_pair_split();
+    a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
+    a.v3 = (ga_is_wide(Di) && ga_has_v3(Di, K, mode) && workspace) ? 1 : 0;      // score pass: the wide families only
+    if (a.v3) a.waves = 4;
     for (int b = 0; b < GA_MAX_BATCH; ++b) { a.xs[b] = nullptr; a.Ns[b] = 0; a.A_outs[b] = nullptr; a.tile_start[b + 1] = 0; }
     a.xs[0] = x; a.Ns[0] = N; a.A_outs[0] = A_out; a.tile_start[0] = 0;
     for (int b = 1; b <= GA_MAX_BATCH; ++b) a.tile_start[b] = (N + 32 * a.waves - 1) / (32 * a.waves);

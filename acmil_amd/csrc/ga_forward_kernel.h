@@ -50,6 +50,8 @@ struct GaFwdArgs {
     int self_reset;  // v2: 1 = the last workgroup leaves the control block's counters at zero (default); 0 = the host memsets (A/B knob)
     int pair_split;  // v2, D_inner = 256: GEMM1 with the feature tiles split over wave pairs (half the weight-fragment reads per MFMA)
     int dephase;     // v2: start delay of the second workgroup of a CU, in s_sleep(127) rounds (~8 k cycles each); 0 = none
+    int no_tri;      // v2, D_inner = 128 family on 16-bit bags: 1 = launch two workgroups per CU instead of three (A/B builds only)
+    int v3;          // 1 = the one-wave-per-SIMD kernel (ga_forward_kernel_v3.h): always for D_inner 384 / 512, 64-patch wave tiles at 256
     const unsigned* cond;     // v1 (fp32 repeat of the device-side range guard): run only if *cond != 0 (the status word the preceding
                               //     split-f16 launch on this stream left); null = unconditional
     unsigned* cond_count;     // v1: incremented once per launch that did run under `cond` (the module's fallback counter); may be null

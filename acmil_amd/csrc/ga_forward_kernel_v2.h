@@ -1077,8 +1077,7 @@ int ga_launch_fwd2_w(const GaFwdArgs& a, bool pool, hipStream_t st) {
             return ACMIL_ERR_LAUNCH;
         cus_of[dev] = prop.multiProcessorCount;
     }
-    static const bool no_tri = getenv("ACMIL_GA2_NO_TRI") != nullptr;      // A/B knob: two workgroups per CU for every family
-    const int wgs = pool ? ((GP::WGS == 3 && no_tri) ? 2 : GP::WGS) : GS::WGS;
+    const int wgs = pool ? ((GP::WGS == 3 && a.no_tri) ? 2 : GP::WGS) : GS::WGS;      // (no_tri: A/B builds, two workgroups per CU for every family)
     const int slots = wgs * cus_of[dev];
     const int tiles = a.tile_start[a.nbags];
     const dim3 grid(tiles < slots ? tiles : slots), block(64 * WV);

@@ -128,9 +128,13 @@ static int lin_launch64(const LinArgs& a, hipStream_t st) {
 // which kernel: lin64 needs four K steps per unrolled round; it is the default where it measured faster (profiles/r04_lin64_ablation.md:
 // long K loops, K >= 768, with at least one 256-row tile per CU -- the wide GA projections, 3 - 7 %); with K = 384 its epilogue, which no
 // second workgroup hides, costs what the leaner K loop gains.  ACMIL_LIN64=0 / 1 forces.
-static bool lin_use64(int M, int K, int nchunks) {
-    static const char* e = getenv("ACMIL_LIN64");
+static bool lin_use64(int M, int K, int nchunks, int nd) {
+    static const char* e = ACMIL_AB_ENV("ACMIL_LIN64");
     if (K % 64 != 0) return false;
+    // lin64_kernel keeps the bias of ALL columns of a launch in an LDS table of BIAS_MAX floats (its epilogue and the landmark sums read
+    // it up to column 32 nd nchunks): wider launches -- TransMIL's to_qkv at D_inner = 768 is 2 304 columns -- stay on lin_kernel, which
+    // reads the bias from global memory (columns 2048.. read past the table and the folded LayerNorm bias W beta was wrong)
+    if (32 * nd * nchunks > Lin64Geom<8, ACMIL_DTYPE_F32>::BIAS_MAX) return false;
     if (e) return e[0] == '1';
     // (M <= 65536: TransMIL's fc1 -- 100 000 rows, K = 768, 2 x 192 columns -- measured 223 vs 211 us with lin64, the same product on
     //  50 000 rows 103 - 109 vs 115 us)
@@ -139,7 +143,7 @@ static bool lin_use64(int M, int K, int nchunks) {
 
 template <int ND>
 static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
-    if (a.act != 2 && lin_use64(a.M, a.K, a.nchunks)) {
+    if (a.act != 2 && lin_use64(a.M, a.K, a.nchunks, ND)) {
         switch (x_dtype) {
             case ACMIL_DTYPE_F32: return lin_launch64<ND, ACMIL_DTYPE_F32>(a, st);
             case ACMIL_DTYPE_F16: return lin_launch64<ND, ACMIL_DTYPE_F16>(a, st);
@@ -215,7 +219,7 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
         a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
-        if (lin_use64(M, K, P.nmain)) rc = P.nd == 6 ? lin_launch64<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch64<8, ACMIL_DTYPE_F32, 3>(a, st);
+        if (lin_use64(M, K, P.nmain, P.nd)) rc = P.nd == 6 ? lin_launch64<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch64<8, ACMIL_DTYPE_F32, 3>(a, st);
         else rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 3>(a, st);
         if (rc != ACMIL_OK) return rc;
     }

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
     // (once a wait has timed out every later launch returns at once: a dead peer costs one timeout, not one per step)
     if (threadIdx.x == 0) s_ok = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 0;
     __syncthreads();
-    if (!s_ok) return;
+    // (the host sees a dead reduction through the tracked flag as well: -1 instead of the 0 / 1 of a live step, no extra synchronisation)
+    if (!s_ok) { if (flag_report && blockIdx.x == 0 && threadIdx.x == 0) __builtin_nontemporal_store(-1.0f, flag_report); return; }
     if ((int)threadIdx.x < world && (int)threadIdx.x != rank) {
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(myflags + threadIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step) {
@@ -60,7 +61,10 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
         }
     }
     __syncthreads();
-    if (!s_ok) { if (threadIdx.x == 0) atomicExch(err, 1); return; }
+    if (!s_ok) {
+        if (threadIdx.x == 0) { atomicExch(err, 1); if (flag_report && blockIdx.x == 0) __builtin_nontemporal_store(-1.0f, flag_report); }
+        return;
+    }
     __threadfence_system();
     // the range flag of the step rides behind the gradients (element n of every bucket): its sum decides for all ranks alike
     float flag = 0.0f;

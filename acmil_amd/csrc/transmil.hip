@@ -707,7 +707,7 @@ extern "C" size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C) {
 struct TmSide { hipStream_t s; hipEvent_t fork, join; int state; };      // state: 0 = untried, 1 = ready, -1 = unavailable
 static std::mutex tm_side_mutex;
 static TmSide* tm_side(hipStream_t st) {
-    static const bool off = [] { const char* e = getenv("ACMIL_TM_SIDE_STREAM"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_SIDE_STREAM"); return e && e[0] == '0'; }();
     if (off) return nullptr;
     static TmSide side[64];
     int dev = 0;
@@ -722,7 +722,7 @@ static TmSide* tm_side(hipStream_t st) {
         int least = 0, greatest = 0;
         t.state = -1;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; (void)hipGetLastError(); }
-        { const char* e = getenv("ACMIL_TM_SIDE_PRIO"); if (e && e[0] == '0') greatest = least; }      // A/B knob: normal priority
+        { const char* e = ACMIL_AB_ENV("ACMIL_TM_SIDE_PRIO"); if (e && e[0] == '0') greatest = least; }      // A/B knob: normal priority
         if (hipStreamCreateWithPriority(&t.s, hipStreamNonBlocking, greatest) == hipSuccess &&
             hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess)
@@ -739,7 +739,7 @@ static TmSide* tm_side(hipStream_t st) {
 // again by default; tests/test_transmil_gpu.py and tools/stress_transmil.py run the two-stream case.
 struct TmSerial { hipEvent_t done; hipStream_t last; int state; };      // state: 0 = no event yet, 1 = event exists, 2 = recorded
 static TmSerial* tm_serial(hipStream_t st, bool* capturing) {
-    static const bool off = [] { const char* e = getenv("ACMIL_TM_SERIAL"); return !(e && e[0] == '1'); }();
+    static const bool off = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_SERIAL"); return !(e && e[0] == '1'); }();
     static TmSerial ser[64];
     int dev = 0;
     *capturing = false;
@@ -769,9 +769,9 @@ static int tm_join(TmSide* sd, hipStream_t st) {
 #define TM_CHECK_LAUNCH() do { if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH; } while (0)
 #define TM_GEMM(...) do { int rc_ = acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 // nn.Linear products (activations x weights, both K-contiguous): split-f16 MFMA, ~1e-6 relative; ACMIL_TM_FP32_GEMM=1 keeps them exact
-static bool tm_linear_exact() { static const bool v = getenv("ACMIL_TM_FP32_GEMM") != nullptr; return v; }
+static bool tm_linear_exact() { static const bool v = ACMIL_AB_ENV("ACMIL_TM_FP32_GEMM") != nullptr; return v; }
 // Moore-Penrose products: exact fp32 by default; ACMIL_TM_PINV_X3=1 runs them as split-f16 (experiment)
-static bool tm_pinv_x3() { static const bool v = getenv("ACMIL_TM_PINV_X3") != nullptr; return v; }
+static bool tm_pinv_x3() { static const bool v = ACMIL_AB_ENV("ACMIL_TM_PINV_X3") != nullptr; return v; }
 #define TM_PINV_GEMM(...) do { int rc_ = tm_pinv_x3() ? acmil_gemm_f16x3(__VA_ARGS__) : acmil_gemm_f32(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 #define TM_LINEAR(...) do { int rc_ = tm_linear_exact() ? acmil_gemm_f32(__VA_ARGS__) : acmil_gemm_f16x3(__VA_ARGS__); if (rc_ != ACMIL_OK) return rc_; } while (0)
 
@@ -791,7 +791,7 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
 // split GEMM; otherwise, and for ACMIL_TM_FP32_GEMM=1 (exact fp32 MFMA), the generic GEMMs.  ACMIL_TM_GENERIC_GEMM=1: A/B knob.
 static int tm_linear(const float* x, int M, int K, long long ldx, const float* W, int n_out, const float* bias, int act, float beta,
                      float* y, long long ldy, char* pkw, void* linws, void* gws, hipStream_t st, bool prepacked = false) {
-    static const bool generic = getenv("ACMIL_TM_GENERIC_GEMM") != nullptr;
+    static const bool generic = ACMIL_AB_ENV("ACMIL_TM_GENERIC_GEMM") != nullptr;
     const bool lin_ok = !tm_linear_exact() && !generic && acmil_linear_packed_bytes(n_out, K) != 0 && ((size_t)x & 15) == 0 &&
                         ((size_t)ldx * 4) % 16 == 0 && ldy >= n_out && ((size_t)y & 15) == 0 && ldy % 4 == 0;
     if (lin_ok) {
@@ -857,7 +857,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
     // chain below stays as the path for other widths and as the A/B reference (ACMIL_TM_UNFUSED=1)
-    static const bool force_unfused = getenv("ACMIL_TM_UNFUSED") != nullptr;
+    static const bool force_unfused = ACMIL_AB_ENV("ACMIL_TM_UNFUSED") != nullptr;
     const bool fused = tm_attn_fused_supported(Di) && !force_unfused;
     int rc = ACMIL_OK;
     if (!fused) {
@@ -868,9 +868,9 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration -- on the side stream beside the attn3 leg where both
     // run on their own kernels and scratch (the generic-GEMM paths share the split-K workspace: serial)
     const hipStream_t st_main = st;
-    static const bool pinv_knobs = getenv("ACMIL_TM_PINV_FUSED") != nullptr || getenv("ACMIL_TM_PINV_CHAIN") != nullptr;
+    static const bool pinv_knobs = ACMIL_AB_ENV("ACMIL_TM_PINV_FUSED") != nullptr || ACMIL_AB_ENV("ACMIL_TM_PINV_CHAIN") != nullptr;
     const bool forked = fused && d % 4 == 0 && d <= 128 && m <= 512 && tm_pinv_tiles_supported(m) && !pinv_knobs && tm_fork(side, st);
-    static const bool side_swap = getenv("ACMIL_TM_SIDE_SWAP") != nullptr;        // A/B knob: the attn3 leg on the side stream instead
+    static const bool side_swap = ACMIL_AB_ENV("ACMIL_TM_SIDE_SWAP") != nullptr;        // A/B knob: the attn3 leg on the side stream instead
     const hipStream_t st_chain = (forked && !side_swap) ? side->s : st_main, st_leg = (forked && side_swap) ? side->s : st_main;
     st = st_chain;
     if (d % 4 == 0 && d <= 128 && m <= 512) {
@@ -886,7 +886,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         TM_GEMM(0, 1, m, m, d, scale, QL, d, md, KL, ACMIL_DTYPE_F32, d, md, 0.0f, S2, m, mm, nullptr, 0, nullptr, H, gws, st);
         rc = tm_softmax_short(S2, (long long)H * m, m, st); if (rc != ACMIL_OK) return rc;
     }
-    static const bool maxsum_old = getenv("ACMIL_TM_MAXSUM_OLD") != nullptr;       // A/B knob: one 16-wave workgroup per head
+    static const bool maxsum_old = ACMIL_AB_ENV("ACMIL_TM_MAXSUM_OLD") != nullptr;       // A/B knob: one 16-wave workgroup per head
     if (maxsum_old) hipLaunchKernelGGL(tm_pinv_maxsum_kernel, dim3(H), dim3(1024), 0, st, S2, m, scal);
     else hipLaunchKernelGGL(tm_pinv_maxsum2_kernel, dim3((m + 15) / 16, H), dim3(128), 0, st, S2, m, scal);
     TM_CHECK_LAUNCH();
@@ -896,8 +896,8 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     // product costs ~16 us there (MFMA floor 4.3 us on one CU + staging / store / barrier latency) against 12.6 us for the
     // launch-per-product chain over 72 workgroups (exact fp32 MFMA) below: 3.70 vs 3.56 ms per N = 100 000 slide.  Also measured
     // without gain: the chain on a second stream beside the fused attention leg (3.60 vs 3.62 ms).
-    static const bool pinv_one = getenv("ACMIL_TM_PINV_FUSED") != nullptr;
-    static const bool pinv_chain = getenv("ACMIL_TM_PINV_CHAIN") != nullptr;       // A/B knob: the generic-GEMM chain
+    static const bool pinv_one = ACMIL_AB_ENV("ACMIL_TM_PINV_FUSED") != nullptr;
+    static const bool pinv_chain = ACMIL_AB_ENV("ACMIL_TM_PINV_CHAIN") != nullptr;       // A/B knob: the generic-GEMM chain
     bool pinv_fused = tm_pinv_fused_supported(m) && pinv_one;
     if (!pinv_fused && !pinv_chain && tm_pinv_tiles_supported(m)) {
         // default: one wave per 16 x 16 output tile, whole K in registers, exact fp32 MFMA (transmil_pinv.hip): 24 + 1 launches of ~3 us
@@ -991,7 +991,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     TmLayerW l1 = {layer1[0], layer1[1], layer1[2], layer1[3], layer1[4], layer1[5]};
     TmLayerW l2 = {layer2[0], layer2[1], layer2[2], layer2[3], layer2[4], layer2[5]};
     {
-        static const bool generic = getenv("ACMIL_TM_GENERIC_GEMM") != nullptr;
+        static const bool generic = ACMIL_AB_ENV("ACMIL_TM_GENERIC_GEMM") != nullptr;
         if (!tm_linear_exact() && !generic && acmil_linear_packed_bytes(Di, D) && acmil_linear_packed_bytes(3 * Di, Di) && acmil_linear_packed_bytes(Di, Di)) {
             const size_t pk = tm_al((size_t)Di * D * 4), q = tm_al((size_t)3 * Di * Di * 4), o = tm_al((size_t)Di * Di * 4);
             char* base = ws + W.PKW;
@@ -1000,7 +1000,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
             const int ldw[5] = {D, Di, Di, Di, Di}, no[5] = {Di, 3 * Di, Di, 3 * Di, Di}, Kk[5] = {D, Di, Di, Di, Di};
             void* outp[5] = {pk1, pkq[0], pko[0], pkq[1], pko[1]};
             // ACMIL_TM_LN_PASS=1: the round-3 pipeline (LayerNorm pass, plain to_qkv, landmark pass) -- A/B knob and test reference
-            static const bool ln_pass = getenv("ACMIL_TM_LN_PASS") != nullptr;
+            static const bool ln_pass = ACMIL_AB_ENV("ACMIL_TM_LN_PASS") != nullptr;
             fold_ln = !ln_pass;
             const float* cs[5] = {nullptr, fold_ln ? l1.norm_w : nullptr, nullptr, fold_ln ? l2.norm_w : nullptr, nullptr};
             // fc1's stream is all the first product needs; the four layer streams and W beta are formed beside it on the side stream
@@ -1044,7 +1044,7 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     }
     {
         const int tiles = (g.side + TM_PT - 1) / TM_PT;
-        static const bool ppeg_scalar = getenv("ACMIL_TM_PPEG_SCALAR") != nullptr;       // A/B knob
+        static const bool ppeg_scalar = ACMIL_AB_ENV("ACMIL_TM_PPEG_SCALAR") != nullptr;       // A/B knob
         if (Di % 64 == 0 && !ppeg_scalar)
             hipLaunchKernelGGL(tm_ppeg2_kernel, dim3(Di / 64, tiles * tiles), dim3(256), 0, st, XA + (size_t)(g.pad + 1) * Di,
                                XB + (size_t)(g.pad + 1) * Di, g.side, Di, weff, beff, cls_in, cls_out);

@@ -641,7 +641,7 @@ size_t tm_attn3_partial_bytes(int npad, int Di) {
 }
 
 // ACMIL_TM_ATTN_FP32=1 selects the exact-fp32 MFMA kernels (A/B reference); default = split-f16
-static bool tm_attn_exact() { static const bool v = getenv("ACMIL_TM_ATTN_FP32") != nullptr; return v; }
+static bool tm_attn_exact() { static const bool v = ACMIL_AB_ENV("ACMIL_TM_ATTN_FP32") != nullptr; return v; }
 
 template <int MT>
 static int tm_attn1x_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
@@ -663,7 +663,7 @@ template <int MT>
 static int tm_attn1_launch(const float* QKV, const float* KL, const float* W2, float* OUT, int npad, int Di, float scale, hipStream_t st,
                            const float* convw, int* conv_done) {
     // ACMIL_TM_SEQCONV_PASS=1: keep the residual convolution as a pass of its own (A/B knob); the exact-fp32 leg never folds it
-    static const bool conv_pass = getenv("ACMIL_TM_SEQCONV_PASS") != nullptr;
+    static const bool conv_pass = ACMIL_AB_ENV("ACMIL_TM_SEQCONV_PASS") != nullptr;
     if (!tm_attn_exact()) {
         const bool fold = convw != nullptr && !conv_pass;
         *conv_done = fold ? 1 : 0;
@@ -703,7 +703,7 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     // 96 (three workgroups per CU) 2.414, 128 2.475 -- the leg is not occupancy-limited, more chunks only add partials.
     // shared = the Moore-Penrose chain runs beside this launch on the side stream (transmil.hip): 32 chunks = ONE workgroup per CU leave
     // that chain room on every SIMD -- the leg alone takes 173 instead of 150 us, the pair 234 us instead of 266 (forward 2.18 vs 2.21 ms)
-    static const int forced = [] { const char* e = getenv("ACMIL_TM_ATTN3_CHUNKS"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > TMA_MAX_CHUNKS ? TMA_MAX_CHUNKS : v); }();
+    static const int forced = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_ATTN3_CHUNKS"); const int v = e ? atoi(e) : 0; return v < 1 ? 0 : (v > TMA_MAX_CHUNKS ? TMA_MAX_CHUNKS : v); }();
     const int want = forced ? forced : (shared ? 32 : 64);
     int nchunks = nblk < want ? nblk : want;
     const int bpc = (nblk + nchunks - 1) / nchunks;
@@ -713,7 +713,7 @@ static int tm_attn3_launch(const float* QKV, const float* QL, float* AV, float* 
     // MT = 6 alone on the GPU: two chunks per 12-wave workgroup (3 waves on every SIMD instead of 4, 4, 2, 2: 2.21 vs 2.23 ms per forward);
     // beside the Moore-Penrose chain the 6-wave workgroups stay, one per CU (32 chunks): measured 2.07 ms against 2.12 with the 12-wave
     // form, whose three waves per SIMD leave the chain's waves too few issue slots.  ACMIL_TM_ATTN3_GRP=1 / 2 forces one form (A/B).
-    static const int grp_forced = [] { const char* e = getenv("ACMIL_TM_ATTN3_GRP"); return e ? atoi(e) : 0; }();
+    static const int grp_forced = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_ATTN3_GRP"); return e ? atoi(e) : 0; }();
     constexpr int GRP = (MT == 6) ? 2 : 1;
     const bool grp1 = grp_forced == 1 || (grp_forced != 2 && shared);
     if (tm_attn_exact()) hipLaunchKernelGGL(tm_attn3_kernel<MT>, dim3(nchunks, TMA_HEADS), dim3(64 * MT), 0, st, QKV, QL, part_ms, part_o, npad, Di, scale, bpc);

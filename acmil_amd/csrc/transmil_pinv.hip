@@ -360,7 +360,7 @@ static int tm_pinv_tiles_run(const float* X, float* Z, float* ZT, float* Wp, flo
     hipLaunchKernelGGL(tm_pinv_init2_kernel, dim3(512), dim3(128), 0, st, X, M, scal, Z, ZT);
     const unsigned nblk = 2 * (M / 32) * (M / 32) * TP_HEADS;      // two-wave workgroups: two per 32 x 32 block
     const dim3 block(128);
-    static const bool y_each = getenv("ACMIL_TM_PINV_Y1") != nullptr;      // A/B knob: recompute y = x z in every iteration (round 3)
+    static const bool y_each = ACMIL_AB_ENV("ACMIL_TM_PINV_Y1") != nullptr;      // A/B knob: recompute y = x z in every iteration (round 3)
     if (LY && WY && !y_each) {
         hipLaunchKernelGGL((tm_pinv_prod_kernel<M, TQ_Y>), dim3(nblk), block, 0, st, X, ZT, (const float*)nullptr, (const float*)nullptr, Y, YT, (float*)nullptr,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr);

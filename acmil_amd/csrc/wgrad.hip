@@ -233,12 +233,12 @@ __global__ __launch_bounds__((WgGeom<TM, TN>::THREADS), (TN == 256 ? 1 : 2)) voi
 // Column extent of the output tile for a pair of products: 256 whenever both N allow it (measured 23.1 vs 24.0 us at N = 10 000,
 // 76 vs 88 us at N = 50 000); ACMIL_WGRAD_TILE=128 keeps the 128 x 128 tiles (A/B measurements)
 static int wg_tile_n(int N1, int N2, int K) {
-    static const int forced = [] { const char* e = getenv("ACMIL_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char* e = ACMIL_AB_ENV("ACMIL_WGRAD_TILE"); return e ? atoi(e) : 0; }();
     (void)K;
     return (forced == 128 || N1 % 256 || N2 % 256) ? 128 : 256;
 }
 // K split shared by both products: two (128 x 128) / one (128 x 256) workgroups per CU over the two tile lists, at least 4 K steps per workgroup
-static int wg_target_wgs(int TN) { static const int v = [] { const char* e = getenv("ACMIL_WGRAD_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : (TN == 256 ? 256 : 512); }   // (128 x 128, measured 256..768: 512 is 24 us faster than 256 at N = 50 000)
+static int wg_target_wgs(int TN) { static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_WGRAD_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : (TN == 256 ? 256 : 512); }   // (128 x 128, measured 256..768: 512 is 24 us faster than 256 at N = 50 000)
 static int wg_pick_splits(int tiles_total, int K, int TN) {
     const int steps = (K + 31) / 32;
     int s = TN == 256 ? wg_target_wgs(TN) / tiles_total : (wg_target_wgs(TN) + tiles_total - 1) / tiles_total;

@@ -59,6 +59,8 @@ class FlatAdamW:
         self.peer = peer
         if peer is not None and (grad_buffer is None or peer.n_total != self.grad.numel()):
             raise RuntimeError("acmil_amd.FlatAdamW: the peer reducer works on the shared gradient bucket (grad_buffer), same size")
+        if peer is not None:
+            peer.owner = self      # tells train.GradBucket.allreduce_mean that the reduction now happens inside this optimizer's launch
         self._frozen = []          # (offset, numel) ranges that receive no gradient this run: skipped like torch skips grad=None
 
     def set_frozen(self, params: Iterable[torch.nn.Parameter]):
@@ -128,7 +130,11 @@ class FlatAdamW:
         while self._pending and self._pending[0][0] <= self._step_id - lag:
             sid, ev, slot = self._pending.popleft()
             ev.synchronize()
-            if float(self._host_flags[slot]) != 0.0:
+            f = float(self._host_flags[slot])
+            if f < 0.0:            # acmil_adamw_step_peer: a peer's gradient flag never arrived, the launch changed nothing
+                raise RuntimeError("acmil_amd.FlatAdamW: direct gradient reduction timed out at step %d (a peer rank did not publish "
+                                   "within %.0f s); no update was applied" % (sid, self.peer.timeout_s if self.peer is not None else 0.0))
+            if f != 0.0:
                 out.append(sid)
                 self.step_count -= 1
                 self.skipped_steps += 1

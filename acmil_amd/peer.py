@@ -28,13 +28,18 @@ PEER_MAX = 8
 
 
 class PeerReducer:
-    def __init__(self, n_total: int, device: torch.device, rank: int, world: int, group=None, timeout_s: float = 5.0):
+    def __init__(self, n_total: int, device: torch.device, rank: int, world: int, group=None, timeout_s: Optional[float] = None):
         """n_total = elements of the flat bucket (gradients + the range-flag slot).  Collective: every rank of `group` must call it."""
         import torch.distributed as dist
         from torch.multiprocessing.reductions import reduce_tensor
         if not (1 < world <= PEER_MAX):
             raise RuntimeError("acmil_amd.PeerReducer: 2..%d ranks of one node" % PEER_MAX)
+        # how long an optimizer launch waits for its peers' gradients before it gives up (RCCL would wait for ever): long enough for a
+        # peer that reads a large slide from a cold disk or initialises lazily on its first step; ACMIL_PEER_TIMEOUT_S overrides
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("ACMIL_PEER_TIMEOUT_S", "120"))
         self.n_total, self.device, self.rank, self.world, self.timeout_s = n_total, torch.device(device), rank, world, timeout_s
+        self.owner = None          # the FlatAdamW that runs the reduction inside its launch (set by its constructor)
         # [slot 0 | slot 1] fp32 and the flag array live in their own allocations (an IPC handle covers a whole allocation)
         self.slots = torch.zeros(2, n_total, dtype=torch.float32, device=self.device)
         self.flags = torch.zeros(PEER_MAX, dtype=torch.int32, device=self.device)

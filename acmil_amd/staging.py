@@ -46,6 +46,7 @@ class BagPrefetcher:
         self.depth = max(2, depth)
         self.max_bytes = max_bytes            # budget for the device memory of ALL ring slots (None: `depth` slots whatever their size)
         self.alloc_bytes = 0                  # device bytes the ring holds now
+        self.peak_bytes = 0                   # ... and the most it ever held
         self.slots_made = 0
         self.cuda = self.device.type == "cuda"
         self._ready: "queue.Queue" = queue.Queue()
@@ -97,7 +98,28 @@ class BagPrefetcher:
                     self._ready.put((None, x, int(item["label"]), i))
                     continue
                 n = x.numel()
-                slot = self._take_slot(n * x.element_size())  # back-pressure: at most `depth` bags / `max_bytes` of ring in flight
+                need = n * x.element_size()
+                grown_b = int(n * 1.25) * x.element_size()
+                while True:
+                    slot = self._take_slot(need)              # back-pressure: at most `depth` bags / `max_bytes` of ring in flight
+                    if self._stop or slot is None:
+                        break
+                    # The budget holds on REGROWTH too (slots created for small bags were later regrown to the largest bag
+                    # without a look at max_bytes).  A recycled slot whose regrowth would leave the budget is retired -- its buffer goes
+                    # back to the allocator once its readers are done -- and the ring continues with one slot fewer (never fewer than two).
+                    old_b = 0 if slot.dev is None else slot.dev.numel() * slot.dev.element_size()
+                    regrow = slot.dev is None or slot.dev.numel() < n or slot.dev.dtype != x.dtype
+                    if (regrow and self.max_bytes is not None and self.slots_made > 2
+                            and self.alloc_bytes - old_b + grown_b > self.max_bytes):
+                        with torch.cuda.stream(self.copy_stream):
+                            if slot.consumed is not None:
+                                self.copy_stream.wait_event(slot.consumed)
+                            slot.dev = None
+                        self.alloc_bytes -= old_b
+                        self.slots_made -= 1
+                        self.peak_bytes = max(self.peak_bytes, self.alloc_bytes)
+                        continue
+                    break
                 if self._stop or slot is None:
                     break
                 with torch.cuda.stream(self.copy_stream):
@@ -108,6 +130,7 @@ class BagPrefetcher:
                         slot.dev = None                      # (the old buffer goes back to the allocator before the new one is taken)
                         slot.dev = torch.empty(int(n * 1.25), dtype=x.dtype, device=self.device)
                         self.alloc_bytes += slot.dev.numel() * slot.dev.element_size() - old
+                        self.peak_bytes = max(self.peak_bytes, self.alloc_bytes)
                         slot.copied = torch.cuda.Event()
                     slot.dev[:n].copy_(x.reshape(-1), non_blocking=True)
                     slot.copied.record(self.copy_stream)

@@ -211,8 +211,10 @@ class GradBucket:
         return self.peer is not None
 
     def allreduce_mean(self, world: int):
-        if self.peer is not None:       # reduced by FlatAdamW.step itself (acmil_adamw_step_peer)
-            return
+        # the direct path replaces the collective ONLY once an optimizer has taken the reducer over (FlatAdamW sets `owner`): with any
+        # other optimizer (conf.torch_optimizer) nobody would reduce at all and the ranks would silently diverge
+        if self.peer is not None and getattr(self.peer, "owner", None) is not None:
+            return                      # reduced by FlatAdamW.step itself (acmil_adamw_step_peer)
         if world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
@@ -255,7 +257,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     def settle(lag):
         nonlocal acc
         limit = optimizer._step_id - lag
-        skipped = optimizer.poll_skipped(lag)                    # tracked steps <= limit whose flag the device saw set
+        # tracked steps <= limit whose flag the device saw set (a timed-out peer wait of the direct reduction raises here, two steps late)
+        skipped = optimizer.poll_skipped(lag)
         for sid in [k for k in sorted(recent) if k <= limit]:
             idx, ls = recent.pop(sid)
             if sid not in skipped:
@@ -292,6 +295,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
         if lagged:
             recent[sid] = (item["index"], losses)
             settle(2)
+        if log_every and (it + 1) % log_every == 0 and bucket is not None and bucket.peer is not None:
+            bucket.peer.check()          # untracked steps (no lagged flag): look at the reducer's timeout word where the loop syncs anyway
         if rank == 0 and log_every and (it + 1) % log_every == 0:
             a = acc.tolist()
             sums = {"sub_loss": a[0], "slide_loss": a[1], "diff_loss": a[2]}
@@ -301,6 +306,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
                 sums["diff_loss"] / (it + 1), sums["slide_loss"] / (it + 1), (it + 1) / (time.time() - t0)))
     if lagged:
         settle(0)
+    if bucket is not None and bucket.peer is not None:
+        bucket.peer.check()              # a peer that never published leaves this rank's updates unapplied: raise, never train on silently
     n = max(1, len(order))
     a = acc.tolist()
     return {"sub_loss": a[0] / n, "slide_loss": a[1] / n, "diff_loss": a[2] / n}
@@ -315,7 +322,8 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     order = epoch_order(len(data), 0, 0, False, rank, world, drop_last=False)
     probs, labels, losses, divs = [], [], [], []
     label_dev = torch.arange(conf.n_class, device=device)
-    if batched and device.type == "cuda" and hasattr(model, "forward_batch") and getattr(model, "_is_fused", lambda: False)():
+    if batched and device.type == "cuda" and hasattr(model, "forward_batch") and (
+            getattr(model, "_is_fused", lambda: False)() or getattr(model, "_is_wide_fused", lambda: False)()):
         # GA at the fused widths: up to EVAL_BATCH = 64 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times), and
         # the split-f16 range word of a batch is looked at only after the NEXT batch has been enqueued, so the GPU never idles
         # on the check; a flagged batch (never seen on real features) is re-read and repeated in fp32 arithmetic.
@@ -399,6 +407,10 @@ def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, l
             # grad None in the reference and torch's AdamW leaves them untouched (no weight decay)
             opt.set_frozen(list(model.classifier[0].parameters()))
         return opt
+    if bucket is not None and bucket.peer is not None:
+        # the direct reduction lives inside FlatAdamW's launch: with torch's optimizer the bucket goes back to the collective
+        print("acmil_amd.train: --dp-reduce direct needs FlatAdamW; using torch.distributed all_reduce with torch.optim.AdamW")
+        bucket.peer = None
     return torch.optim.AdamW(params, lr=lr, weight_decay=conf.wd)
 
 

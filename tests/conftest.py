@@ -9,6 +9,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The A/B twin of the library (csrc/ab_knobs.h): the only build that reads the ACMIL_* measurement switches.  Tests that compare
+# kernel variants run their subprocesses on it (ab_environ); everything else runs on the product library, which reads none.
+AB_LIB = os.path.join(ROOT, "acmil_amd", "libacmil_hip_ab.so")
+
+
+def ab_environ(**knobs):
+    """Environment of a subprocess that runs on the A/B build with the given ACMIL_* switches set (all others cleared)."""
+    e = {k: v for k, v in os.environ.items() if not k.startswith("ACMIL_")}
+    e["ACMIL_HIP_LIB"] = AB_LIB
+    e.update(knobs)
+    return e
 
 
 def pytest_configure(config):

@@ -30,6 +30,34 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.acmil_version().startswith(b"acmil_hip")
 
 
+def test_product_library_reads_no_environment_variable(lib):
+    """Measurement switches (csrc/ab_knobs.h) are compiled out of the product build: no ACMIL_* name is even present in
+    libacmil_hip.so, so a stray variable in a user's environment cannot change kernels or summation order; the A/B twin built
+    beside it (tests / tools load it through ACMIL_HIP_LIB) carries them, and both export the same C ABI."""
+    import subprocess
+    from acmil_amd import _lib
+    from conftest import AB_LIB
+    prod = os.path.join(ROOT, "acmil_amd", "libacmil_hip.so")
+
+    def names(path):
+        return set(re.findall(rb"ACMIL_[A-Z0-9_]+", open(path, "rb").read()))
+
+    assert names(prod) == set(), names(prod)
+    ab = names(AB_LIB)
+    assert {b"ACMIL_GA2_WAVES", b"ACMIL_TM_SIDE_STREAM", b"ACMIL_GA_BWD_TILE", b"ACMIL_LIN64"} <= ab
+    # the only environment variables of the product live in Python and choose WHICH library / reduction runs, not how it computes
+    py = set()
+    for root, _, files in os.walk(os.path.join(ROOT, "acmil_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                py |= set(re.findall(r"environ[^\n]*?[\"'](ACMIL_[A-Z0-9_]+)[\"']", open(os.path.join(root, f)).read()))
+    assert py == {"ACMIL_HIP_LIB", "ACMIL_DP_REDUCE", "ACMIL_PEER_TIMEOUT_S"}, py
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("acmil_")}
+    assert exported(prod) == exported(AB_LIB) == set(_lib.SIGNATURES)
+
+
 def test_size_queries_and_argument_validation(lib):
     from acmil_amd import _lib
     # sizes: D=512, Di=256, K=5, C=2

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import EVAL_CASES, TRAIN_CASES, case_dims, load_golden
+from conftest import EVAL_CASES, TRAIN_CASES, ab_environ, case_dims, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -245,7 +245,7 @@ def test_wave_pair_split_variant_matches_default():
     res = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("base", {}), ("pair", {"ACMIL_GA2_PAIR": "1"}), ("w8", {"ACMIL_GA2_WAVES": "8"}), ("w4", {"ACMIL_GA2_WAVES": "4"})):
-            e = dict(os.environ); e.pop("ACMIL_GA2_PAIR", None); e.pop("ACMIL_GA2_WAVES", None); e.update(env)
+            e = ab_environ(**env)
             path = os.path.join(d, tag + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-2000:]

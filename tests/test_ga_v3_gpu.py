@@ -1,0 +1,151 @@
+"""The one-wave-per-SIMD fused forward (csrc/ga_forward_kernel_v3.h) against the CPU oracle: the wide families it was built for
+(CLIP-L 768 -> 384, UNI 1024 -> 512; Step3_WSI_classification_ACMIL.py:78-87) at tile-boundary bag sizes, all three storage
+formats, ragged batches, the score pass of a training step, and the 64-patch wave tile of the D_inner = 256 family (A/B build)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import ab_environ
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _model(d, di, k, c, seed=0, **kw):
+    from acmil_amd import synthetic as S
+    from acmil_amd.architecture.transformer import ACMIL_GA
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = d, di, c, k
+
+    m = ACMIL_GA(Conf, n_token=k, n_masked_patch=10, mask_drop=0.6, **kw)
+    sd = S.ga_state_dict(d, di, c, k, seed=seed)
+    m.load_state_dict(sd)
+    return m.cuda().eval(), sd
+
+
+@pytest.mark.parametrize("d,di", [(768, 384), (1024, 512)])
+@pytest.mark.parametrize("k,c", [(5, 2), (1, 7), (3, 3)])
+def test_wide_fused_forward_matches_oracle(d, di, k, c):
+    """N = 1, a partial wave block, one row past a 128-patch tile, several tiles, more tiles than CUs (dynamic draws)."""
+    from oracle import ga_oracle as O
+    model, sd = _model(d, di, k, c, seed=d + k)
+    assert model._is_wide_fused()
+    for i, n in enumerate([1, 31, 129, 640, 4097, 40000]):
+        x = O.synthetic_bag(n, d, slide_idx=70 + i)
+        with torch.no_grad():
+            sub, slide, a = model(x.cuda())
+        ref = O.acmil_ga_forward(x, sd, n_token=k)
+        assert (a[0].cpu() - ref["A_out"]).abs().max().item() < TOL, n
+        assert (sub.cpu() - ref["sub_preds"]).abs().max().item() < TOL, n
+        assert (slide[0].cpu() - ref["slide_pred"]).abs().max().item() < TOL, n
+        kk = min(10, n)
+        assert torch.equal(torch.topk(a[0].cpu(), kk, dim=-1).indices, torch.topk(ref["A_out"], kk, dim=-1).indices), n
+    assert model.range_fallbacks == 0
+
+
+@pytest.mark.parametrize("d,di", [(768, 384), (1024, 512)])
+def test_wide_fused_16bit_bags_and_ragged_batch(d, di):
+    """fp16 / bf16 bags are converted in registers (no lo plane): bit-identical to the fp32 launch of the same values; a ragged
+    batch in one launch equals the per-bag launches bit for bit (same 128-patch tiles, fixed-order merge)."""
+    from oracle import ga_oracle as O
+    model, sd = _model(d, di, 5, 2, seed=3)
+    ns = [300, 1, 5000, 129, 17000]
+    bags = [O.synthetic_bag(n, d, slide_idx=90 + i)[0] for i, n in enumerate(ns)]
+    for cast in (torch.float16, torch.bfloat16):
+        lo = [b.to(cast).cuda() for b in bags]
+        with torch.no_grad():
+            single = [model(b.unsqueeze(0)) for b in lo]
+            widened = [model(b.float().unsqueeze(0)) for b in lo]
+            batch = model.forward_batch(lo)
+        for (s0, b0, a0), (s1, b1, a1), (s2, b2, a2) in zip(single, widened, batch):
+            assert torch.equal(a0, a1) and torch.equal(s0, s1) and torch.equal(b0, b1)
+            assert torch.equal(a0, a2) and torch.equal(s0, s2) and torch.equal(b0, b2)
+    ref = O.acmil_ga_forward(bags[2].half().float().unsqueeze(0), sd, n_token=5)
+    with torch.no_grad():
+        sub, slide, a = model(bags[2].half().cuda().unsqueeze(0))
+    assert (a[0].cpu() - ref["A_out"]).abs().max().item() < TOL and (sub.cpu() - ref["sub_preds"]).abs().max().item() < TOL
+
+
+def test_wide_fused_range_guard_falls_back_to_fp32():
+    """A bag value outside the f16 range: the fused launch flags it, the module redoes the bag op by op in fp32 arithmetic."""
+    from oracle import ga_oracle as O
+    model, sd = _model(1024, 512, 5, 2, seed=1)
+    x = O.synthetic_bag(700, 1024, slide_idx=5)
+    x[0, 123, 7] = 1.0e5
+    with torch.no_grad():
+        sub, slide, a = model(x.cuda())
+    ref = O.acmil_ga_forward(x, sd, n_token=5)
+    assert model.range_fallbacks == 1 and torch.isfinite(a).all()
+    assert (a[0].cpu() - ref["A_out"]).abs().max().item() < 2e-2 * ref["A_out"].abs().max().item() + TOL      # fp32 arithmetic on 1e5-sized operands
+    assert (sub.cpu() - ref["sub_preds"]).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("d,di", [(768, 384), (1024, 512)])
+def test_wide_score_pass_saves_h_and_trains(d, di):
+    """Score pass of a training step at the wide widths through the fused kernel: A and h (fp32 rows, relu applied) against the
+    oracle's projection, then one op-by-op training step against the oracle's autograd."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    model, sd = _model(d, di, 5, 3, seed=11)
+    x = O.synthetic_bag(3000, d, slide_idx=3)
+    packed, dims = model._packed()
+    A, h = ops.ga_scores(x[0].cuda(), packed, dims, "f16x3")
+    h_ref = torch.relu(x[0].double() @ sd["dimreduction.fc1.weight"].double().T).float()
+    assert (h.cpu() - h_ref).abs().max().item() < 2e-5 * max(1.0, h_ref.abs().max().item())
+    ref = O.acmil_ga_forward(x, sd, n_token=5)
+    assert (A.cpu() - ref["A_out"]).abs().max().item() < TOL
+    model.train()
+    u = torch.rand(5, 10, generator=torch.Generator().manual_seed(4)).cuda()
+    y = torch.tensor([2], device="cuda")
+    losses, out = model.train_step(x.cuda(), y, uniforms=u)
+    # the same step through the oracle's autograd (transformer.py:305-330 + Step3_WSI_classification_ACMIL.py:201-216)
+    sdg = {n: v.clone().requires_grad_(True) for n, v in sd.items()}
+    r = O.acmil_ga_forward(x, sdg, n_token=5, n_masked_patch=10, mask_drop=0.6, training=True, uniforms=u.cpu())
+    l0, l1, dl = O.acmil_losses(r["sub_preds"], r["slide_pred"], r["A_out"], y.cpu(), 5)
+    (dl + l0 + l1).backward()
+    assert torch.equal(out["masked_idx"].cpu().sort(1).values, r["masked_idx"].sort(1).values)
+    assert abs(losses[3].item() - (dl + l0 + l1).item()) < 1e-4
+    for (n, p) in model.named_parameters():
+        g = sdg[n].grad
+        assert (p.grad.cpu() - g).abs().max().item() <= 2e-3 * max(1e-4, g.abs().max().item()), n
+
+
+def test_64_patch_wave_tile_of_the_256_family_matches_the_default_kernel(tmp_path):
+    """ACMIL_GA3=1 (A/B build): D_inner = 256 on the one-wave-per-SIMD kernel with TWO 32-patch blocks per wave.  Per-patch scores
+    are bit-identical to the default kernel (same products, same accumulation order per patch); pooled outputs agree to rounding
+    (256- instead of 128-patch tiles = another summation order); both within 1e-4 of the oracle."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from acmil_amd import ops; from oracle import ga_oracle as O; from acmil_amd import synthetic as S\n"
+        "res = []\n"
+        "for k, c in ((5, 2), (1, 7)):\n"
+        "    sd = {n: v.cuda() for n, v in S.ga_state_dict(512, 256, c, k, seed=k).items()}\n"
+        "    packed, dims = ops.ga_pack_weights(sd['dimreduction.fc1.weight'], sd['attention.attention_V.0.weight'], sd['attention.attention_V.0.bias'],\n"
+        "        sd['attention.attention_U.0.weight'], sd['attention.attention_U.0.bias'], sd['attention.attention_weights.weight'],\n"
+        "        sd['attention.attention_weights.bias'], [sd['classifier.%%d.fc.weight' %% i] for i in range(k)],\n"
+        "        [sd['classifier.%%d.fc.bias' %% i] for i in range(k)], sd['Slide_classifier.fc.weight'], sd['Slide_classifier.fc.bias'], 'f16x3')\n"
+        "    xs = [O.synthetic_bag(n, 512, 300 + i)[0].cuda() for i, n in enumerate([1, 255, 257, 3000, 70000])]\n"
+        "    xs += [xs[3].half(), xs[3].bfloat16()]\n"
+        "    outs = [ops.ga_forward(x, packed, dims, 'f16x3') for x in xs]\n"
+        "    b = ops.ga_forward_batch(xs[:5], packed, dims, 'f16x3')\n"
+        "    res.append([(o['A_out'].cpu(), o['sub_preds'].cpu(), o['slide_pred'].cpu()) for o in outs]\n"
+        "               + [(b['A_out'][i].cpu(), b['sub_preds'][i].cpu(), b['slide_pred'][i].cpu()) for i in range(5)])\n"
+        "torch.save(res, sys.argv[1])\n" % root)
+    got = {}
+    for tag, env in (("v2", {}), ("v3", {"ACMIL_GA3": "1"})):
+        path = str(tmp_path / (tag + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, path], env=ab_environ(**env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:]
+        got[tag] = torch.load(path)
+    for fam2, fam3 in zip(got["v2"], got["v3"]):
+        for (a2, s2, b2), (a3, s3, b3) in zip(fam2, fam3):
+            assert torch.equal(a2, a3)
+            assert (s2 - s3).abs().max().item() < 2e-6 and (b2 - b3).abs().max().item() < 2e-6
+        # v3: batched launch == single launches, bit for bit
+        for i in range(5):
+            assert all(torch.equal(p, q) for p, q in zip(fam3[i], fam3[7 + i]))

@@ -33,6 +33,22 @@ def test_linear_matches_fp64(m, k, n_out, xdt):
     assert torch.equal(big[:, :32].cpu(), big[:, :32].cpu()) and torch.isfinite(big).all()
 
 
+def test_wide_launch_with_bias_beyond_the_lin64_bias_table():
+    """n_out = 2 304 columns (TransMIL's to_qkv at D_inner = 768), K = 768, bias: a shape lin64_kernel would be picked for by its K /
+    tile rule, but whose launch is wider than that kernel's 2 048-float LDS bias table (columns 2048.. read past it)."""
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(11)
+    m, k, n_out = 8000, 768, 2304
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n_out, k, generator=g) * 0.05
+    b = torch.randn(n_out, generator=g) * 3.0
+    ref = x.double() @ w.double().T + b.double()
+    scale = (x.double().abs() @ w.double().abs().T).max().item()
+    y = ops.linear_f16x3(x.cuda(), ops.linear_pack(w.cuda()), n_out, bias=b.cuda())
+    err = (y.cpu().double() - ref).abs()
+    assert err[:, 2048:].max().item() <= 3e-6 * scale + 1e-6 and err.max().item() <= 3e-6 * scale + 1e-6
+
+
 def test_single_k_step_is_refused():
     """K = 16 is one K step: the two-step-deep DMA ring would read past the operands (round-4 finding) -- refused, not attempted."""
     from acmil_amd import _lib

@@ -70,7 +70,9 @@ def test_staged_groups_respect_the_byte_budget():
     order = list(range(len(sizes))) * 2
     dev = torch.device("cuda", 0)
     budget = int(3.2 * 12000 * 128 * 2 * 1.25)          # about three of the largest bags (with the ring's 25 % head room)
-    pf_groups = staged_groups(data, order, dev, group=8, max_bytes=budget)
+    from acmil_amd.staging import BagPrefetcher
+    pf = BagPrefetcher(data, order, dev, depth=16, max_bytes=budget)
+    pf_groups = pf.iter_groups(8)
     seen, lens, checks = [], [], []
     for grp in pf_groups:
         lens.append(len(grp))
@@ -80,6 +82,8 @@ def test_staged_groups_respect_the_byte_budget():
     torch.cuda.synchronize()
     assert seen == order
     assert max(lens) < 8, "the budget, not the group size, must have closed the groups: %s" % lens
+    # the budget also holds when recycled slots are regrown (small bags first, large ones later): never more than max_bytes in the ring
+    assert 0 < pf.peak_bytes <= budget, (pf.peak_bytes, budget)
     for s, r in checks:
         assert torch.allclose(s, r.float().to(dev).sum(), rtol=1e-5, atol=1e-3)
     # unbounded ring of the same loop: full groups

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import TRAIN_CASES, case_dims, load_golden
+from conftest import TRAIN_CASES, ab_environ, case_dims, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -299,9 +299,7 @@ def test_backward_tile_kernel_geometries_match_three_launch_path(di, k, tmp_path
         "torch.save(out, sys.argv[1])\n" % root)
     res = {}
     for tag, env in (("three", {"ACMIL_GA_BWD_TILE": "0"}), ("auto", {}), ("r32", {"ACMIL_GA_BWD_ROWS": "32"}), ("r64", {"ACMIL_GA_BWD_ROWS": "64"})):
-        e = dict(os.environ)
-        e.pop("ACMIL_GA_BWD_TILE", None); e.pop("ACMIL_GA_BWD_ROWS", None)
-        e.update(env)
+        e = ab_environ(**env)
         path = str(tmp_path / (tag + ".pt"))
         r = subprocess.run([sys.executable, "-c", code, path, str(di), str(k)], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:]

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import ab_environ, load_golden
 
 pytestmark = pytest.mark.gpu
 CASES = ["transmil_eval_n1_d384_c2", "transmil_eval_n50_d384_c2", "transmil_eval_n129_d384_c2", "transmil_eval_n1000_d384_c2"]
@@ -45,6 +45,25 @@ def test_matches_reference_golden(name):
 def test_matches_oracle_other_shapes(n, d, di, c):
     from oracle import transmil_oracle as TO
     sd = TO.default_state_dict(d, di, c, seed=3)
+    x = torch.randn(1, n, d, generator=torch.Generator().manual_seed(n))
+    ref = TO.transmil_forward(x, sd)
+    model = _model(sd, d, di, c)
+    with torch.no_grad():
+        logits = model(x.cuda(), debug=True)
+    assert (model._last["h2"].cpu() - ref["h2"][0]).abs().max() < 1e-4
+    assert (logits.cpu() - ref["logits"]).abs().max() < 1e-4
+
+
+def test_trained_layernorm_at_gigapath_width_matches_oracle():
+    """D_inner = 768: to_qkv is 2 304 columns wide and its bias is the folded LayerNorm term W beta -- zero for a freshly constructed
+    module, so only trained-like gamma / beta expose a wrong bias column (lin64's 2 048-float bias table)."""
+    from oracle import transmil_oracle as TO
+    d, di, c, n = 1536, 768, 2, 8000
+    sd = TO.default_state_dict(d, di, c, seed=9)
+    g = torch.Generator().manual_seed(77)
+    for layer in ("layer1", "layer2"):
+        sd[layer + ".norm.weight"] = 1.0 + 0.2 * torch.randn(di, generator=g)
+        sd[layer + ".norm.bias"] = 0.3 * torch.randn(di, generator=g)
     x = torch.randn(1, n, d, generator=torch.Generator().manual_seed(n))
     ref = TO.transmil_forward(x, sd)
     model = _model(sd, d, di, c)
@@ -164,7 +183,7 @@ def test_one_launch_pinv_kernel_matches_the_product_chain():
     out = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("chain", {}), ("one", {"ACMIL_TM_PINV_FUSED": "1"})):
-            e = dict(os.environ); e.pop("ACMIL_TM_PINV_FUSED", None); e.update(env)
+            e = ab_environ(**env)
             path = os.path.join(d, tag + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-2000:]
@@ -199,7 +218,7 @@ def test_side_stream_pipeline_matches_the_serial_one():
     out = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("side", {}), ("serial", {"ACMIL_TM_SIDE_STREAM": "0"})):
-            e = dict(os.environ); e.pop("ACMIL_TM_SIDE_STREAM", None); e.pop("ACMIL_TM_ATTN3_CHUNKS", None); e.update(env)
+            e = ab_environ(**env)
             path = os.path.join(d, tag + ".pt")
             r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
             assert r.returncode == 0, r.stdout[-2000:]
