@@ -25,6 +25,7 @@ _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t
 SIGNATURES = {
     "acmil_version": (C.c_char_p, []),
     "acmil_check_device": (_i, []),
+    "acmil_mfma_probe": (_i, [_i, _i, _vp, C.POINTER(C.c_longlong), _vp]),
     "acmil_ga_packed_bytes": (_sz, [_i] * 6),
     "acmil_ga_pack_weights": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp)] + [_vp] * 2 + [_i] * 6 + [_vp, _vp]),
     "acmil_ga_workspace_bytes": (_sz, [_i] * 6),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "acmil_transmil_workspace_bytes": (_sz, [_i] * 4),
     "acmil_transmil_forward": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "acmil_transmil_forward_ex": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "acmil_ga_backward_workspace_bytes": (_sz, [_i] * 5),
     "acmil_ga_backward": (_i, [_vp, _i, _i] + [_vp] * 8 + [C.POINTER(_vp)] + [_vp] * 4 + [_vp] * 7 +
                           [C.POINTER(_vp), C.POINTER(_vp)] + [_vp, _vp] + [_i] * 6 + [_vp, _vp]),

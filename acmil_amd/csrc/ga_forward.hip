@@ -145,15 +145,19 @@ static int ga_dephase() {
 // kernel skips its end-of-kernel counter reset (the round-2 scheme before the self-resetting block)
 static bool ga_memset_mode() { static const bool v = ACMIL_AB_ENV("ACMIL_GA_MEMSET") != nullptr; return v; }
 
-// tile geometry of the persistent split-f16 kernel: 4 waves (128-patch tiles, two workgroups per CU) or 8 waves (256-patch tiles, one
-// workgroup per CU: the weight stream is staged once per 256 patches).  4 waves is the default for every launch, so the pooled results
-// of a bag do not depend on what else shares its launch (tile partition = summation order).  The 8-wave geometry is an opt-in
-// (ACMIL_GA2_WAVES=8, read once); measured with tools/time_single_bag.py, us per forward incl. merge + heads, 4 / 8 waves:
-// one bag of 313 tiles 78.3 / 72.6, 391 (N = 50 000): 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- but 256 tiles:
-// 57.1 / 68.7, a single tile: 43.8 / 62.5, and the batched launches (6 256 tiles): 872 / 896.
-static int ga_v2_waves() {
-    static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA2_WAVES"); return (e && atoi(e) == 8) ? 8 : 4; }();
-    return v;
+// Tile geometry of the persistent split-f16 kernel, chosen PER LAUNCH (round 5): 4 waves (128-patch tiles, two workgroups per CU) or
+// 8 waves (256-patch tiles, one workgroup per CU: the weight stream is staged once per 256 patches).  Measured with
+// tools/time_single_bag.py, us per forward incl. merge + heads, 4 / 8 waves: one bag of 313 tiles 78.3 / 72.6, 391 (N = 50 000):
+// 85.4 / 79.8, 512: 96.9 / 91.8, 782: 160.6 / 155.9 -- but 256 tiles: 57.1 / 68.7, a single tile: 43.8 / 62.5, and the batched
+// launches (6 256 tiles): 872 / 896.  So: 8 waves when the launch holds 257 .. 1 024 tiles of 128 patches (one large slide per
+// call -- the reference's own call pattern, Step3_WSI_classification_ACMIL.py:193-200,253-258), 4 waves otherwise.  The tile
+// partition is the summation order of the pooled features, so a bag's logits may differ in the last bits (<= 2e-6 measured; the
+// contract is 1e-4) with what shares its launch; per-patch scores are bit-identical in both geometries, and a given launch is
+// bit-reproducible.  ACMIL_GA2_WAVES=4|8 forces (A/B builds).
+static int ga_v2_waves(long long tiles128) {
+    static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA2_WAVES"); return e ? atoi(e) : 0; }();
+    if (v == 4 || v == 8) return v;
+    return (tiles128 > 256 && tiles128 <= 1024) ? 8 : 4;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
@@ -286,7 +290,9 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     }
     long long total_patches = 0;
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
-    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(maxN, total_patches);
+    long long tiles128 = 0;
+    for (int b = 0; b < nbags; ++b) tiles128 += (Ns[b] + 127) / 128;
+    a.waves = ga_use_v2(mode) ? ga_v2_waves(tiles128) : ga_pick_waves(maxN, total_patches);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
     a.v3 = ga_pick_v3(Di, K, mode, nbags, total_patches);
     if (a.v3) a.waves = ga_is_wide(Di) ? 4 : 8;        // tile rows = 32 * waves: 128 (32 patches per wave) / 256 (64 per wave)
@@ -366,7 +372,7 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     }
     hipStream_t st = (hipStream_t)stream;
     GaFwdArgs a;
-    a.waves = ga_use_v2(mode) ? ga_v2_waves() : ga_pick_waves(N);
+    a.waves = ga_use_v2(mode) ? 4 : ga_pick_waves(N);      // score pass: 8 waves gain nothing for it (0.3154 vs 0.3153 ms per training step)
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
     a.v3 = (ga_is_wide(Di) && ga_has_v3(Di, K, mode) && workspace) ? 1 : 0;      // score pass: the wide families only
     if (a.v3) a.waves = 4;
@@ -380,6 +386,45 @@ extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* p
     if (a.tile_counter && !a.self_reset && hipMemsetAsync(a.tile_counter, 0, 16, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     a.L = ga_layout(D, Di, K, C, mode);
     return ga_dispatch(a, mode, x_dtype, false, st);
+}
+
+// MFMA-only probe (include/acmil_hip.h: acmil_mfma_probe): what the matrix pipe delivers under the power cap, measured by bench.py
+// beside every roofline line.  Operands are pseudo-random f16 (zero-filled operands clock ~19 % higher: MI355X_MICROARCH.md, DVFS).
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(int iters, float* __restrict__ sink) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    f16x8 A[4], B[2];
+    unsigned s = t * 2654435761u + 12345u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s = s * 1664525u + 1013904223u; A[i][j] = (_Float16)(((int)(s >> 16) - 32768) * (1.0f / 1048576.0f)); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s = s * 1664525u + 1013904223u; B[i][j] = (_Float16)(((int)(s >> 16) - 32768) * (1.0f / 32768.0f)); }
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[q & 3], B[q >> 2], acc[q], 0, 0, 0);
+    }
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v += acc[q][r];
+    sink[t] = v;
+}
+
+extern "C" int acmil_mfma_probe(int iters, int workgroups, float* sink, long long* mfmas, void* stream) {
+    if (iters <= 0 || workgroups <= 0) return ACMIL_ERR_SHAPE;
+    if (!sink) return ACMIL_ERR_NULL;
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
+    if (mfmas) *mfmas = (long long)workgroups * 4 * iters * 8;
+    return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
 extern "C" const char* acmil_version(void) { return "acmil_hip 0.1 (gfx950)"; }

@@ -955,30 +955,22 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
                      pk_out != nullptr);
 }
 
-extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
-                                      const float* cls_token, const float* const* layer1 /*6 ptrs*/,
-                                      const float* const* layer2 /*6 ptrs*/, const float* const* ppeg /*w7,b7,w5,b5,w3,b3*/,
-                                      const float* norm_w, const float* norm_b, const float* fc2_w, const float* fc2_b,
-                                      float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2, void* workspace,
-                                      void* stream) {
+// The forward proper.  `side` = the second stream + event pair the Moore-Penrose chain / weight packing use beside `stream` (null:
+// every launch on `stream`).  Whoever owns `side` guarantees that one forward at a time records / waits on its events.
+static int tm_forward_impl(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
+                           const float* cls_token, const float* const* layer1 /*6 ptrs*/,
+                           const float* const* layer2 /*6 ptrs*/, const float* const* ppeg /*w7,b7,w5,b5,w3,b3*/,
+                           const float* norm_w, const float* norm_b, const float* fc2_w, const float* fc2_b,
+                           float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2, void* workspace,
+                           hipStream_t st, TmSide* side) {
     if (N <= 0 || D <= 0 || Di <= 0 || C <= 0) return ACMIL_ERR_SHAPE;
     if (Di % 16 != 0 || Di / 2 > 1024 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;      // (Di <= 1024: tm_cls_head_kernel's row buffer)
     if (!x || !fc1_w || !fc1_b || !cls_token || !layer1 || !layer2 || !ppeg || !norm_w || !norm_b || !fc2_w || !fc2_b || !logits || !workspace)
         return ACMIL_ERR_NULL;
     for (int i = 0; i < 6; ++i) if (!layer1[i] || !layer2[i] || !ppeg[i]) return ACMIL_ERR_NULL;
-    hipStream_t st = (hipStream_t)stream;
     const TmGeom g = tm_geom(N, D, Di, C);
     const TmWs W = tm_ws(g);
     char* ws = (char*)workspace;
-    std::lock_guard<std::mutex> side_lock(tm_side_mutex);      // one forward at a time records / waits on the side stream's events
-    TmSide* side = tm_side(st);
-    bool capturing = false;
-    TmSerial* ser = tm_serial(st, &capturing);
-    if (ser && ser->state == 2 && ser->last != st && hipStreamWaitEvent(st, ser->done, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;
-    struct SerialMark {      // the end of this forward, recorded on every return path
-        TmSerial* s; hipStream_t st;
-        ~SerialMark() { if (s && hipEventRecord(s->done, st) == hipSuccess) { s->state = 2; s->last = st; } else if (s) (void)hipGetLastError(); }
-    } serial_mark{ser, st};
     float* XA = (float*)(ws + W.XA); float* XB = (float*)(ws + W.XB); float* LN = (float*)(ws + W.LN);
     float* weff = (float*)(ws + W.WEFF); float* beff = (float*)(ws + W.BEFF);
     void* gws = ws + W.GEMM;
@@ -1060,4 +1052,44 @@ extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int 
     hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);
     TM_CHECK_LAUNCH();
     return ACMIL_OK;
+}
+
+// Convenience entry: the side stream and its event pair are the LIBRARY's (one per device, created at first use, never while the
+// caller is capturing), the enqueue holds a lock -- the one place where this library keeps state (include/acmil_hip.h says so).
+// Callers that want the ownership contract of every other entry point use acmil_transmil_forward_ex.
+extern "C" int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
+                                      const float* cls_token, const float* const* layer1, const float* const* layer2,
+                                      const float* const* ppeg, const float* norm_w, const float* norm_b, const float* fc2_w,
+                                      const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2, void* workspace,
+                                      void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> side_lock(tm_side_mutex);      // one forward at a time records / waits on the side stream's events
+    TmSide* side = tm_side(st);
+    bool capturing = false;
+    TmSerial* ser = tm_serial(st, &capturing);
+    if (ser && ser->state == 2 && ser->last != st && hipStreamWaitEvent(st, ser->done, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;
+    struct SerialMark {      // the end of this forward, recorded on every return path
+        TmSerial* s; hipStream_t st;
+        ~SerialMark() { if (s && hipEventRecord(s->done, st) == hipSuccess) { s->state = 2; s->last = st; } else if (s) (void)hipGetLastError(); }
+    } serial_mark{ser, st};
+    return tm_forward_impl(x, N, D, Di, C, fc1_w, fc1_b, cls_token, layer1, layer2, ppeg, norm_w, norm_b, fc2_w, fc2_b, logits, dbg_h1, dbg_hp,
+                           dbg_h2, workspace, st, side);
+}
+
+// The same forward with CALLER-OWNED concurrency objects (the library allocates nothing and keeps no state):
+// side_stream = a second stream of the same device, fork_event / join_event = two events (timing may be disabled); all three NULL =
+// every launch on `stream`.  The call records fork_event on `stream` / join_event on side_stream and makes each stream wait for
+// the other's event, several times; when it returns, `stream` alone orders the outputs.  The caller must not use the three objects
+// for anything else while a call is being ENQUEUED (one forward at a time per triple; the GPU work of consecutive forwards may overlap).
+extern "C" int acmil_transmil_forward_ex(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
+                                         const float* cls_token, const float* const* layer1, const float* const* layer2,
+                                         const float* const* ppeg, const float* norm_w, const float* norm_b, const float* fc2_w,
+                                         const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2, void* workspace,
+                                         void* stream, void* side_stream, void* fork_event, void* join_event) {
+    const int given = (side_stream != nullptr) + (fork_event != nullptr) + (join_event != nullptr);
+    if (given != 0 && given != 3) return ACMIL_ERR_NULL;
+    if (given == 3 && side_stream == stream) return ACMIL_ERR_SHAPE;
+    TmSide side = {(hipStream_t)side_stream, (hipEvent_t)fork_event, (hipEvent_t)join_event, 1};
+    return tm_forward_impl(x, N, D, Di, C, fc1_w, fc1_b, cls_token, layer1, layer2, ppeg, norm_w, norm_b, fc2_w, fc2_b, logits, dbg_h1, dbg_hp,
+                           dbg_h2, workspace, (hipStream_t)stream, given == 3 ? &side : nullptr);
 }

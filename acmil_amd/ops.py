@@ -7,6 +7,7 @@ there is no fallback: CPU tensors are rejected.
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -439,11 +440,46 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 
 
+_TM_SIDE: Dict[tuple, tuple] = {}
+_TM_SIDE_LOCK = threading.Lock()
+
+
+def _transmil_side(dev: torch.device):
+    """The (side stream, fork event, join event) triple acmil_transmil_forward_ex works with beside the current stream: owned HERE,
+    by the caller of the library (one per device and compute stream, high priority, created at first use).  Nothing is created
+    inside a graph capture: a capturing stream without a triple of its own (torch.cuda.graph captures on an internal stream) takes
+    the device's spare triple, made together with the first eager one -- or runs serially if there has been no eager call yet.
+    Returns raw handles, or (None, None, None)."""
+    cur = torch.cuda.current_stream(dev)
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (di, cur.cuda_stream)
+    t = _TM_SIDE.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            t = _TM_SIDE.get((di, "capture"))
+            if t is None:
+                return None, None, None
+        else:
+            with _TM_SIDE_LOCK:
+                t = _TM_SIDE.get(key)
+                if t is None:
+                    def make():
+                        side = torch.cuda.Stream(device=dev, priority=-1)
+                        fork, join = torch.cuda.Event(), torch.cuda.Event()
+                        fork.record(cur); join.record(side)          # torch creates the hipEvent_t at the first record
+                        return (side, fork, join)
+                    t = _TM_SIDE[key] = make()
+                    if (di, "capture") not in _TM_SIDE:
+                        _TM_SIDE[(di, "capture")] = make()
+    return t[0].cuda_stream, t[1].cuda_event, t[2].cuda_event
+
+
 def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int, debug: bool = False,
-                     workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-    """acmil_transmil_forward.  x [N,D] fp32 CUDA; sd: parameters under the reference's state_dict names
+                     workspace: Optional[torch.Tensor] = None, side_stream: bool = True) -> Dict[str, torch.Tensor]:
+    """acmil_transmil_forward_ex.  x [N,D] fp32 CUDA; sd: parameters under the reference's state_dict names
     (fp32, CUDA, contiguous).  Returns {'logits': [C]} plus 'h1','hp','h2' [(side^2+1), Di] when debug.
-    workspace: a caller-owned uint8 CUDA buffer of at least acmil_transmil_workspace_bytes (tests: pre-filled scratch, canaries)."""
+    workspace: a caller-owned uint8 CUDA buffer of at least acmil_transmil_workspace_bytes (tests: pre-filled scratch, canaries).
+    side_stream=False: every launch on the current stream (the serial pipeline)."""
     lib = _lib.load()
     _need_cuda(x)
     if x.dtype != torch.float32:
@@ -478,10 +514,11 @@ def transmil_forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], n_class: int,
     import math
     side = int(math.ceil(math.sqrt(N)))
     dbg = [torch.empty(side * side + 1, Di, dtype=torch.float32, device=x.device) for _ in range(3)] if debug else [None] * 3
-    rc = lib.acmil_transmil_forward(x.data_ptr(), N, D, Di, n_class, small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(),
-                                    l1, l2, pp, small[3].data_ptr(), small[4].data_ptr(), small[5].data_ptr(), small[6].data_ptr(),
-                                    logits.data_ptr(), _ptr(dbg[0]), _ptr(dbg[1]), _ptr(dbg[2]), ws.data_ptr(), _stream())
-    _lib.check(rc, "acmil_transmil_forward")
+    ss, ef, ej = _transmil_side(x.device) if side_stream else (None, None, None)
+    rc = lib.acmil_transmil_forward_ex(x.data_ptr(), N, D, Di, n_class, small[0].data_ptr(), small[1].data_ptr(), small[2].data_ptr(),
+                                       l1, l2, pp, small[3].data_ptr(), small[4].data_ptr(), small[5].data_ptr(), small[6].data_ptr(),
+                                       logits.data_ptr(), _ptr(dbg[0]), _ptr(dbg[1]), _ptr(dbg[2]), ws.data_ptr(), _stream(), ss, ef, ej)
+    _lib.check(rc, "acmil_transmil_forward_ex")
     out = {"logits": logits}
     if debug:
         out.update(h1=dbg[0], hp=dbg[1], h2=dbg[2])

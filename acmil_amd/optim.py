@@ -92,25 +92,13 @@ class FlatAdamW:
         if track and len(self._pending) >= 12:
             raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
         slot = self._step_id % 16
-        if self.peer is not None:
+        if self.peer is not None and not self.peer.verified:
+            self._first_peer_step(lib, g, b1, b2, track, slot)
+        elif self.peer is not None:
             # direct data-parallel reduction: bucket -> own slot + flags at the peers, then wait + reduce (rank order) + AdamW in ONE launch
-            self.peer.publish(self.grad)
-            rc = lib.acmil_adamw_step_peer(self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.numel,
-                                           self.peer.slot_ptrs(), self.peer.flags.data_ptr(), self.peer.world, self.peer.rank,
-                                           self.peer.step_id, float(self.peer.timeout_s), self.peer.err.data_ptr(), float(g["lr"]),
-                                           float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._launches,
-                                           0 if self.guard_flag is None else 1, self._skipped_dev.data_ptr(),
-                                           self._host_flags.data_ptr() + 4 * slot if track else None, None,
-                                           torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "acmil_adamw_step_peer")
-        else:
-          # tracked: the launch itself stores the flag into pinned host memory (no copy on the stream)
-          rc = lib.acmil_adamw_step_report(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                                         self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
-                                         self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
-                                         self._skipped_dev.data_ptr(), self._host_flags.data_ptr() + 4 * slot if track else None,
-                                         torch.cuda.current_stream().cuda_stream)
-          _lib.check(rc, "acmil_adamw_step_report")
+            self._peer_launch(lib, g, b1, b2, track, slot, None)
+        if self.peer is None:
+            self._plain_launch(lib, g, b1, b2, track, slot)
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
@@ -120,6 +108,65 @@ class FlatAdamW:
             ev.record()
             self._pending.append((self._step_id, ev, slot))
         return self._step_id
+
+    def _plain_launch(self, lib, g, b1, b2, track, slot):
+        # tracked: the launch itself stores the flag into pinned host memory (no copy on the stream)
+        rc = lib.acmil_adamw_step_report(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                         self.numel, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                         self._launches, None if self.guard_flag is None else self.guard_flag.data_ptr(),
+                                         self._skipped_dev.data_ptr(), self._host_flags.data_ptr() + 4 * slot if track else None,
+                                         torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "acmil_adamw_step_report")
+
+    def _peer_launch(self, lib, g, b1, b2, track, slot, reduced_out):
+        self.peer.publish(self.grad)
+        rc = lib.acmil_adamw_step_peer(self.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.numel,
+                                       self.peer.slot_ptrs(), self.peer.my_flags_ptr, self.peer.world, self.peer.rank,
+                                       self.peer.step_id, float(self.peer.timeout_s), self.peer.err.data_ptr(), float(g["lr"]),
+                                       float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]), self._launches,
+                                       0 if self.guard_flag is None else 1, self._skipped_dev.data_ptr(),
+                                       self._host_flags.data_ptr() + 4 * slot if track else None,
+                                       None if reduced_out is None else reduced_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "acmil_adamw_step_peer")
+
+    def _first_peer_step(self, lib, g, b1, b2, track, slot):
+        """The first step of the direct reduction, CHECKED (collective; one synchronisation): the bucket as the fused launch reduced
+        it must equal one torch.distributed all_reduce of the same bucket.  A mismatch means the peers' slots are not read coherently
+        on this machine (the path has only ever run with two ranks on one GPU): the step is undone, redone on the collective's result,
+        and every rank drops to torch.distributed for good -- loudly, never silently diverging."""
+        import torch.distributed as dist
+        peer = self.peer
+        keep = (self.flat.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self._skipped_dev.clone())
+        if dist.get_backend(peer.group) == "nccl":
+            ref = self.grad.clone()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=peer.group)
+        else:                                                       # (gloo control plane of the single-GPU test: reduce on the host)
+            ref = self.grad.cpu()
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=peer.group)
+            ref = ref.to(self.grad.device)
+        ref.div_(peer.world)
+        reduced = torch.empty_like(self.grad)
+        self._peer_launch(lib, g, b1, b2, track, slot, reduced)
+        timed_out = int(peer.err.item()) != 0                      # (synchronises)
+        if getattr(peer, "_selfcheck_perturb", False):             # test hook (tests/dist_worker_peer.py): what a stale remote line would look like
+            reduced[0] += 1.0
+        n = self.numel
+        scale = float(ref[:n].abs().max().item())
+        ok = (not timed_out) and bool(torch.isfinite(reduced).all()) and \
+            float((reduced - ref).abs().max().item()) <= 1e-6 * max(scale, 1e-30) + 1e-12
+        if not peer._agree(1 if ok else 0, self.flat.device, peer.group):
+            print("acmil_amd.FlatAdamW[rank %d]: direct gradient reduction disagrees with torch.distributed on its first step (%s); "
+                  "falling back to all_reduce" % (peer.rank, "timeout" if timed_out else "max |d| %.3e of %.3e" % (
+                      float((reduced - ref).abs().max().item()) if not timed_out else float("nan"), scale)))
+            self.flat.copy_(keep[0]); self.exp_avg.copy_(keep[1]); self.exp_avg_sq.copy_(keep[2]); self._skipped_dev.copy_(keep[3])
+            self.grad.copy_(ref)
+            peer.verdict = "mismatch: fell back to torch.distributed"
+            peer.owner = None                                       # train.GradBucket.allreduce_mean takes over from the next step on
+            self.peer = None
+            self._plain_launch(lib, g, b1, b2, track, slot)
+            return
+        peer.verified = True
+        peer.verdict = "first step equals all_reduce (max |d| %.1e)" % float((reduced - ref).abs().max().item())
 
     def poll_skipped(self, lag: int = 2) -> List[int]:
         """Ids of tracked steps the device did NOT apply (range flag set), looking only at steps at least `lag` calls old -- their

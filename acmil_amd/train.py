@@ -500,6 +500,8 @@ def main(argv=None):
     if rank == 0:
         save_model(conf, epoch, model, optimizer, os.path.join(conf.out_dir, "checkpoint-last.pth"))
         print("Results on best epoch:"); print(best)
+    if bucket is not None and bucket.peer is not None:
+        bucket.peer.close()          # collective: a peer's last optimizer launch may still be reading this rank's slots
     if world > 1:
         dist.destroy_process_group()
 

@@ -37,6 +37,7 @@ N_BAGS = 16      # resident bags (grown to the batch size in main)
 
 SOURCES_OF = {     # kernel sources whose change invalidates a workload's PMC summary
     "ga": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h"),
+    "ga3": ("ga_common.h", "ga_forward_kernel_v2.h", "ga_forward_kernel_v3.h"),
     "transmil": ("transmil.hip", "transmil_attn.hip", "transmil_pinv.hip", "linear_kernel.h", "linear.hip", "gemm_f32.hip", "gemm_internal.h"),
     "wide": ("ga_common.h", "linear_kernel.h", "linear.hip", "ga_forward_kernel_v2.h", "ga_train.hip"),
     "train": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h", "ga_step.hip", "ga_train.hip", "ga_bwd_tile.hip", "ga_backward.hip",
@@ -48,7 +49,7 @@ def kernel_source_id(workload="ga_eval"):
     """Fingerprint of a workload's kernel sources; tools/pmc_ga.py stamps it into every PMC summary it writes."""
     import hashlib
     h = hashlib.sha1()
-    for f in SOURCES_OF.get("wide" if workload in ("ga_uni", "ga_gigapath", "ga_clip_l") else workload, SOURCES_OF["ga"]):
+    for f in SOURCES_OF.get("wide" if workload == "ga_gigapath" else "ga3" if workload in ("ga_uni", "ga_clip_l") else workload, SOURCES_OF["ga"]):
         with open(os.path.join(ROOT, "acmil_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
@@ -77,6 +78,29 @@ def pmc_traffic(workload, precision, batch):
         except Exception:
             continue
     return None, "no PMC summary for this workload / precision / batch under profiles/"
+
+
+def mfma_probe_tflops(dev, iters=1000, launches=40):
+    """acmil_mfma_probe: the rate of v_mfma_f32_32x32x16_f16 ALONE (two 4-wave workgroups per CU, pseudo-random operands, no
+    memory traffic) on this box, now, in TFLOP/s -- events on the launch stream, back-to-back launches (~13 ms in all, enough for
+    the socket to settle at its power cap).  The ceiling of every split-f16 kernel here; reported beside the nominal 2.5 PF."""
+    import ctypes
+    from acmil_amd import _lib
+    lib = _lib.load()
+    wgs = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+    sink = torch.empty(wgs * 256, dtype=torch.float32, device=dev)
+    n = ctypes.c_longlong(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        _lib.check(lib.acmil_mfma_probe(iters, wgs, sink.data_ptr(), ctypes.byref(n), st), "acmil_mfma_probe")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(launches):
+        lib.acmil_mfma_probe(iters, wgs, sink.data_ptr(), None, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return n.value * 32768.0 * launches / (e0.elapsed_time(e1) * 1e-3) / 1e12
 
 
 def algorithmic_work(n, d, di, k, c, da=D_ATTN, s_in=4):
@@ -170,10 +194,23 @@ def dry_run(args):
     """Launcher / rendezvous check without a GPU: K empty steps bracketed exactly like the real loop."""
     world, rank, dev = _dist_setup(args)
     dt = _timed(lambda i: None, args, world, dev)
+    extra = {}
+    if args.workload == "train":
+        # the data-parallel fields of the train line, through the same objects (GradBucket.allreduce_mean on gloo, one 833 216-byte
+        # bucket); the direct reduction needs GPUs: its keys are present, its check says so
+        from acmil_amd import train as T
+        p = torch.nn.Parameter(torch.zeros(208303))
+        bucket = T.GradBucket([p])
+        t0 = time.perf_counter()
+        for _ in range(5):
+            bucket.allreduce_mean(world)
+        extra = {"allreduce_us": round((time.perf_counter() - t0) / 5 * 1e6, 1) if world > 1 else None,
+                 "allreduce_bytes": int(bucket.flat.numel() * 4),
+                 "direct_reduce": {"ms_per_step": None, "value": None, "first_step_check": "not run (dry run: no GPU)", "slot_memory": None}}
     if rank == 0:
-        print(json.dumps({"dry_run": True, "metric": "launcher check (no compute)", "value": None, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 6),
-                          "workload": args.workload}))
+        print(json.dumps(dict({"dry_run": True, "metric": "launcher check (no compute)", "value": None, "n_gpus": world,
+                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 6),
+                               "workload": args.workload}, **extra)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -310,10 +347,15 @@ def other_workloads(args, ctx):
             bucket_d = T.GradBucket(list(model.parameters()))
             if bucket_d.enable_direct(rank, world):
                 opt_d = T.make_optimizer(model, conf, dev, bucket_d, lr=conf.lr)
-                dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)
-                opt_d.peer.check()
+                peer = bucket_d.peer
+                dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)      # (its first step is the checked one: compared with all_reduce)
+                if opt_d.peer is not None:
+                    opt_d.peer.check()
                 direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * args.steps / dt_d, 1), "unit": "slides/s",
-                          "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"}
+                          "first_step_check": peer.verdict, "slot_memory": peer.memory,
+                          "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"
+                                  if opt_d.peer is not None else "the first-step check failed: these steps ran on torch.distributed all_reduce"}
+                peer.close()
             else:
                 direct = {"error": "peer mapping unavailable: torch.distributed only"}
         except (Exception, SystemExit) as e:
@@ -365,10 +407,8 @@ def other_workloads(args, ctx):
     return result
 
 
-WIDE_SHAPES = {   # the reference's wider feature extractors (Step3_WSI_classification_ACMIL.py:78-87): no single-kernel family, composed path
-    "ga_uni": dict(N=50000, D=1024, Di=512, K=5, C=2, name="UNI (ViT-L/16, 1024 -> 512)"),
+WIDE_SHAPES = {   # the reference's widest feature extractor (Step3_WSI_classification_ACMIL.py:78-87): no single-kernel family, composed path
     "ga_gigapath": dict(N=50000, D=1536, Di=768, K=5, C=2, name="GigaPath (ViT-g, 1536 -> 768)"),
-    "ga_clip_l": dict(N=50000, D=768, Di=384, K=5, C=2, name="CLIP-L-336 (768 -> 384)"),
 }
 
 
@@ -461,6 +501,12 @@ GA_SHAPES = {
                     metric="slides/sec (ACMIL-ga attention-aggregation forward, N=50000 D=512)"),
     "ga_cfg3": dict(N=50000, D=384, Di=128, K=5, C=2, xdtype="bfloat16",
                     metric="slides/sec (ACMIL-ga forward, Camelyon16-shape bags N=50000 D=384 D_inner=128, bf16 bags)"),
+    # the wide families with a fused kernel since round 5 (csrc/ga_forward_kernel_v3.h: one 512-register wave per SIMD); the step is the
+    # headline's: one fused launch of --batch bags (as acmil_amd.train.evaluate drives the module); `model(x)` per slide rides along
+    "ga_uni": dict(N=50000, D=1024, Di=512, K=5, C=2, xdtype="float32",
+                   metric="slides/sec (ACMIL-ga eval forward, N=50000 D=1024 D_inner=512: UNI (ViT-L/16, 1024 -> 512))"),
+    "ga_clip_l": dict(N=50000, D=768, Di=384, K=5, C=2, xdtype="float32",
+                      metric="slides/sec (ACMIL-ga eval forward, N=50000 D=768 D_inner=384: CLIP-L-336 (768 -> 384))"),
 }
 
 
@@ -616,6 +662,8 @@ def ga_workload(args, ctx):
     e1.record()
     torch.cuda.synchronize()
     t_kernel = e0.elapsed_time(e1) * 1e-3 / n_k  # seconds per launch (back-to-back launches on the launch stream)
+    # the matrix pipe alone on this box, right after the kernel (same power state): the ceiling `executed` is to be read against
+    probe_tf = mfma_probe_tflops(dev) if args.precision != "fp32" else None
 
 
     dt = _timed(step, args, world, dev)   # W untimed + exactly K timed steps, barrier + synchronize both sides, max over ranks
@@ -708,8 +756,10 @@ def ga_workload(args, ctx):
     else:                 # ga_pick_waves of the round-1 kernel
         waves = 4 if (B * N_PATCH >= 1024 * 128 or N_PATCH < 32768) else 8
     traffic, traffic_src = pmc_traffic(args.workload, args.precision, B)
+    v3 = split and D_INNER in (384, 512)      # csrc/ga_forward.hip::ga_pick_v3: the wide families run the one-wave-per-SIMD kernel
     roofline = {
-        "kernel": "%s<ND=%d,KP=%d,%s,x=%s,waves=%d>, %d bags per launch" % (
+        "kernel": ("ga_fwd3_kernel<ND=%d,PB=1,KP=%d,x=%s>, %d bags per launch" % (D_INNER // 32, 5 if N_TOKEN > 1 else 1, shape["xdtype"], B)) if v3 else
+                  "%s<ND=%d,KP=%d,%s,x=%s,waves=%d>, %d bags per launch" % (
             "ga_fwd2_kernel" if version == 2 else "ga_fwd_kernel", D_INNER // 32, 5 if N_TOKEN > 1 else 1, args.precision,
             shape["xdtype"], waves, B),
         "bound": "mfma",
@@ -719,6 +769,9 @@ def ga_workload(args, ctx):
         "us_per_launch": round(t_kernel * 1e6, 2),
         "executed_tflops": round(executed / t_kernel / 1e12, 1),
         "executed_frac": round(executed / t_kernel / 1e12 / mfma_peak, 4),
+        "mfma_only_probe_tflops": None if probe_tf is None else round(probe_tf, 1),
+        "mfma_only_probe_frac_of_peak": None if probe_tf is None else round(probe_tf / mfma_peak, 4),
+        "executed_frac_of_probe": None if probe_tf is None else round(executed / t_kernel / 1e12 / probe_tf, 4),
         "note": "flops = algorithmic (SURVEY 8d: %.2f GFLOP/slide x slides per launch); executed = MFMA flops issued "
                 "(split-f16: 3 f16 products per fp32 product)" % (flops / B / 1e9),
         "hbm": {"achieved": round(nbytes / t_kernel / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

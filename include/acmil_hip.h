@@ -7,7 +7,10 @@
  * replaces.  Conventions:
  *   - every pointer is a DEVICE pointer unless marked "host"; the caller (PyTorch's caching allocator in
  *     the shipped host code) owns every buffer including `packed` and `workspace`; the library allocates
- *     nothing and keeps no global state, so it is re-entrant across threads and streams;
+ *     nothing, keeps no global state and reads no environment variable, so it is re-entrant across threads
+ *     and streams.  ONE documented exception: acmil_transmil_forward owns a per-device side stream + event
+ *     pair behind a lock (a convenience wrapper; acmil_transmil_forward_ex takes caller-owned ones and has
+ *     no exception).  Measurement switches exist only in the A/B build libacmil_hip_ab.so (csrc/ab_knobs.h);
  *   - `stream` is the caller's hipStream_t (0 = default stream); all work is enqueued on it, nothing
  *     synchronises the device;
  *   - return value: ACMIL_OK, or a negative ACMIL_ERR_* for a bad shape / unsupported configuration /
@@ -51,6 +54,14 @@ const char* acmil_version(void);
 
 /* 0 if the current HIP device is gfx950, else ACMIL_ERR_ARCH.  (host-side query; no kernel launch) */
 int acmil_check_device(void);
+
+/* Measurement aid of bench.py's roofline line (no reference counterpart): a launch that issues ONLY the matrix instruction of the
+ * split-f16 kernels -- iters x 8 independent v_mfma_f32_32x32x16_f16 per wave on pseudo-random f16 operands, two 4-wave workgroups
+ * per CU (the headline kernel's residency), no loads, no LDS, no barriers.  Its rate under the socket's power cap is the ceiling any
+ * split-f16 kernel of this library can reach on THIS box at THIS moment; bench.py times it with events and reports it next to the
+ * nominal 2.5 PF.  sink: >= workgroups * 256 floats (written so that the loop cannot be removed); returns the number of MFMA
+ * instructions the launch issues in *mfmas (host pointer, may be NULL). */
+int acmil_mfma_probe(int iters, int workgroups, float* sink, long long* mfmas, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Rearranges the parameters of ACMIL_GA / ABMIL
@@ -283,9 +294,8 @@ int acmil_ga_loss(const float* sub_preds, const float* slide_pred, const float* 
  * Streams: everything is ordered on `stream` as far as the caller can tell -- but inside a layer the Moore-Penrose chain runs on ONE
  * library-owned non-blocking stream per device beside the attn3 leg, forked from and joined back into `stream` with events before the
  * call's last launches are enqueued (so `stream` alone orders the outputs; HIP-graph capture of the call works; concurrent callers are
- * serialised over the enqueue by a lock).  ACMIL_TM_SIDE_STREAM=0 keeps every launch on `stream`.  Forwards on different streams may
- * overlap on the GPU (tested: tools/stress_transmil.py; ACMIL_TM_SERIAL=1 makes each wait for the previous one); the workspace may hold
- * anything on entry.
+ * serialised over the enqueue by a lock).  Forwards on different streams may overlap on the GPU (tested: tools/stress_transmil.py);
+ * the workspace may hold anything on entry.
  * ------------------------------------------------------------------------------------------- */
 size_t acmil_transmil_workspace_bytes(int N, int D, int Di, int C);
 
@@ -294,6 +304,19 @@ int acmil_transmil_forward(const float* x, int N, int D, int Di, int C, const fl
                            const float* const* ppeg, const float* norm_w, const float* norm_b, const float* fc2_w,
                            const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2,
                            void* workspace, void* stream);
+
+/* The same forward with CALLER-OWNED concurrency objects -- the ownership contract of every other entry point (the library
+ * allocates nothing, keeps no state, takes no lock): side_stream = a second hipStream_t of the same device, fork_event /
+ * join_event = two hipEvent_t (timing may be disabled); all three NULL = every launch on `stream`.  The call records / waits on the
+ * two events several times and joins back before its last launches, so `stream` alone orders the outputs (HIP-graph capture works).
+ * One forward at a time may be ENQUEUED per (side_stream, fork_event, join_event) triple; their GPU work may overlap.
+ * acmil_amd.ops.transmil_forward owns one triple per (device, stream) and calls this entry. */
+int acmil_transmil_forward_ex(const float* x, int N, int D, int Di, int C, const float* fc1_w, const float* fc1_b,
+                              const float* cls_token, const float* const* layer1, const float* const* layer2,
+                              const float* const* ppeg, const float* norm_w, const float* norm_b, const float* fc2_w,
+                              const float* fc2_b, float* logits, float* dbg_h1, float* dbg_hp, float* dbg_h2,
+                              void* workspace, void* stream, void* side_stream, void* fork_event, void* join_event);
+
 
 /* ---------------------------------------------------------------------------------------------
  * ACMIL_MHA eval forward (architecture/transformer.py:49-83 with MutiHeadAttention :107-185 and

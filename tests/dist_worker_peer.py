@@ -81,9 +81,40 @@ def main():
     flats = [torch.empty_like(opt.flat).cpu() for _ in range(world)]
     dist.all_gather(flats, opt.flat.cpu())
     assert torch.equal(flats[0], flats[1]) and torch.isfinite(flats[0]).all(), "ranks diverged in the unsynchronised run"
+    assert opt.peer.verified and opt.peer.verdict.startswith("first step equals all_reduce"), opt.peer.verdict
+    memory = opt.peer.memory
+    opt.peer.close()                                               # collective teardown: drain, meet, unmap
+    # ---- the first-step self-check catching a wrong reduction: rank 1 sees a perturbed bucket (what a stale remote line would look
+    # like); BOTH ranks must undo the step, redo it on the collective's result and stay on torch.distributed afterwards
+    conf2, model2, bucket2, opt2 = setup(dev, 7, rank, world)
+    _, twin2, tbucket2, topt2 = setup(dev, 99)
+    twin2.load_state_dict(model2.state_dict())
+    opt2.peer._selfcheck_perturb = (rank == 1)
+    for step in range(2):
+        x, y = bag_of(rank, step)
+        model2.train_step(x.to(dev).unsqueeze(0), torch.tensor([y], device=dev), uniforms=uniforms[step], guard_flag=opt2.guard_flag)
+        bucket2.sync_from_grads()
+        if step > 0:                                               # after the fallback the bucket is reduced by the collective again
+            before = bucket2.flat.clone()
+            cpu = bucket2.flat.cpu(); dist.all_reduce(cpu); bucket2.flat.copy_((cpu / world).to(dev))      # (gloo control plane: host all-reduce)
+            assert not torch.equal(before, bucket2.flat)
+        opt2.step(track_flag=True)
+        opt2.poll_skipped(0)
+        assert opt2.peer is None and bucket2.peer.owner is None and bucket2.peer.verdict.startswith("mismatch"), bucket2.peer.verdict
+        acc = torch.zeros_like(tbucket2.flat)
+        for r in range(world):
+            xr, yr = bag_of(r, step)
+            twin2.train_step(xr.to(dev).unsqueeze(0), torch.tensor([yr], device=dev), uniforms=uniforms[step], guard_flag=topt2.guard_flag)
+            tbucket2.sync_from_grads()
+            acc += tbucket2.flat
+        tbucket2.flat.copy_(acc / world)
+        topt2.step(track_flag=True)
+        topt2.poll_skipped(0)
+        assert torch.equal(topt2.flat, opt2.flat), "fallback step %d != single process on averaged gradients" % step
+    bucket2.peer.close()
     dist.barrier()
     if rank == 0:
-        print("PEER_OK")
+        print("PEER_OK memory=%s" % memory)
     dist.destroy_process_group()
 
 

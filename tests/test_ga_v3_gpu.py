@@ -39,11 +39,11 @@ def test_wide_fused_forward_matches_oracle(d, di, k, c):
         with torch.no_grad():
             sub, slide, a = model(x.cuda())
         ref = O.acmil_ga_forward(x, sd, n_token=k)
-        assert (a[0].cpu() - ref["A_out"]).abs().max().item() < TOL, n
+        assert (a.cpu() - ref["A_out"]).abs().max().item() < TOL, n
         assert (sub.cpu() - ref["sub_preds"]).abs().max().item() < TOL, n
         assert (slide[0].cpu() - ref["slide_pred"]).abs().max().item() < TOL, n
         kk = min(10, n)
-        assert torch.equal(torch.topk(a[0].cpu(), kk, dim=-1).indices, torch.topk(ref["A_out"], kk, dim=-1).indices), n
+        assert torch.equal(torch.topk(a.cpu(), kk, dim=-1).indices, torch.topk(ref["A_out"], kk, dim=-1).indices), n
     assert model.range_fallbacks == 0
 
 
@@ -67,7 +67,7 @@ def test_wide_fused_16bit_bags_and_ragged_batch(d, di):
     ref = O.acmil_ga_forward(bags[2].half().float().unsqueeze(0), sd, n_token=5)
     with torch.no_grad():
         sub, slide, a = model(bags[2].half().cuda().unsqueeze(0))
-    assert (a[0].cpu() - ref["A_out"]).abs().max().item() < TOL and (sub.cpu() - ref["sub_preds"]).abs().max().item() < TOL
+    assert (a.cpu() - ref["A_out"]).abs().max().item() < TOL and (sub.cpu() - ref["sub_preds"]).abs().max().item() < TOL
 
 
 def test_wide_fused_range_guard_falls_back_to_fp32():
@@ -80,7 +80,7 @@ def test_wide_fused_range_guard_falls_back_to_fp32():
         sub, slide, a = model(x.cuda())
     ref = O.acmil_ga_forward(x, sd, n_token=5)
     assert model.range_fallbacks == 1 and torch.isfinite(a).all()
-    assert (a[0].cpu() - ref["A_out"]).abs().max().item() < 2e-2 * ref["A_out"].abs().max().item() + TOL      # fp32 arithmetic on 1e5-sized operands
+    assert (a.cpu() - ref["A_out"]).abs().max().item() < 2e-2 * ref["A_out"].abs().max().item() + TOL      # fp32 arithmetic on 1e5-sized operands
     assert (sub.cpu() - ref["sub_preds"]).abs().max().item() < 1e-3
 
 
@@ -97,7 +97,7 @@ def test_wide_score_pass_saves_h_and_trains(d, di):
     h_ref = torch.relu(x[0].double() @ sd["dimreduction.fc1.weight"].double().T).float()
     assert (h.cpu() - h_ref).abs().max().item() < 2e-5 * max(1.0, h_ref.abs().max().item())
     ref = O.acmil_ga_forward(x, sd, n_token=5)
-    assert (A.cpu() - ref["A_out"]).abs().max().item() < TOL
+    assert (A.cpu() - ref["A_out"][0]).abs().max().item() < TOL
     model.train()
     u = torch.rand(5, 10, generator=torch.Generator().manual_seed(4)).cuda()
     y = torch.tensor([2], device="cuda")

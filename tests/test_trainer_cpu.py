@@ -140,6 +140,9 @@ def test_bench_self_launch_command_and_dry_run_world2():
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         js = json.loads(line)
         assert js["dry_run"] is True and js["n_gpus"] == 2 and js["steps"] == 3 and js["value"] is None
+        if workload == "train":      # the data-parallel fields of the train line: the collective's time, and the direct reduction with its check
+            assert js["allreduce_us"] > 0 and js["allreduce_bytes"] == 833216
+            assert set(js["direct_reduce"]) >= {"ms_per_step", "first_step_check", "slot_memory"}
 
 
 def _dp_step_worker(rank, world, port, out):
@@ -188,6 +191,42 @@ def test_data_parallel_step_through_bucket_and_make_optimizer_matches_single_pro
         a, b = torch.load(o2, weights_only=False), torch.load(o1, weights_only=False)
     for pa, pb in zip(a, b):
         assert torch.allclose(pa, pb, atol=1e-6, rtol=1e-6)
+
+
+def _peer_fail_worker(rank, world, port, fail_rank):
+    """PeerReducer.try_create where the set-up cannot succeed (no GPU here; `fail_rank` additionally fails EARLY, before its
+    allocation): every rank must come back with None from the same number of collectives -- no hang, no mismatched collective."""
+    import torch.distributed as dist
+    from acmil_amd import peer as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == fail_rank:
+        orig = P.PeerReducer._alloc
+        P.PeerReducer._alloc = lambda self, memory: (_ for _ in ()).throw(RuntimeError("injected allocation failure"))
+    red = P.PeerReducer.try_create(1000, torch.device("cpu"), rank, world)
+    assert red is None
+    t = torch.tensor([rank + 1.0])
+    dist.all_reduce(t)                     # the process group is still in step: the next collective matches on every rank
+    assert t.item() == 3.0
+    # torch optimizer + a reducer nobody took over: the bucket keeps using the collective (ADVICE r4), make_optimizer drops the reducer
+    from acmil_amd import train as T
+    model = torch.nn.Linear(4, 3)
+    bucket = T.GradBucket(list(model.parameters()))
+
+    class _FakePeer:
+        owner = None
+    bucket.peer = _FakePeer()
+    bucket.flat.fill_(float(rank))
+    bucket.allreduce_mean(world)
+    assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, 0.5))
+    opt = T.make_optimizer(model, T.Struct(wd=0.0, torch_optimizer=True), torch.device("cpu"), bucket, lr=1e-3)
+    assert isinstance(opt, torch.optim.AdamW) and bucket.peer is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_peer_reducer_setup_failure_is_agreed_by_all_ranks(fail_rank):
+    mp.spawn(_peer_fail_worker, args=(2, _free_port(), fail_rank), nprocs=2, join=True)
 
 
 def test_grad_bucket_sync_repoints_only_what_autograd_replaced():

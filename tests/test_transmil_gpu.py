@@ -193,40 +193,53 @@ def test_one_launch_pinv_kernel_matches_the_product_chain():
 
 
 def test_side_stream_pipeline_matches_the_serial_one():
-    """Round 4: the Moore-Penrose chain of a layer runs on a library-owned side stream beside the attn3 leg (csrc/transmil.hip:
-    tm_side / tm_fork / tm_join; nystrom_attention.py:12-27 beside :113-127).  ACMIL_TM_SIDE_STREAM=0 is the serial pipeline:
-    logits agree to 1e-5 (the leg merges 32 instead of 64 key chunks when it shares the GPU: another summation order), the
-    intermediates h1 / hp / h2 to 2e-5 relative, and ten back-to-back forwards on one workspace (fork / join events re-recorded
-    every layer, no host synchronisation between them) are bit-identical.  Own processes: the library reads the knob once."""
-    import os
-    import subprocess
-    import sys
-    import tempfile
-    code = (
-        "import sys, torch; sys.path.insert(0, %r)\n"
-        "from acmil_amd import ops; from acmil_amd import synthetic as S\n"
-        "res = []\n"
-        "for n, d, di in ((700, 384, 128), (5000, 512, 256), (40000, 768, 384)):\n"
-        "    sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=3).items()}\n"
-        "    x = torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda()\n"
-        "    outs = [ops.transmil_forward(x, sd, 2, debug=True) for _ in range(10)]\n"
-        "    torch.cuda.synchronize()\n"
-        "    for o in outs[1:]:\n"
-        "        assert torch.equal(o['logits'], outs[0]['logits']) and torch.equal(o['h2'], outs[0]['h2'])\n"
-        "    res.append({k: outs[0][k].cpu() for k in ('logits', 'h1', 'hp', 'h2')})\n"
-        "torch.save(res, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = {}
-    with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("side", {}), ("serial", {"ACMIL_TM_SIDE_STREAM": "0"})):
-            e = ab_environ(**env)
-            path = os.path.join(d, tag + ".pt")
-            r = subprocess.run([sys.executable, "-c", code, path], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-            assert r.returncode == 0, r.stdout[-2000:]
-            out[tag] = torch.load(path)
-    for a, b in zip(out["side"], out["serial"]):
+    """The Moore-Penrose chain of a layer runs on a second stream beside the attn3 leg (csrc/transmil.hip: tm_fork / tm_join;
+    nystrom_attention.py:12-27 beside :113-127).  Round 5: that stream and its event pair are CALLER-owned
+    (acmil_transmil_forward_ex; acmil_amd.ops keeps one triple per device and compute stream); side_stream=False passes none =
+    the serial pipeline: logits agree to 1e-5 (the leg merges 32 instead of 64 key chunks when it shares the GPU: another summation
+    order), the intermediates h1 / hp / h2 to 2e-5 relative, and ten back-to-back forwards on one workspace (fork / join events
+    re-recorded every layer, no host synchronisation between them) are bit-identical.  The convenience entry
+    acmil_transmil_forward (library-owned stream) gives the side pipeline's bits."""
+    import ctypes
+    from acmil_amd import _lib, ops
+    from acmil_amd import synthetic as S
+    for n, d, di in ((700, 384, 128), (5000, 512, 256), (40000, 768, 384)):
+        sd = {k: v.cuda() for k, v in S.transmil_state_dict(d, di, 2, seed=3).items()}
+        x = torch.randn(n, d, generator=torch.Generator().manual_seed(n)).cuda()
+        res = {}
+        for tag, side in (("side", True), ("serial", False)):
+            outs = [ops.transmil_forward(x, sd, 2, debug=True, side_stream=side) for _ in range(10)]
+            torch.cuda.synchronize()
+            for o in outs[1:]:
+                assert torch.equal(o["logits"], outs[0]["logits"]) and torch.equal(o["h2"], outs[0]["h2"]), tag
+            res[tag] = outs[0]
+        a, b = res["side"], res["serial"]
         assert torch.isfinite(a["logits"]).all() and (a["logits"] - b["logits"]).abs().max().item() < 1e-5, (a["logits"], b["logits"])
         for k in ("h1", "hp", "h2"):
             assert (a[k] - b[k]).abs().max().item() <= 2e-5 * max(1.0, b[k].abs().max().item()), k
+        # the library-owned convenience entry
+        lib = _lib.load()
+        c = lambda k: sd[k].contiguous()
+        arr = lambda keys: (ctypes.c_void_p * len(keys))(*[c(k).data_ptr() for k in keys])
+        lay = lambda p: arr([p + ".norm.weight", p + ".norm.bias", p + ".attn.to_qkv.weight", p + ".attn.to_out.0.weight",
+                             p + ".attn.to_out.0.bias", p + ".attn.res_conv.weight"])
+        pp = arr(["pos_layer.proj.weight", "pos_layer.proj.bias", "pos_layer.proj1.weight", "pos_layer.proj1.bias",
+                  "pos_layer.proj2.weight", "pos_layer.proj2.bias"])
+        ws = torch.empty(lib.acmil_transmil_workspace_bytes(n, d, di, 2), dtype=torch.uint8, device="cuda")
+        logits = torch.empty(2, device="cuda")
+        rc = lib.acmil_transmil_forward(x.data_ptr(), n, d, di, 2, c("_fc1.0.weight").data_ptr(), c("_fc1.0.bias").data_ptr(),
+                                        c("cls_token").data_ptr(), lay("layer1"), lay("layer2"), pp, c("norm.weight").data_ptr(),
+                                        c("norm.bias").data_ptr(), c("_fc2.weight").data_ptr(), c("_fc2.bias").data_ptr(),
+                                        logits.data_ptr(), None, None, None, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(logits, a["logits"])
+        # partial triples are refused
+        assert lib.acmil_transmil_forward_ex(x.data_ptr(), n, d, di, 2, c("_fc1.0.weight").data_ptr(), c("_fc1.0.bias").data_ptr(),
+                                             c("cls_token").data_ptr(), lay("layer1"), lay("layer2"), pp, c("norm.weight").data_ptr(),
+                                             c("norm.bias").data_ptr(), c("_fc2.weight").data_ptr(), c("_fc2.bias").data_ptr(),
+                                             logits.data_ptr(), None, None, None, ws.data_ptr(), torch.cuda.current_stream().cuda_stream,
+                                             torch.cuda.Stream().cuda_stream, None, None) == -3
 
 
 def test_forward_with_the_side_stream_captures_into_a_hip_graph():
