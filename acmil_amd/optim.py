@@ -162,8 +162,7 @@ class FlatAdamW:
             self.grad.copy_(ref)
             peer.verdict = "mismatch: fell back to torch.distributed"
             peer.owner = None                                       # train.GradBucket.allreduce_mean takes over from the next step on
-            self.peer = None
-            self._plain_launch(lib, g, b1, b2, track, slot)
+            self.peer = None                                        # (step() now issues the plain launch on the collective's result)
             return
         peer.verified = True
         peer.verdict = "first step equals all_reduce (max |d| %.1e)" % float((reduced - ref).abs().max().item())

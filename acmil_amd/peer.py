@@ -54,7 +54,8 @@ class _Hip:
         L.hipIpcCloseMemHandle.argtypes = [ctypes.c_void_p]
         L.hipFree.argtypes = [ctypes.c_void_p]
         L.hipMemset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
-        for f in ("hipExtMallocWithFlags", "hipIpcGetMemHandle", "hipIpcOpenMemHandle", "hipIpcCloseMemHandle", "hipFree", "hipMemset"):
+        L.hipGetLastError.argtypes = []
+        for f in ("hipExtMallocWithFlags", "hipIpcGetMemHandle", "hipIpcOpenMemHandle", "hipIpcCloseMemHandle", "hipFree", "hipMemset", "hipGetLastError"):
             getattr(L, f).restype = ctypes.c_int
 
     @classmethod
@@ -63,9 +64,13 @@ class _Hip:
             cls._inst = cls()
         return cls._inst
 
-    @staticmethod
-    def ok(rc: int, what: str):
+    @classmethod
+    def ok(cls, rc: int, what: str):
         if rc != 0:
+            try:
+                cls.get().lib.hipGetLastError()        # clear the runtime's sticky last-error: torch's next call would trip over it
+            except Exception:
+                pass
             raise RuntimeError("%s failed (hipError %d)" % (what, rc))
 
 
@@ -111,7 +116,7 @@ class PeerReducer:
                     _Hip.ok(hip.lib.hipMemset(p, 0, max(nb, 4096)), "hipMemset")
                     h = _IpcHandle()
                     _Hip.ok(hip.lib.hipIpcGetMemHandle(ctypes.byref(h), p), "hipIpcGetMemHandle")
-                    ptrs.append(p.value); handles.append(bytes(h.reserved))
+                    ptrs.append(p.value); handles.append(ctypes.string_at(ctypes.byref(h), 64))      # (h.reserved would stop at the first NUL)
             torch.cuda.synchronize(self.device)
             self._mine = (ptrs[0], ptrs[1])
             return ("uncached", handles[0], handles[1])
@@ -164,6 +169,8 @@ class PeerReducer:
                 hip.lib.hipIpcCloseMemHandle(ctypes.c_void_p(p))
             for p in self._own_ptrs:
                 hip.lib.hipFree(ctypes.c_void_p(p))
+            if hip is not None:
+                hip.lib.hipGetLastError()
         except Exception:
             pass
         self._opened, self._own_ptrs, self._keep = [], [], []

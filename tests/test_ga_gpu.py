@@ -201,8 +201,11 @@ def test_batched_forward_equals_per_bag_forward(precision):
 
 
 def test_large_batch_launch_of_64_ragged_bags():
-    """One launch takes up to 64 bags (binary search of the tile -> bag map): 64 ragged bags equal their single launches bit for
-    bit; a 65th is refused with ACMIL_ERR_SHAPE."""
+    """One launch takes up to 64 bags (binary search of the tile -> bag map); a 65th is refused with ACMIL_ERR_SHAPE.  Per-patch
+    scores of the 64 ragged bags equal their single launches bit for bit.  The pooled logits agree to rounding: round 5 picks the
+    tile geometry per LAUNCH (this batch holds ~770 tiles of 128 patches -> 256-patch tiles, the single launches 128-patch tiles), and
+    the tile partition is the summation order of the pooled features -- 2e-6 here, the contract is 1e-4 (north_star); a launch by
+    itself stays bit-reproducible."""
     from acmil_amd import ops
     from oracle import ga_oracle as O
     sd = O.default_state_dict(512, 256, 2, 5)
@@ -213,8 +216,11 @@ def test_large_batch_launch_of_64_ragged_bags():
     out = ops.ga_forward_batch(xs, packed, dims, "f16x3")
     for i in (0, 1, 17, 31, 32, 47, 63):
         single = ops.ga_forward(xs[i], packed, dims, "f16x3")
-        assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
-        assert torch.equal(single["slide_pred"], out["slide_pred"][i])
+        assert torch.equal(single["A_out"], out["A_out"][i])
+        assert (single["sub_preds"] - out["sub_preds"][i]).abs().max().item() < 2e-6
+        assert (single["slide_pred"] - out["slide_pred"][i]).abs().max().item() < 2e-6
+    again = ops.ga_forward_batch(xs, packed, dims, "f16x3")
+    assert torch.equal(again["sub_preds"], out["sub_preds"]) and torch.equal(again["slide_pred"], out["slide_pred"])
     with pytest.raises(RuntimeError, match="ACMIL_ERR_SHAPE"):
         ops.ga_forward_batch(xs + [xs[0]], packed, dims, "f16x3")
 
