@@ -149,3 +149,50 @@ def test_64_patch_wave_tile_of_the_256_family_matches_the_default_kernel(tmp_pat
         # v3: batched launch == single launches, bit for bit
         for i in range(5):
             assert all(torch.equal(p, q) for p, q in zip(fam3[i], fam3[7 + i]))
+
+
+def test_wide_abmil_and_batched_evaluate():
+    """ABMIL (one branch, no bag head) at the UNI width runs the fused kernel too; train.evaluate drives the wide module through
+    forward_batch with the lagged range check: per-slide probabilities equal the one-slide-per-call loop, also with one bag outside the
+    f16 range (its batch is repeated op by op in fp32 arithmetic)."""
+    from acmil_amd import synthetic as S
+    from acmil_amd import train as T
+    from acmil_amd.architecture.transformer import ABMIL
+    from oracle import ga_oracle as O
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 1024, 512, 3, 1
+
+    sd = S.ga_state_dict(1024, 512, 3, 1, seed=5, abmil=True)
+    ab = ABMIL(Conf)
+    ab.load_state_dict(sd)
+    ab = ab.cuda().eval()
+    assert ab._is_wide_fused()
+    x = O.synthetic_bag(2500, 1024, slide_idx=12)
+    with torch.no_grad():
+        logits = ab(x.cuda())
+    assert (logits.cpu() - O.abmil_forward(x, sd)).abs().max().item() < TOL
+
+    conf = T.Struct(train_epoch=1, warmup_epoch=0, wd=1e-2, lr=1e-3, min_lr=0, n_class=3, n_token=5, n_masked_patch=0, mask_drop=0.0,
+                    arch="ga", precision="f16x3", seed=1, D_feat=1024, D_inner=512)
+    dev = torch.device("cuda", 0)
+    T.set_seed(2)
+    model = T.build_model(conf).to(dev)
+    g = torch.Generator().manual_seed(4)
+    bags = [(torch.randn(200 + 37 * i, 1024, generator=g).half(), i % 3) for i in range(T.EVAL_BATCH + 5)]
+    bad = bags[7][0].float().clone(); bad[3, 5] = 2.0e5
+    bags[7] = (bad, bags[7][1])
+
+    class _Bags:
+        def __len__(self): return len(bags)
+        def __getitem__(self, i): return {"input": bags[i][0], "label": bags[i][1]}
+
+    d_b, d_s = {}, {}
+    model.range_fallbacks = 0
+    res_b = T.evaluate(model, _Bags(), dev, conf, "Val", batched=True, detail=d_b)
+    assert model.range_fallbacks == 1
+    res_s = T.evaluate(model, _Bags(), dev, conf, "Val", batched=False, detail=d_s)
+    assert torch.isfinite(d_b["prob"]).all()
+    assert (d_b["prob"] - d_s["prob"]).abs().max().item() < 1e-5 and (d_b["loss"] - d_s["loss"]).abs().max().item() < 1e-5
+    for a, b in zip(res_b, res_s):
+        assert abs(a - b) < 1e-5
