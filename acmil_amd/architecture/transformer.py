@@ -154,6 +154,15 @@ class _GatedBase(nn.Module):
     def _heads(self):
         raise NotImplementedError
 
+    def _check_dropout(self):
+        """Classifier_1fc(droprate != 0) (network.py:10-16; the reference's ACMIL / ABMIL constructors pass their `droprate` through,
+        transformer.py:270-275,292-299, every shipped script leaves it 0): nn.Dropout is the identity in eval mode, so such a model
+        -- e.g. a checkpoint trained elsewhere with head dropout -- evaluates here exactly as in the reference.  TRAINING with it would
+        need the mask inside the fused head / tail kernels: refused, loudly."""
+        if getattr(self, "droprate", 0) != 0 and self.training:
+            raise NotImplementedError("acmil_amd: training with classifier dropout (droprate != 0) is not built: the heads live inside the "
+                                      "fused kernels; eval mode works (dropout is the identity there)")
+
     def _raw_params(self):
         wc, bc, ws, bs = self._heads()
         a = self.attention
@@ -388,8 +397,7 @@ class _GatedBase(nn.Module):
 class ABMIL(_GatedBase):
     def __init__(self, conf, D=128, droprate=0, *, precision="f16x3", range_guard=True):
         super().__init__()
-        if droprate != 0:
-            raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
+        self.droprate = droprate      # Classifier_1fc's dropout (network.py:10-16): identity in eval mode; training with it is refused at call time
         self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
         self.attention = Attention_Gated(conf.D_inner, D, 1)
         self.classifier = Classifier_1fc(conf.D_inner, conf.n_class, droprate)
@@ -400,6 +408,7 @@ class ABMIL(_GatedBase):
         return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
 
     def forward(self, x):  # x: [1, N, D_feat] -> logits [1, C]   (transformer.py:277-286)
+        self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
@@ -415,8 +424,7 @@ class ACMIL_GA(_GatedBase):
     def __init__(self, conf, D=128, droprate=0, n_token=1, n_masked_patch=0, mask_drop=0, *, precision="f16x3", range_guard=True):
         super().__init__()
         self.range_guard = range_guard
-        if droprate != 0:
-            raise NotImplementedError("acmil_amd: classifier dropout is unused on this path (always 0 in the reference)")
+        self.droprate = droprate      # see ABMIL
         self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
         self.attention = Attention_Gated(conf.D_inner, D, n_token)
         self.classifier = nn.ModuleList()
@@ -434,6 +442,7 @@ class ACMIL_GA(_GatedBase):
 
     def forward(self, x, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N])  (transformer.py:305-330)."""
+        self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
@@ -463,6 +472,7 @@ class ACMIL_GA(_GatedBase):
         FlatAdamW.guard_flag): no read-back at all -- the step leaves 1.0 / 0.0 there for the optimizer launch to act on
         (it skips a flagged step; train.train_one_epoch repeats the bag in fp32 two steps later).  precision overrides the
         module's arithmetic for this call ("fp32": the repeat)."""
+        self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training

@@ -130,3 +130,26 @@ def test_fixtures_load_into_modules():
     m = ACMIL_GA(Conf, n_token=k)
     missing, unexpected = m.load_state_dict(sd, strict=True)
     assert not missing and not unexpected
+
+
+def test_classifier_dropout_is_accepted_for_eval_and_refused_for_training():
+    """Classifier_1fc(droprate != 0) (reference network.py:10-16): same state_dict keys (nn.Dropout has no parameters), the module
+    constructs and may evaluate; a training-mode call is refused before anything is launched."""
+    from acmil_amd.architecture.transformer import ABMIL, ACMIL_GA
+
+    class Conf:
+        D_feat, D_inner, n_class, n_token = 384, 128, 3, 5
+
+    plain = ACMIL_GA(Conf, n_token=5)
+    drop = ACMIL_GA(Conf, droprate=0.25, n_token=5)
+    assert list(plain.state_dict()) == list(drop.state_dict())
+    drop.train()
+    with pytest.raises(NotImplementedError, match="classifier dropout"):
+        drop(torch.zeros(1, 4, 384))
+    ab = ABMIL(Conf, droprate=0.1).train()
+    with pytest.raises(NotImplementedError, match="classifier dropout"):
+        ab(torch.zeros(1, 4, 384))
+    drop.eval()
+    with pytest.raises(RuntimeError):          # eval mode passes the dropout check and reaches the library: a CPU tensor is refused there
+        with torch.no_grad():
+            drop(torch.zeros(1, 4, 384))
