@@ -344,6 +344,9 @@ def other_workloads(args, ctx):
     if world > 1:
         try:
             opt.poll_skipped(0)
+            # a benchmark must not sit out the trainer's 120 s patience if a peer's flags never arrive on an untried fabric: 10 s, then the
+            # first-step check reports the timeout and the steps run on all_reduce
+            os.environ.setdefault("ACMIL_PEER_TIMEOUT_S", "10")
             bucket_d = T.GradBucket(list(model.parameters()))
             if bucket_d.enable_direct(rank, world):
                 opt_d = T.make_optimizer(model, conf, dev, bucket_d, lr=conf.lr)
