@@ -6,18 +6,21 @@
 // (192 columns: no half-rate remainder launch; the TransMIL width and CLIP-L's D_inner: 272 vs 323 us at M = 100 000, K = 768).  Chunk = K/16 steps; step = ND "hi"
 // fragment rows then ND "lo" rows; fragment row (step s, tile d): lane (i = lane & 31, hi = lane >> 5) holds the 8 f16 halves of
 // W[col0 + 32 d + i][16 s + 8 hi .. + 7].
-struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; const float* colscale; };   // colscale [K] or null: pack W[c][k] * colscale[k]
+struct LinPackArgs { const float* W; char* out; int ldw, n_out, K; const float* colscale; int wide8; };   // colscale [K] or null: pack W[c][k] * colscale[k]
 struct LinPlan { int nd, nmain, nd_rem; };      // nmain chunks of 32 * nd columns, then one chunk of 32 * nd_rem columns (0 = none)
-__host__ __device__ static inline LinPlan lin_plan(int n_out) {
-    if (n_out % 192 == 0 && n_out % 256 != 0) return LinPlan{6, n_out / 192, 0};      // 384 (TransMIL width), 1152 (its to_qkv), 576, ...
+// wide8: the 8-wave geometry (256-row tiles) needs whole fragment rows per wave, i.e. ND = 8 / 4 chunks
+__host__ __device__ static inline LinPlan lin_plan(int n_out, bool wide8 = false) {
+    if (!wide8 && n_out % 192 == 0 && n_out % 256 != 0) return LinPlan{6, n_out / 192, 0};      // 384 (TransMIL width), 1152 (its to_qkv), 576, ...
     return LinPlan{8, n_out / 256, (n_out % 256) ? 4 : 0};
 }
+// A/B builds: ACMIL_LIN_WAVES=8 runs every packed Linear launch on the 8-wave geometry (pack and launch must agree: read once)
+static bool lin_wide8() { static const bool v = [] { const char* e = ACMIL_AB_ENV("ACMIL_LIN_WAVES"); return e && atoi(e) == 8; }(); return v; }
 
 __device__ __forceinline__ void lin_pack_rows(const LinPackArgs& a, unsigned block) {
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const size_t row = (size_t)block * 4 + (threadIdx.x >> 6);
     const int S1 = a.K / 16;
-    const LinPlan P = lin_plan(a.n_out);
+    const LinPlan P = lin_plan(a.n_out, a.wide8 != 0);
     const size_t per = (size_t)S1 * 2 * P.nd;                 // fragment rows of one main chunk
     const size_t rows_full = (size_t)P.nmain * per;
     const size_t rows_all = rows_full + (size_t)S1 * 2 * P.nd_rem;
@@ -55,7 +58,7 @@ static bool lin_dims_ok(int n_out, int K) { return n_out > 0 && K >= 32 && n_out
 
 extern "C" size_t acmil_linear_packed_bytes(int n_out, int K) {
     if (!lin_dims_ok(n_out, K)) return 0;
-    const LinPlan P = lin_plan(n_out);
+    const LinPlan P = lin_plan(n_out, lin_wide8());
     return (size_t)(K / 16) * GA_FRAG_ROW * ((size_t)2 * P.nd * P.nmain + 2 * P.nd_rem);
 }
 
@@ -69,7 +72,7 @@ int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, cons
         const int q = j < n ? j : 0;
         if (!lin_dims_ok(n_out[q], K[q]) || ldw[q] < K[q]) return ACMIL_ERR_SHAPE;
         if (!W[q] || !packed[q]) return ACMIL_ERR_NULL;
-        m.job[j] = LinPackArgs{W[q], (char*)packed[q], ldw[q], n_out[q], K[q], colscale ? colscale[q] : nullptr};
+        m.job[j] = LinPackArgs{W[q], (char*)packed[q], ldw[q], n_out[q], K[q], colscale ? colscale[q] : nullptr, lin_wide8() ? 1 : 0};
         const size_t rows = acmil_linear_packed_bytes(n_out[q], K[q]) / GA_FRAG_ROW;
         if (rows > maxrows) maxrows = rows;
     }
@@ -80,15 +83,15 @@ int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, cons
 extern "C" int acmil_linear_pack(const float* W, int ldw, int n_out, int K, void* packed, void* stream) {
     if (!lin_dims_ok(n_out, K) || ldw < K) return ACMIL_ERR_SHAPE;
     if (!W || !packed) return ACMIL_ERR_NULL;
-    LinPackArgs a = {W, (char*)packed, ldw, n_out, K, nullptr};
+    LinPackArgs a = {W, (char*)packed, ldw, n_out, K, nullptr, lin_wide8() ? 1 : 0};
     const size_t rows = acmil_linear_packed_bytes(n_out, K) / GA_FRAG_ROW;
     hipLaunchKernelGGL(lin_pack_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
-template <int ND, int XDT, int FX = 0>
+template <int ND, int XDT, int FX = 0, int WV = 4>
 static int lin_launch(const LinArgs& a, hipStream_t st) {
-    using G = Ga2Geom<ND, 1, XDT>;
+    using G = Ga2Geom<ND, 1, XDT, WV>;
     // per DEVICE: the dynamic-LDS attribute and the CU count (a process may drive several GPUs, or switch device after the first call)
     static int slots_of[16] = {0};
     int dev = 0;
@@ -96,13 +99,13 @@ static int lin_launch(const LinArgs& a, hipStream_t st) {
     if (slots_of[dev] == 0) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return ACMIL_ERR_LAUNCH;
-        if (hipFuncSetAttribute((const void*)lin_kernel<ND, XDT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
-        slots_of[dev] = 2 * prop.multiProcessorCount;
+        if (hipFuncSetAttribute((const void*)lin_kernel<ND, XDT, FX, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return ACMIL_ERR_LAUNCH;
+        slots_of[dev] = G::WGS * prop.multiProcessorCount;
     }
     const int slots = slots_of[dev];
     const long long tiles = (long long)((a.M + G::ROWS - 1) / G::ROWS) * a.nchunks;
-    const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(256);
-    hipLaunchKernelGGL((lin_kernel<ND, XDT, FX>), grid, block, G::LDS, st, a);
+    const dim3 grid((unsigned)(tiles < slots ? tiles : slots)), block(64 * WV);
+    hipLaunchKernelGGL((lin_kernel<ND, XDT, FX, WV>), grid, block, G::LDS, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
@@ -143,13 +146,16 @@ static bool lin_use64(int M, int K, int nchunks, int nd) {
 
 template <int ND>
 static int lin_launch_dt(const LinArgs& a, int x_dtype, hipStream_t st) {
-    if (a.act != 2 && lin_use64(a.M, a.K, a.nchunks, ND)) {
+    if (a.act != 2 && !lin_wide8() && lin_use64(a.M, a.K, a.nchunks, ND)) {
         switch (x_dtype) {
             case ACMIL_DTYPE_F32: return lin_launch64<ND, ACMIL_DTYPE_F32>(a, st);
             case ACMIL_DTYPE_F16: return lin_launch64<ND, ACMIL_DTYPE_F16>(a, st);
             case ACMIL_DTYPE_BF16: return lin_launch64<ND, ACMIL_DTYPE_BF16>(a, st);
         }
         return ACMIL_ERR_UNSUPPORTED;
+    }
+    if constexpr (ND == 8 || ND == 4) {
+        if (lin_wide8() && a.act != 2 && x_dtype == ACMIL_DTYPE_F32) return lin_launch<ND, ACMIL_DTYPE_F32, 0, 8>(a, st);
     }
     switch (x_dtype) {
         case ACMIL_DTYPE_F32: return lin_launch<ND, ACMIL_DTYPE_F32>(a, st);
@@ -182,7 +188,7 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
     a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
     a.nt_store = lin_nt_store(M, n_out, beta);
     a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
-    const LinPlan P = lin_plan(n_out);
+    const LinPlan P = lin_plan(n_out, lin_wide8());
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
         a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
@@ -215,11 +221,12 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0; a.status = nullptr;
     a.rowab = rowab; a.zrows = zrows; a.lm_part = lm_part; a.lm_l = lm_l; a.lm_cols = lm_part ? lm_cols : 0;
     a.nt_store = lin_nt_store(M, n_out, 0.0f);
-    const LinPlan P = lin_plan(n_out);
+    const LinPlan P = lin_plan(n_out, lin_wide8());
     int rc = ACMIL_OK;
     if (P.nmain > 0) {
         a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
-        if (lin_use64(M, K, P.nmain, P.nd)) rc = P.nd == 6 ? lin_launch64<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch64<8, ACMIL_DTYPE_F32, 3>(a, st);
+        if (lin_wide8()) rc = lin_launch<8, ACMIL_DTYPE_F32, 3, 8>(a, st);
+        else if (lin_use64(M, K, P.nmain, P.nd)) rc = P.nd == 6 ? lin_launch64<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch64<8, ACMIL_DTYPE_F32, 3>(a, st);
         else rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 3>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 3>(a, st);
         if (rc != ACMIL_OK) return rc;
     }
@@ -227,7 +234,7 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
         const int c0 = P.nmain * 32 * P.nd;
         a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
         a.bias = bias + c0; a.tile_counter = ctr + 16; a.done = ctr + 5;
-        rc = lin_launch<4, ACMIL_DTYPE_F32, 3>(a, st);
+        rc = lin_wide8() ? lin_launch<4, ACMIL_DTYPE_F32, 3, 8>(a, st) : lin_launch<4, ACMIL_DTYPE_F32, 3>(a, st);
     }
     return rc;
 }

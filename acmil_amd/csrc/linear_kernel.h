@@ -69,11 +69,14 @@ struct LinArgs {
     int nt_store;                   // non-zero: the epilogue's y stores bypass the L2 (outputs beyond the Infinity Cache)
 };
 
-template <int ND, int XDT, int FX = 0>
-__global__ __launch_bounds__(256, 2) void lin_kernel(LinArgs a) {
+// WV = 4: two 4-wave workgroups per CU, 128-row tiles (default).  WV = 8 (round 5, ND = 8 / 4 only): ONE 8-wave workgroup per CU, 256-row
+// tiles -- the weight stream crosses L2 -> LDS once per 256 rows (the Linear launches are bound by the CU's LDS-DMA / store path, not by the
+// matrix pipe: profiles/r04_lin64_ablation.md), still two waves per SIMD (lin64_kernel has the same bytes but one wave per SIMD).
+template <int ND, int XDT, int FX = 0, int WV = 4>
+__global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = Ga2Geom<ND, 1, XDT>;
-    constexpr int NTHR = 256, PD = G::PD, NB = G::NB;
+    using G = Ga2Geom<ND, 1, XDT, WV>;
+    constexpr int NTHR = 64 * WV, PD = G::PD, NB = G::NB;
     // lo plane: fp32 activations, and any LayerNorm-folded operand (an affine image of a 16-bit value is not f16-exact); a bf16
     // operand is f16-exact like an fp16 one (ga_forward_kernel_v2.h) and is only converted
     constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);

@@ -35,5 +35,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
     else:
-        for v in ("0", "1"):
-            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ACMIL_LIN64=v))
+        ab = os.path.join(ROOT, "acmil_amd", "libacmil_hip_ab.so")      # the knobs exist in the A/B build only
+        for env in ({"ACMIL_LIN64": "0"}, {"ACMIL_LIN64": "1"}, {"ACMIL_LIN_WAVES": "8"}, {"ACMIL_LIN64": "0"}, {"ACMIL_LIN_WAVES": "8"}):
+            print("==", env, flush=True)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, ACMIL_HIP_LIB=ab, **env))
