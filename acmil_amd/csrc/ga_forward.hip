@@ -172,11 +172,15 @@ static int ga_no_tri() { static const int v = ACMIL_AB_ENV("ACMIL_GA2_NO_TRI") !
 // The one-wave-per-SIMD kernel (ga_forward_kernel_v3.h, split-f16 arithmetic only): the only fused kernel of the wide families
 // (D_inner 384 / 512: 32 patches per wave); at D_inner = 256 its 64-patch wave tile is chosen per launch by ga_pick_geometry().
 static bool ga_is_wide(int Di) { return Di == 384 || Di == 512; }
-static bool ga_has_v3(int Di, int K, int mode) { return mode == ACMIL_MODE_F16X3 && K <= 5 && (ga_is_wide(Di) || Di == 256); }
+static bool ga_has_v3(int Di, int K, int mode, int x_dtype = ACMIL_DTYPE_F16) {
+    return mode == ACMIL_MODE_F16X3 && K <= 5 && (ga_is_wide(Di) || Di == 256 || (Di == 128 && x_dtype != ACMIL_DTYPE_F32));
+}
+// 32-patch blocks per wave of the v3 family of a width: (16, 1), (12, 1), (8, 2), (4, 3: 16-bit bags only)
+static int ga_v3_pb(int Di) { return Di == 256 ? 2 : Di == 128 ? 3 : 1; }
 
 // Geometry of a pooled (eval) launch.  Wide families: always v3.  D_inner = 256: ACMIL_GA3=0|1 forces (A/B builds); default below.
-static int ga_pick_v3(int Di, int K, int mode, int nbags, long long total_patches) {
-    if (!ga_has_v3(Di, K, mode)) return 0;
+static int ga_pick_v3(int Di, int K, int mode, int x_dtype, int nbags, long long total_patches) {
+    if (!ga_has_v3(Di, K, mode, x_dtype)) return 0;
     if (ga_is_wide(Di)) return 1;
     static const int env = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA3"); return e ? atoi(e) : -1; }();
     if (env == 0 || env == 1) return env;
@@ -189,7 +193,7 @@ static int ga_dispatch(const GaFwdArgs& a, int mode, int x_dtype, bool pool, hip
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
     if (a.v3) {
         if (mode != ACMIL_MODE_F16X3) return ACMIL_ERR_UNSUPPORTED;
-        const int PB = ND == 8 ? 2 : 1;
+        const int PB = ga_v3_pb(32 * ND);
 #define GA3_FAMILY(ND_, PB_, KP_) \
         if (ND == ND_ && PB == PB_ && KP == KP_) return ga_fwd3_family_##ND_##_##PB_##_##KP_(a, x_dtype, pool, st);
 #include "ga_families3.inc"
@@ -294,8 +298,9 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     for (int b = 0; b < nbags; ++b) tiles128 += (Ns[b] + 127) / 128;
     a.waves = ga_use_v2(mode) ? ga_v2_waves(tiles128) : ga_pick_waves(maxN, total_patches);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
-    a.v3 = ga_pick_v3(Di, K, mode, nbags, total_patches);
-    if (a.v3) a.waves = ga_is_wide(Di) ? 4 : 8;        // tile rows = 32 * waves: 128 (32 patches per wave) / 256 (64 per wave)
+    a.v3 = ga_pick_v3(Di, K, mode, x_dtype, nbags, total_patches);
+    if (packed_fp32 && Di == 128) a.v3 = 0;            // the exact-fp32 repeat (v1 kernel) shares the tile partition: 128- / 256-patch tiles only
+    if (a.v3) a.waves = 4 * ga_v3_pb(Di);              // tile rows = 32 * waves: 128 (32 patches per wave) / 256 (64) / 384 (96)
     if (a.v3 && !ga_use_v2(mode)) return ACMIL_ERR_UNSUPPORTED;
     a.tile_start[0] = 0;
     for (int b = 0; b < GA_MAX_BATCH; ++b) {
