@@ -249,7 +249,10 @@ class PeerReducer:
         return self._slot_ptrs[self.step_id & 1]
 
     def check(self):
-        """Host-side look at the timeout word (synchronises): raises if a peer's flag never arrived."""
+        """Host-side look at the timeout word (synchronises): raises if a peer's flag never arrived.  A reducer the optimizer has
+        given up (first-step check failed: training continues on torch.distributed) has nothing left to report."""
+        if self.owner is None and self.verdict.startswith("mismatch"):
+            return
         if int(self.err.item()) != 0:
             raise RuntimeError("acmil_amd.PeerReducer: a peer's gradient flag did not arrive within %.1f s (rank %d)" % (self.timeout_s, self.rank))
 

@@ -111,6 +111,7 @@ def main():
         topt2.step(track_flag=True)
         topt2.poll_skipped(0)
         assert torch.equal(topt2.flat, opt2.flat), "fallback step %d != single process on averaged gradients" % step
+    bucket2.peer.check()                                           # a reducer that fell back has nothing to report (no raise)
     bucket2.peer.close()
     dist.barrier()
     if rank == 0:
