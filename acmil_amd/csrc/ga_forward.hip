@@ -154,10 +154,12 @@ static bool ga_memset_mode() { static const bool v = ACMIL_AB_ENV("ACMIL_GA_MEMS
 // partition is the summation order of the pooled features, so a bag's logits may differ in the last bits (<= 2e-6 measured; the
 // contract is 1e-4) with what shares its launch; per-patch scores are bit-identical in both geometries, and a given launch is
 // bit-reproducible.  ACMIL_GA2_WAVES=4|8 forces (A/B builds).
-static int ga_v2_waves(long long tiles128) {
+static int ga_v2_waves(long long tiles128, int Di) {
     static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA2_WAVES"); return e ? atoi(e) : 0; }();
     if (v == 4 || v == 8) return v;
-    return (tiles128 > 256 && tiles128 <= 1024) ? 8 : 4;
+    // (D_inner = 256 only: that is where the table above was measured; the 128-wide family keeps its three 4-wave workgroups per CU --
+    //  one bf16 bag of 391 tiles: 50.8 us with them, 52.4 with one 8-wave workgroup)
+    return (Di == 256 && tiles128 > 256 && tiles128 <= 1024) ? 8 : 4;
 }
 
 // wave-pair split of GEMM1 (ga_forward_kernel_v2.h); ACMIL_GA2_PAIR=0|1 overrides (A/B measurements); read once
@@ -296,7 +298,7 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
     for (int b = 0; b < nbags; ++b) total_patches += Ns[b];
     long long tiles128 = 0;
     for (int b = 0; b < nbags; ++b) tiles128 += (Ns[b] + 127) / 128;
-    a.waves = ga_use_v2(mode) ? ga_v2_waves(tiles128) : ga_pick_waves(maxN, total_patches);
+    a.waves = ga_use_v2(mode) ? ga_v2_waves(tiles128, Di) : ga_pick_waves(maxN, total_patches);
     a.dephase = ga_dephase(); a.pair_split = ga_pair_split(); a.no_tri = ga_no_tri();
     a.v3 = ga_pick_v3(Di, K, mode, x_dtype, nbags, total_patches);
     if (packed_fp32 && Di == 128) a.v3 = 0;            // the exact-fp32 repeat (v1 kernel) shares the tile partition: 128- / 256-patch tiles only
