@@ -196,3 +196,71 @@ def test_wide_abmil_and_batched_evaluate():
     assert (d_b["prob"] - d_s["prob"]).abs().max().item() < 1e-5 and (d_b["loss"] - d_s["loss"]).abs().max().item() < 1e-5
     for a, b in zip(res_b, res_s):
         assert abs(a - b) < 1e-5
+
+
+def _wide_cases(seed, count):
+    import random
+    rng = random.Random(seed)
+    edge = [1, 2, 31, 32, 33, 127, 128, 129, 255, 256, 257, 383, 385, 511, 513, 1025]
+    out = []
+    for _ in range(count):
+        n = rng.choice(edge) if rng.random() < 0.4 else rng.randint(1, 7000)
+        d, di = rng.choice([(768, 384), (1024, 512), (512, 384), (1536, 512), (384, 512)])
+        out.append((n, d, di, rng.randint(1, 5), rng.randint(2, 7), rng.choice(["float32", "float32", "float16", "bfloat16"])))
+    return out
+
+
+@pytest.mark.parametrize("case", _wide_cases(77, 40), ids=lambda c: "n%d_d%d_di%d_k%d_c%d_%s" % c)
+def test_wide_fused_forward_random_shapes(case):
+    """Seeded sweep of ga_fwd3_kernel<12 | 16, 1>: ragged N incl. tile edges, any D (also D < D_inner), n_token 1..5, classes, bag dtypes."""
+    from acmil_amd import ops, synthetic as S
+    from oracle import ga_oracle as O
+    n, d, di, k, c, xdt = case
+    sd = S.ga_state_dict(d, di, c, k, seed=n + d + k)
+    x = S.synthetic_bag(n, d, slide_idx=n)[0].to(getattr(torch, xdt))
+    ref = O.acmil_ga_forward(x.float().unsqueeze(0), sd, n_token=k)
+    dev = {kk: v.cuda() for kk, v in sd.items()}
+    packed, dims = ops.ga_pack_weights(
+        dev["dimreduction.fc1.weight"], dev["attention.attention_V.0.weight"], dev["attention.attention_V.0.bias"],
+        dev["attention.attention_U.0.weight"], dev["attention.attention_U.0.bias"], dev["attention.attention_weights.weight"],
+        dev["attention.attention_weights.bias"], [dev["classifier.%d.fc.weight" % i] for i in range(k)],
+        [dev["classifier.%d.fc.bias" % i] for i in range(k)], dev["Slide_classifier.fc.weight"], dev["Slide_classifier.fc.bias"], "f16x3")
+    out = ops.ga_forward(x.cuda(), packed, dims, "f16x3", want_afeat=True, want_bag_feat=True)
+    assert int(out["range_status"]) == 0
+    assert (out["A_out"].cpu() - ref["A_out"][0]).abs().max() < TOL
+    assert (out["sub_preds"].cpu() - ref["sub_preds"]).abs().max() < TOL
+    assert (out["slide_pred"].cpu() - ref["slide_pred"][0]).abs().max() < TOL
+    assert (out["afeat"].cpu() - ref["afeat"]).abs().max() < TOL
+    assert (out["bag_feat"].cpu() - ref["bag_feat"][0]).abs().max() < TOL
+    kk = min(10, n)
+    assert torch.equal(torch.topk(out["A_out"].cpu(), kk, dim=-1).indices, torch.topk(ref["A_out"][0], kk, dim=-1).indices)
+    # the score pass of a training step on the same bag: same scores bit for bit, h = relu(x W1^T)
+    A, h = ops.ga_scores(x.cuda(), packed, dims, "f16x3")
+    assert torch.equal(A, out["A_out"])
+    assert (h.cpu() - ref["h"]).abs().max() < 2e-5 * max(1.0, ref["h"].abs().max().item())
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_wide_batched_launch_random_ragged_bags(seed):
+    import random
+    from acmil_amd import ops, synthetic as S
+    from oracle import ga_oracle as O
+    rng = random.Random(seed)
+    d, di, k, c = rng.choice([(1024, 512, 5, 2), (768, 384, 3, 4), (768, 512, 1, 7)])
+    sd = S.ga_state_dict(d, di, c, k, seed=seed)
+    dev = {kk: v.cuda() for kk, v in sd.items()}
+    packed, dims = ops.ga_pack_weights(
+        dev["dimreduction.fc1.weight"], dev["attention.attention_V.0.weight"], dev["attention.attention_V.0.bias"],
+        dev["attention.attention_U.0.weight"], dev["attention.attention_U.0.bias"], dev["attention.attention_weights.weight"],
+        dev["attention.attention_weights.bias"], [dev["classifier.%d.fc.weight" % i] for i in range(k)],
+        [dev["classifier.%d.fc.bias" % i] for i in range(k)], dev["Slide_classifier.fc.weight"], dev["Slide_classifier.fc.bias"], "f16x3")
+    ns = [rng.choice([1, 33, 128, 129, 700, 2500, 4097]) if rng.random() < 0.5 else rng.randint(1, 5000) for _ in range(rng.randint(2, 24))]
+    bags = [S.synthetic_bag(n, d, slide_idx=100 * seed + i)[0] for i, n in enumerate(ns)]
+    out = ops.ga_forward_batch([b.cuda() for b in bags], packed, dims, "f16x3")
+    for i, b in enumerate(bags):
+        ref = O.acmil_ga_forward(b.unsqueeze(0), sd, n_token=k)
+        assert (out["A_out"][i].cpu() - ref["A_out"][0]).abs().max() < TOL, (i, ns[i])
+        assert (out["sub_preds"][i].cpu() - ref["sub_preds"]).abs().max() < TOL, (i, ns[i])
+        assert (out["slide_pred"][i].cpu() - ref["slide_pred"][0]).abs().max() < TOL, (i, ns[i])
+        single = ops.ga_forward(b.cuda(), packed, dims, "f16x3")
+        assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
