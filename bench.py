@@ -320,6 +320,25 @@ def other_workloads(args, ctx):
             if opt.poll_skipped(2):
                 raise SystemExit("bench: a synthetic bag left the split-f16 range")
         return step
+    if getattr(args, "direct_leg", False):
+        # child mode (see below): the same steps with the DIRECT reduction, one JSON line on rank 0, nothing else
+        opt.poll_skipped(0)
+        os.environ.setdefault("ACMIL_PEER_TIMEOUT_S", "10")     # a benchmark must not sit out the trainer's 120 s patience
+        bucket_d = T.GradBucket(list(model.parameters()))
+        if bucket_d.enable_direct(rank, world):
+            opt_d = T.make_optimizer(model, conf, dev, bucket_d, lr=conf.lr)
+            peer = bucket_d.peer
+            dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)      # (its first step is the checked one: compared with all_reduce)
+            if opt_d.peer is not None:
+                opt_d.peer.check()
+            direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * args.steps / dt_d, 1), "unit": "slides/s",
+                      "first_step_check": peer.verdict, "slot_memory": peer.memory,
+                      "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"
+                              if opt_d.peer is not None else "the first-step check failed: these steps ran on torch.distributed all_reduce"}
+            peer.close()
+        else:
+            direct = {"error": "peer mapping unavailable: torch.distributed only"}
+        return {"direct_leg": direct}
     dt = _timed(make_step(bucket, opt), args, world, dev)
     # the collective alone (what the step pays for data parallelism): the same flat-bucket all-reduce + mean, back to back, events on
     # the launch stream; None on one GPU (GradBucket.allreduce_mean issues nothing there)
@@ -339,30 +358,28 @@ def other_workloads(args, ctx):
         dist.all_reduce(t_ar, op=dist.ReduceOp.MAX)
         allreduce_us = round(float(t_ar.item()), 2)
     # the same steps with the DIRECT reduction (acmil_amd/peer.py: the optimizer launch reads the peers' buckets through IPC-mapped
-    # pointers; no collective launch), timed after the RCCL line so that `value` keeps its meaning; never fatal
+    # pointers; no collective launch), timed after the RCCL line so that `value` keeps its meaning.  It runs in a CHILD process per rank
+    # (own rendezvous port): the path has never crossed a real xGMI link, and a fault in a kernel that reads a wrongly mapped peer
+    # buffer must cost this field, not the whole line.  Never fatal, bounded in time.
     direct = None
     if world > 1:
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}      # (no agent store: the child ranks make their own)
+        port = int(os.environ.get("MASTER_PORT", "29500"))
+        env["MASTER_PORT"] = str(port + 17 if port + 17 < 65000 else port - 17)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "train", "--train-n", str(N), "--gpus", str(world), "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--precision", args.precision, "--direct-leg", "--no-cpu-baseline"]
         try:
-            opt.poll_skipped(0)
-            # a benchmark must not sit out the trainer's 120 s patience if a peer's flags never arrive on an untried fabric: 10 s, then the
-            # first-step check reports the timeout and the steps run on all_reduce
-            os.environ.setdefault("ACMIL_PEER_TIMEOUT_S", "10")
-            bucket_d = T.GradBucket(list(model.parameters()))
-            if bucket_d.enable_direct(rank, world):
-                opt_d = T.make_optimizer(model, conf, dev, bucket_d, lr=conf.lr)
-                peer = bucket_d.peer
-                dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)      # (its first step is the checked one: compared with all_reduce)
-                if opt_d.peer is not None:
-                    opt_d.peer.check()
-                direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * args.steps / dt_d, 1), "unit": "slides/s",
-                          "first_step_check": peer.verdict, "slot_memory": peer.memory,
-                          "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"
-                                  if opt_d.peer is not None else "the first-step check failed: these steps ran on torch.distributed all_reduce"}
-                peer.close()
-            else:
-                direct = {"error": "peer mapping unavailable: torch.distributed only"}
-        except (Exception, SystemExit) as e:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if rank == 0:
+                direct = json.loads(lines[-1])["direct_leg"] if (r.returncode == 0 and lines) else {
+                    "error": "child exited with %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "")}
+        except subprocess.TimeoutExpired:
+            direct = {"error": "child timed out (240 s)"}
+        except Exception as e:
             direct = {"error": "%s: %s" % (type(e).__name__, e)}
+        _sync(world, dev)
     _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
     flops = fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)
     t_step = dt / args.steps
@@ -536,6 +553,7 @@ def main(argv=None):
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload only: skip the nested `secondary` lines (configs[2], [3], [4])")
+    ap.add_argument("--direct-leg", action="store_true", help=argparse.SUPPRESS)      # child mode of the train workload (direct gradient reduction)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check on CPU with gloo: no GPU, no compute, no metric value")
     args = ap.parse_args(argv)
