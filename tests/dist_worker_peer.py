@@ -53,6 +53,19 @@ def main():
         assert torch.equal(before, bucket.flat)
         sid = opt.step(track_flag=True)
         skipped = opt.poll_skipped(0)
+        if opt.peer is None:
+            # The first-step check found the direct reduction unequal to all_reduce and fell back.  With both ranks on ONE GPU that
+            # is a defect; across real links (a box with several GPUs: the path has never run there) it is the fail-safe doing its
+            # job: the ranks must still agree bit for bit, and the run ends here.
+            assert torch.cuda.device_count() > 1, "direct reduction failed its first-step check on a single GPU: %s" % bucket.peer.verdict
+            flats = [torch.empty_like(opt.flat).cpu() for _ in range(world)]
+            dist.all_gather(flats, opt.flat.cpu())
+            assert torch.equal(flats[0], flats[1]), "ranks diverged after the fallback"
+            bucket.peer.close()
+            if rank == 0:
+                print("PEER_OK fallback (%s)" % bucket.peer.verdict)
+            dist.destroy_process_group()
+            return
         opt.peer.check()
         assert (skipped == [sid]) == (step == 1), (step, skipped)
         flats = [torch.empty_like(opt.flat).cpu() for _ in range(world)]
