@@ -343,15 +343,14 @@ class _GatedBase(nn.Module):
                 out["range_fallback"] = True
             return out
         if self._is_wide_fused():
-            # ONE fused launch + merge + heads; the range word is read after the call (one synchronisation per slide, as the composed
-            # path had in the middle of its forward); a flagged bag (never seen on real features) is redone op by op in fp32
-            out = ops.ga_forward(xb, packed, dims, "f16x3", want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
-            if not self._out_of_range(out["range_status"]):
-                return out
-            A, h = self._score_pass_composed(xb, dims, "fp32")
-            out = ops.ga_pool(h, A, packed, dims, self.precision, None, want_bag_feat=want_bag_feat)
-            out["range_fallback"] = True
-            return out
+            # ONE fused launch + merge + heads, and -- round 5 -- NO host read-back: the exact-fp32 repeat (widen, projection, gated
+            # scores, pooling partials, op by op) is enqueued behind the fused launch with every kernel predicated ON THE DEVICE on its
+            # range status; merge + heads finish whichever result is there (acmil_ga_forward_guarded_wide)
+            if self.range_guard:
+                w1 = self.dimreduction.fc1.weight.detach()
+                return ops.ga_forward_guarded_wide(xb, packed, w1 if w1.is_contiguous() else w1.contiguous(), dims, self._fb_counter(xb.device),
+                                                   want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
+            return ops.ga_forward(xb, packed, dims, "f16x3", want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
         out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False)
         out.pop("h", None)
         return out

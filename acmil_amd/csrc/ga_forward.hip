@@ -275,13 +275,65 @@ extern "C" size_t acmil_ga_batch_workspace_bytes(int nbags, const int* Ns, int D
     return GA_CTRL_BYTES + bytes;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device-side range guard of the WIDE families (round 5).  The fused widths have an exact-fp32 twin of the fused kernel (v1) that is
+// enqueued behind the split-f16 launch and leaves at once unless the status word is set; D_inner 384 / 512 have no such twin (its 256
+// accumulator registers per wave need the one-wave-per-SIMD geometry).  Their repeat is the op-by-op chain in exact fp32 arithmetic --
+// [widen a 16-bit bag] -> h = relu(x W1^T) -> G = h [Wv;Wu]^T + b -> gate pass -> pooling partials -- every launch of it predicated on
+// the status word of the fused launch (4 - 5 launches that exit at once for an in-range bag: ~3 us each), writing the SAME outputs
+// (scores, 128-patch tile partials); merge + heads then finish whichever result is there.  No host read-back on the per-slide path.
+// The only operand the packed buffer does not hold in raw fp32 is W1; scratch (caller-owned) holds x32 / h / G / [scores] / GEMM workspace.
+struct GaWideRepeat { const float* W1; void* scratch; unsigned* fallback_count; };
+struct GaWideScratch { size_t x32, h, A, G, gws, total; };
+extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
+static GaWideScratch ga_wide_scratch(int N, int D, int Di, int K, int x_dtype, bool need_scores) {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    GaWideScratch S;
+    size_t off = 0;
+    S.x32 = off; off += x_dtype == ACMIL_DTYPE_F32 ? 0 : al((size_t)N * D * 4);
+    S.h = off;   off += al((size_t)N * Di * 4);
+    S.A = off;   off += need_scores ? al((size_t)K * N * 4) : 0;
+    S.G = off;   off += al((size_t)N * 2 * GA_DA * 4);
+    const size_t g1 = acmil_gemm_workspace_bytes(N, Di, D, 1), g2 = acmil_gemm_workspace_bytes(N, 2 * GA_DA, Di, 1);
+    S.gws = off; off += al(g1 > g2 ? g1 : g2);
+    S.total = off;
+    return S;
+}
+__global__ __launch_bounds__(256) void ga_widen_cond_kernel(const void* __restrict__ x, int x_dtype, long long n, float* __restrict__ y,
+                                                            const unsigned* __restrict__ cond) {
+    if (__builtin_nontemporal_load(cond) == 0u) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = x_dtype == ACMIL_DTYPE_F16 ? (float)((const _Float16*)x)[i] : (float)((const __bf16*)x)[i];
+}
+static int ga_wide_fp32_repeat(const void* x, int x_dtype, int N, const char* packed, const GaLayout& L, const GaWideRepeat& w,
+                               float* A_out, float* part, const unsigned* cond, hipStream_t st) {
+    const GaWideScratch S = ga_wide_scratch(N, L.D, L.Di, L.K, x_dtype, A_out == nullptr);
+    char* sc = (char*)w.scratch;
+    const float* x32 = (const float*)x;
+    if (x_dtype != ACMIL_DTYPE_F32) {
+        hipLaunchKernelGGL(ga_widen_cond_kernel, dim3(1024), dim3(256), 0, st, x, x_dtype, (long long)N * L.D, (float*)(sc + S.x32), cond);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+        x32 = (const float*)(sc + S.x32);
+    }
+    float* h = (float*)(sc + S.h);
+    int rc = gemm_f32_cond(0, 1, N, L.Di, L.D, 1.0f, x32, L.D, w.W1, ACMIL_DTYPE_F32, L.D, h, L.Di, nullptr, 1 /* relu */, sc + S.gws, st, cond);
+    if (rc != ACMIL_OK) return rc;
+    float* A = A_out ? A_out : (float*)(sc + S.A);
+    const float* tab = (const float*)(packed + L.tab_off);
+    rc = ag_gated_scores_cond(h, N, L.Di, GA_DA, L.K, (const float*)(packed + L.wcat_off), (const float*)(packed + L.bcat_off),
+                              tab + 2 * GA_DA, (const float*)(packed + L.bw_off), A, (float*)(sc + S.G), sc + S.gws, st, cond);
+    if (rc != ACMIL_OK) return rc;
+    return ga_pool_launch(h, A, N, L.K, L.Di, part, nullptr, st, cond, w.fallback_count);
+}
+
 // packed_fp32 != null (split-f16 mode only): the DEVICE-SIDE range guard -- right behind the split-f16 launch an exact-fp32 launch of
 // the same tiles is enqueued that every workgroup leaves at once unless the status word says a bag left the f16 range; it
 // then overwrites the scores and the partials, and merge + heads finish whichever result is there.  No host read-back.
 static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns, int x_dtype, const void* packed,
                                  int D, int Di, int Da, int K, int C, int mode, float* const* A_outs,
                                  float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
-                                 int has_bag_head, void* workspace, void* stream, const void* packed_fp32, unsigned* fallback_count) {
+                                 int has_bag_head, void* workspace, void* stream, const void* packed_fp32, unsigned* fallback_count,
+                                 const GaWideRepeat* wide = nullptr) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (nbags <= 0 || nbags > GA_MAX_BATCH) return ACMIL_ERR_SHAPE;
@@ -327,6 +379,11 @@ static int ga_forward_batch_impl(int nbags, const void* const* xs, const int* Ns
         rc = ga_dispatch(b, ACMIL_MODE_F32, x_dtype, true, st);
         if (rc != ACMIL_OK) return rc;
     }
+    if (wide) {      // the wide families' repeat: op by op in exact fp32, every launch predicated on this launch's status word
+        if (nbags != 1 || !a.v3 || !ga_is_wide(Di) || !a.status || Da != GA_DA) return ACMIL_ERR_UNSUPPORTED;
+        rc = ga_wide_fp32_repeat(xs[0], x_dtype, Ns[0], (const char*)packed, a.L, *wide, A_outs ? A_outs[0] : nullptr, a.part, a.status, st);
+        if (rc != ACMIL_OK) return rc;
+    }
     if (!(sub_preds || slide_pred || afeat || bag_feat)) return ACMIL_OK;
     const size_t poff = ((size_t)a.tile_start[nbags] * K * ga_part_stride(Di) * sizeof(float) + 255) & ~(size_t)255;
     // (measured: the single-launch finish of ga_step.hip -- ga_tail_eval -- costs 26 us against 12 us for these two launches at one
@@ -356,6 +413,25 @@ extern "C" int acmil_ga_forward_guarded(int nbags, const void* const* xs, const 
     if (!ga_use_v2(ACMIL_MODE_F16X3)) return ACMIL_ERR_UNSUPPORTED;
     return ga_forward_batch_impl(nbags, xs, Ns, x_dtype, packed_f16x3, D, Di, Da, K, C, ACMIL_MODE_F16X3, A_outs, sub_preds, slide_pred,
                                  afeat, bag_feat, has_bag_head, workspace, stream, packed_fp32, fallback_count);
+}
+
+extern "C" size_t acmil_ga_forward_guarded_wide_scratch_bytes(int N, int D, int Di, int K, int x_dtype, int need_scores) {
+    if (N <= 0 || D <= 0 || Di <= 0 || K <= 0) return 0;
+    return ga_wide_scratch(N, D, Di, K, x_dtype, need_scores != 0).total;
+}
+
+extern "C" int acmil_ga_forward_guarded_wide(const void* x, int x_dtype, int N, const void* packed_f16x3, const float* W1, int D, int Di,
+                                             int Da, int K, int C, float* A_out, float* sub_preds, float* slide_pred, float* afeat,
+                                             float* bag_feat, int has_bag_head, unsigned* fallback_count, void* scratch, void* workspace,
+                                             void* stream) {
+    if (!W1 || !scratch || !x) return ACMIL_ERR_NULL;
+    if (!ga_is_wide(Di) || K > 5) return ACMIL_ERR_UNSUPPORTED;
+    if (((size_t)scratch & 255) != 0) return ACMIL_ERR_SHAPE;
+    const GaWideRepeat w = {W1, scratch, fallback_count};
+    float* A1[1] = {A_out};
+    const void* x1[1] = {x};
+    return ga_forward_batch_impl(1, x1, &N, x_dtype, packed_f16x3, D, Di, Da, K, C, ACMIL_MODE_F16X3, A1, sub_preds, slide_pred, afeat,
+                                 bag_feat, has_bag_head, workspace, stream, nullptr, nullptr, &w);
 }
 
 extern "C" int acmil_ga_forward(const void* x, int x_dtype, int N, const void* packed, int D, int Di, int Da, int K,

@@ -253,7 +253,12 @@ __global__ void ga_apply_mask_kernel(float* __restrict__ A, int N, int K, const 
 // diversity loss (Step3_WSI_classification_ACMIL.py:207-212).
 template <int KP>
 __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ h, const float* __restrict__ A, int N,
-                                                      int K, int Di, float* __restrict__ part, float* __restrict__ gram) {
+                                                      int K, int Di, float* __restrict__ part, float* __restrict__ gram,
+                                                      const unsigned* __restrict__ cond, unsigned* __restrict__ cond_count) {
+    if (cond) {      // predicated launch: the exact-fp32 repeat of a flagged bag (ga_forward.hip); counted once per launch that ran
+        if (__builtin_nontemporal_load(cond) == 0u) return;
+        if (cond_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cond_count, 1u);
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* p_lds = (float*)smem;                     // [128][KP]
     float* stat = p_lds + 128 * KP;                  // [KP][2] : m, l
@@ -327,18 +332,19 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
 }
 
 // one workgroup per 128-row tile; gram: see the kernel.  Shared by acmil_ga_pool, acmil_attn_pool and the fused step.
-int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st) {
+int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st, const unsigned* cond,
+                   unsigned* cond_count) {
     if (Di % 64 != 0 || Di / 4 > 256 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;
     if (K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
     const int KP = ga_kp(K);
     const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
     const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
     if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
-    void (*kern)(const float*, const float*, int, int, int, float*, float*) =
+    void (*kern)(const float*, const float*, int, int, int, float*, float*, const unsigned*, unsigned*) =
         KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : KP == 8 ? ga_pool_kernel<8> : ga_pool_kernel<16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(ga_pool_tiles(N)), dim3(256), lds, st, h, A, N, K, Di, part, gram);
+    hipLaunchKernelGGL(kern, dim3(ga_pool_tiles(N)), dim3(256), lds, st, h, A, N, K, Di, part, gram, cond, cond_count);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
@@ -359,7 +365,7 @@ extern "C" int acmil_ga_pool(const float* h, float* A, int N, const void* packed
     const GaLayout L = ga_layout(D, Di, K, C, mode);
     const int tiles = ga_pool_tiles(N);
     float* part = (float*)((char*)workspace + GA_CTRL_BYTES);     // same layout as acmil_ga_forward: control block first
-    rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st);
+    rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st, nullptr, nullptr);
     if (rc != ACMIL_OK) return rc;
     return ga_finish(part, tiles, packed, L, sub_preds, slide_pred, afeat, bag_feat, has_bag_head, st);
 }
@@ -379,7 +385,7 @@ extern "C" int acmil_attn_pool(const float* h, const float* A, int N, int Di, in
     hipStream_t st = (hipStream_t)stream;
     const int tiles = ga_pool_tiles(N);
     float* part = (float*)workspace;
-    const int rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st);
+    const int rc = ga_pool_launch(h, A, N, K, Di, part, nullptr, st, nullptr, nullptr);
     if (rc != ACMIL_OK) return rc;
     GaLayout L; L.K = K; L.Di = Di; L.C = 1; L.D = 0; L.ND = Di / 32; L.mode = 0;
     return ga_finish(part, tiles, nullptr, L, nullptr, nullptr, afeat, nullptr, 0, st);

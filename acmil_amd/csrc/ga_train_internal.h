@@ -16,7 +16,13 @@ int ga_tail_eval(const float* part, const int* tile_start, int nbags, const void
 int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
                  int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st, unsigned long long rng_seed = 0,
                  unsigned long long rng_offset = 0);
-int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st);
+// cond (or null): the launch does nothing unless *cond != 0; cond_count (or null) is incremented once by a launch that ran under cond
+int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st,
+                   const unsigned* cond = nullptr, unsigned* cond_count = nullptr);
+
+// attn_generic.hip: exact-fp32 gated scores on the concatenated attention weights, predicated on *cond
+int ag_gated_scores_cond(const float* h, int N, int L, int Da, int K, const float* wcat, const float* bcat, const float* Ww, const float* bw,
+                         float* A, float* G, void* gws, hipStream_t st, const unsigned* cond);
 
 // ga_backward.hip
 struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, gemm2, wg, total; };

@@ -165,6 +165,7 @@ __device__ __forceinline__ void gm_epilogue(const GemmArgs& g, const f32x16 (&ac
 // WT = MFMA tiles per wave and dimension: 2 -> 128 x 128 workgroup tile, 1 -> 64 x 64.
 template <int BDT, int WT>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    if (g.cond && __builtin_nontemporal_load(g.cond) == 0u) return;      // predicated launch (gemm_internal.h)
     constexpr int G = 2 * WT, BT = 64 * WT, LD = BT + 4, WS = 32 * WT;   // groups/thread, tile edge, LDS row, wave tile edge
     __shared__ __attribute__((aligned(16))) float As[GM_BK * LD];
     __shared__ __attribute__((aligned(16))) float Bs[GM_BK * LD];
@@ -419,7 +420,10 @@ __device__ __forceinline__ void gm_reduce_body(const GemmArgs& g, int nbatch, in
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) { gm_reduce_body(g, nbatch, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int nbatch) {
+    if (g.cond && __builtin_nontemporal_load(g.cond) == 0u) return;
+    gm_reduce_body(g, nbatch, blockIdx.x, gridDim.x);
+}
 
 // One launch that finishes up to two split-K products (their fixed-order reduces + epilogues) and one "sum of per-workgroup
 // partial records" job (the gate pass of the GA backward): blocks [0, b1) reduce g1, [b1, b1 + b2) reduce g2, the rest
@@ -465,7 +469,7 @@ extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch) {
 static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                   long long strideA, const void* B, int b_dtype, int ldb, long long strideB, float beta,
                   float* C, int ldc, long long strideC, const float* bias, int act, const float* aux,
-                  int batch, void* workspace, void* stream, GemmArgs* defer = nullptr) {
+                  int batch, void* workspace, void* stream, GemmArgs* defer = nullptr, const unsigned* cond = nullptr) {
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || lda <= 0 || ldb <= 0 || ldc < N) return ACMIL_ERR_SHAPE;
     if (!A || !B || !C) return ACMIL_ERR_NULL;
     if (act < 0 || act > 4) return ACMIL_ERR_UNSUPPORTED;
@@ -475,7 +479,8 @@ static int gm_run(int x3, int transA, int transB, int M, int N, int K, float alp
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sA = strideA; g.sB = strideB; g.sC = strideC;
     g.transA = transA; g.transB = transB; g.b_dtype = b_dtype; g.act = act; g.alpha = alpha; g.beta = beta;
-    g.C2 = nullptr; g.split_row = 0;
+    g.C2 = nullptr; g.split_row = 0; g.cond = cond;
+    if (cond && x3 != 0) return ACMIL_ERR_UNSUPPORTED;      // only the exact-fp32 kernels carry the predicate
     g.splits = gm_pick_splits(M, N, K, batch);
     if (g.splits > 1 && !workspace) return ACMIL_ERR_NULL;
     const int ktiles = (K + GM_BK - 1) / GM_BK;
@@ -549,6 +554,12 @@ int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float
     if (!out) return ACMIL_ERR_NULL;
     return gm_run(x3, transA, transB, M, N, K, alpha, A, lda, 0, B, b_dtype, ldb, 0, beta, C, ldc, 0, bias, act, aux, 1, workspace,
                   (void*)stream, out);
+}
+
+int gemm_f32_cond(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B, int b_dtype, int ldb,
+                  float* C, int ldc, const float* bias, int act, void* workspace, hipStream_t stream, const unsigned* cond) {
+    return gm_run(0, transA, transB, M, N, K, alpha, A, lda, 0, B, b_dtype, ldb, 0, 0.0f, C, ldc, 0, bias, act, nullptr, 1, workspace,
+                  (void*)stream, nullptr, cond);
 }
 
 int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hipStream_t st) {

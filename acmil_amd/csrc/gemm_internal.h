@@ -10,6 +10,8 @@ struct GemmArgs {
     int transA, transB, b_dtype, act, splits, kchunk;
     float alpha, beta;
     float* C2; int split_row;   // deferred split-K products only: rows >= split_row go to C2 (row - split_row); C2 null: one destination
+    const unsigned* cond;       // or null: the launch does nothing unless *cond != 0 (device-side predicate: the exact-fp32 repeat of a
+                                // split-f16 launch that flagged its bag, ga_forward.hip)
 };
 
 // sum `records` partial records of `len` floats (record r at part + r * stride) in a fixed order; element e goes to the
@@ -27,3 +29,6 @@ int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float
                       void* workspace, hipStream_t stream, GemmArgs* out);
 // (set out->C2 / out->split_row after the call to scatter the reduced rows over two tensors, e.g. [dWv; dWu])
 int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hipStream_t stream);
+// exact-fp32 MFMA product C = act(alpha op(A) op(B) + bias), batch 1, that runs only if *cond != 0 (cond null: always)
+int gemm_f32_cond(int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B, int b_dtype, int ldb,
+                  float* C, int ldc, const float* bias, int act, void* workspace, hipStream_t stream, const unsigned* cond);

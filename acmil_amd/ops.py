@@ -233,6 +233,38 @@ def ga_forward_guarded(xs: Sequence[torch.Tensor], packed: torch.Tensor, packed_
     return out
 
 
+def ga_forward_guarded_wide(x: torch.Tensor, packed: torch.Tensor, W1: torch.Tensor, dims: GaDims,
+                            fallback_count: Optional[torch.Tensor] = None, want_scores: bool = True, want_preds: bool = True,
+                            want_afeat: bool = False, want_bag_feat: bool = False) -> Dict[str, torch.Tensor]:
+    """acmil_ga_forward_guarded_wide: the fused split-f16 forward of ONE bag at D_inner 384 / 512 followed, on the device, by its
+    exact-fp32 repeat op by op if (and only if) the bag left the f16 range -- no host read-back.  W1 = dimreduction.fc1.weight (raw
+    fp32, contiguous).  Same returns as ga_forward (unbatched)."""
+    lib = _lib.load()
+    _check_x(x, dims)
+    _need_cuda(packed, W1, fallback_count)
+    if W1.dtype != torch.float32 or not W1.is_contiguous() or tuple(W1.shape) != (dims.Di, dims.D):
+        raise RuntimeError("acmil_amd: W1 must be the contiguous fp32 [D_inner, D_feat] projection weight")
+    N, dev = x.shape[0], x.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    A = torch.empty(dims.K, N, **f32) if want_scores else None
+    sub = torch.empty(dims.K, dims.C, **f32) if want_preds else None
+    slide = torch.empty(dims.C, **f32) if (want_preds and dims.has_bag_head) else None
+    af = torch.empty(dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(dims.Di, **f32) if want_bag_feat else None
+    nsc = lib.acmil_ga_forward_guarded_wide_scratch_bytes(N, dims.D, dims.Di, dims.K, _DT[x.dtype], 0 if want_scores else 1)
+    scratch = torch.empty(nsc, dtype=torch.uint8, device=dev)          # only ever touched by a flagged bag (caching allocator: no cost otherwise)
+    ws = _workspace(N, dims, _lib.MODE_F16X3, dev)
+    rc = lib.acmil_ga_forward_guarded_wide(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), W1.data_ptr(), *dims.args(), _ptr(A), _ptr(sub),
+                                           _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), _ptr(fallback_count),
+                                           scratch.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_forward_guarded_wide")
+    out: Dict[str, torch.Tensor] = {"range_status": _range_status(ws)}
+    for k, v in (("A_out", A), ("sub_preds", sub), ("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out
+
+
 def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, with_status: bool = False):
     """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward);
     with_status: also the device view of the split-f16 range status (see _range_status)."""

@@ -141,6 +141,19 @@ int acmil_ga_forward_guarded(int nbags, const void* const* xs, const int* Ns, in
                              float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
                              unsigned* fallback_count, void* workspace, void* stream);
 
+/* The same device-side guard for the WIDE families (D_inner 384 / 512: architecture/transformer.py:305-330 on the feature extractors of
+ * Step3_WSI_classification_ACMIL.py:78-87), one bag per call: the fused split-f16 launch, then its exact-fp32 repeat OP BY OP
+ * ([widen a 16-bit bag] -> h = relu(x W1^T) -> gated scores -> pooling partials), every launch of it predicated on the status word of
+ * the fused launch, then merge + heads.  W1 [Di, D] = dimreduction.fc1.weight in raw fp32 (the other operands of the repeat are the raw
+ * copies inside `packed_f16x3`); scratch: caller-owned, 256-byte aligned, acmil_ga_forward_guarded_wide_scratch_bytes (need_scores = 1 if
+ * A_out is NULL); fallback_count as acmil_ga_forward_guarded. */
+size_t acmil_ga_forward_guarded_wide_scratch_bytes(int N, int D, int Di, int K, int x_dtype, int need_scores);
+
+int acmil_ga_forward_guarded_wide(const void* x, int x_dtype, int N, const void* packed_f16x3, const float* W1, int D, int Di, int Da,
+                                  int K, int C, float* A_out, float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
+                                  int has_bag_head, unsigned* fallback_count, void* scratch, void* workspace, void* stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * Masked pooling pass of a training step.  Replaces transformer.py:318-330 given the scores and h of the
  * score pass: A[k, masked_idx[k,:]] = -1e9 (written in place into A, which then IS the reference's A_out),

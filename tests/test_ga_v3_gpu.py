@@ -264,3 +264,36 @@ def test_wide_batched_launch_random_ragged_bags(seed):
         assert (out["slide_pred"][i].cpu() - ref["slide_pred"][0]).abs().max() < TOL, (i, ns[i])
         single = ops.ga_forward(b.cuda(), packed, dims, "f16x3")
         assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
+
+
+@pytest.mark.parametrize("d,di,k", [(768, 384, 5), (1024, 512, 1), (1024, 512, 3)])
+@pytest.mark.parametrize("xdt", ["float32", "bfloat16"])
+def test_wide_device_side_guard_repeats_a_flagged_bag_in_fp32(d, di, k, xdt):
+    """acmil_ga_forward_guarded_wide: no host read-back -- the op-by-op exact-fp32 repeat is enqueued behind the fused launch with every
+    kernel predicated on its status word.  An in-range bag: the fused result, counter untouched; a bag with a value outside the f16
+    range (fp32 or bf16 storage): the fp32 result (finite, equal to the oracle to fp32 round-off on 1e5-sized operands), counted once;
+    forward_feature (no scores requested: the repeat keeps them in its scratch) likewise; the next in-range bag is unaffected."""
+    from oracle import ga_oracle as O
+    model, sd = _model(d, di, k, 2, seed=k + 1)
+    good = O.synthetic_bag(1500, d, slide_idx=3).to(getattr(torch, xdt))
+    bad = good.clone()
+    bad[0, 700, 11] = 1.0e5
+    with torch.no_grad():
+        s0, b0, a0 = model(good.cuda())
+        assert model.range_fallbacks == 0
+        s1, b1, a1 = model(bad.cuda())
+        assert model.range_fallbacks == 1
+        f1 = model.forward_feature(bad.cuda())
+        assert model.range_fallbacks == 2
+        s2, b2, a2 = model(good.cuda())
+        assert model.range_fallbacks == 2
+    assert torch.equal(s0, s2) and torch.equal(a0, a2) and torch.equal(b0, b2)
+    ref = O.acmil_ga_forward(bad.float(), sd, n_token=k)
+    assert torch.isfinite(a1).all() and torch.isfinite(s1).all()
+    scale = ref["A_out"].abs().max().item()
+    assert (a1.cpu() - ref["A_out"]).abs().max().item() < 1e-5 * scale + TOL
+    assert (s1.cpu() - ref["sub_preds"]).abs().max().item() < 1e-3
+    assert (b1.cpu() - ref["slide_pred"]).abs().max().item() < 1e-3
+    assert (f1.cpu() - ref["bag_feat"]).abs().max().item() < 1e-3 * max(1.0, ref["bag_feat"].abs().max().item())
+    refg = O.acmil_ga_forward(good.float(), sd, n_token=k)
+    assert (a0.cpu() - refg["A_out"]).abs().max().item() < TOL
