@@ -37,6 +37,8 @@ SIGNATURES = {
     "acmil_ga_forward_guarded": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), _i, _vp, _vp] + [_i] * 5 + [C.POINTER(_vp)] + [_vp] * 4 +
                                  [_i, _vp, _vp, _vp]),
     "acmil_ga_forward_guarded_wide_scratch_bytes": (_sz, [_i] * 6),
+    "acmil_ga_rescore_fp32_cond_scratch_bytes": (_sz, [_i] * 4),
+    "acmil_ga_rescore_fp32_cond": (_i, [_vp, _i, _i, _vp, _vp] + [_i] * 6 + [_vp] * 6),
     "acmil_ga_forward_guarded_wide": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "acmil_ga_pool": (_i, [_vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _i] + [_vp] * 4 + [_i, _vp, _vp]),
     "acmil_stkim_workspace_bytes": (_sz, [_i] * 3),

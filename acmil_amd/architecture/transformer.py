@@ -237,7 +237,7 @@ class _GatedBase(nn.Module):
                 and self.attention.attention_weights.weight.shape[0] <= self.FUSED_MAX_TOKENS
                 and self.attention.attention_V[0].weight.shape[0] == 128)
 
-    def _score_pass(self, xb, packed, dims):
+    def _score_pass(self, xb, packed, dims, device_guard=False):
         """Raw scores A [K,N] and h [N,Di].  Fused widths: one kernel (GEMM chain in registers).  Other widths: the projection
         as a split-f16 MFMA GEMM with the ReLU epilogue (acmil_gemm_f16x3; network.py:49-57), then acmil_gated_scores
         (transformer.py:259-267) on h in HBM -- same arithmetic class, h makes one round trip."""
@@ -257,9 +257,12 @@ class _GatedBase(nn.Module):
                 return A, h
             self._bwd_dims = ops.GaDims(dims.D, dims.Di, dims.K, dims.C, dims.has_bag_head, mode=ops.mode_id("fp32"))
             return self._score_pass_composed(xb, dims, "fp32")
-        return self._score_pass_composed(xb, dims, "fp32" if self.precision == "fp32" else "f16x3")
+        return self._score_pass_composed(xb, dims, "fp32" if self.precision == "fp32" else "f16x3", packed if device_guard else None)
 
-    def _score_pass_composed(self, xb, dims, prec):
+    def _score_pass_composed(self, xb, dims, prec, guard_packed=None):
+        """guard_packed (eval forward only): the module's packed buffer -- the split-f16 range guard is then resolved ON THE DEVICE
+        (ops.ga_rescore_fp32_cond overwrites h and A with their exact-fp32 values iff the projection's status word is set) instead of
+        by a mid-forward read-back; a training step passes None: its backward has to know the arithmetic on the host."""
         base = self._raw_params()[0]
 
         status = None
@@ -275,6 +278,14 @@ class _GatedBase(nn.Module):
             return ops.gemm(x32, base[0].detach(), trans_b=True, act=1, precision=prec)
 
         h = project(prec)
+        if (prec == "f16x3" and self.range_guard and guard_packed is not None and status is not None and h.shape[1] % 16 == 0
+                and self.attention.attention_V[0].weight.shape[0] == 128):
+            pvu, bvu = self._packed_gate()
+            A = ops.gated_scores_packed(h, pvu, bvu, base[5], base[6])
+            w1 = base[0].detach()
+            ops.ga_rescore_fp32_cond(xb, guard_packed, w1 if w1.is_contiguous() else w1.contiguous(), dims, h, A, status,
+                                     self._fb_counter(xb.device))
+            return A, h
         if prec == "f16x3" and self.range_guard:
             # Same rule as the fused kernel's status word, on the same quantity: the projected features (a bag value outside the f16
             # range has an inf hi half and makes its patch's features inf / NaN, so the one test covers both).  The projection kernel
@@ -351,15 +362,16 @@ class _GatedBase(nn.Module):
                 return ops.ga_forward_guarded_wide(xb, packed, w1 if w1.is_contiguous() else w1.contiguous(), dims, self._fb_counter(xb.device),
                                                    want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
             return ops.ga_forward(xb, packed, dims, "f16x3", want_scores=want_scores, want_preds=want_preds, want_bag_feat=want_bag_feat)
-        out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False)
+        out = self._masked_forward(xb, packed, dims, None, want_bag_feat=want_bag_feat, masking=False, device_guard=True)
         out.pop("h", None)
         return out
 
-    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True):
-        """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward)."""
+    def _masked_forward(self, xb, packed, dims, uniforms, want_bag_feat=False, want_afeat=False, masking=True, device_guard=False):
+        """score pass (keeps h) -> STKIM selection -> masked pooling.  masking=False: no mask (plain training forward).
+        device_guard (eval forward of the composed path): no host read-back of the range status, see _score_pass_composed."""
         n = xb.shape[0]
         self._bwd_dims = dims
-        A, h = self._score_pass(xb, packed, dims)
+        A, h = self._score_pass(xb, packed, dims, device_guard=device_guard)
         k = min(self.n_masked_patch, n) if masking else 0
         m = int(k * self.mask_drop)
         topk = midx = None

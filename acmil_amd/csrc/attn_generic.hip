@@ -18,8 +18,12 @@ extern "C" size_t acmil_gemm_workspace_bytes(int M, int N, int K, int batch);
 template <int KP>
 __global__ __launch_bounds__(256) void ag_gate_scores_kernel(const float* __restrict__ G, int N, int Da, int K,
                                                              const float* __restrict__ Ww, const float* __restrict__ bw,
-                                                             float* __restrict__ A, const unsigned* __restrict__ cond = nullptr) {
-    if (cond && __builtin_nontemporal_load(cond) == 0u) return;      // predicated launch (exact-fp32 repeat of a flagged bag)
+                                                             float* __restrict__ A, const unsigned* __restrict__ cond = nullptr,
+                                                             unsigned* __restrict__ cond_count = nullptr) {
+    if (cond) {      // predicated launch (exact-fp32 repeat of a flagged bag); counted once per launch that ran
+        if (__builtin_nontemporal_load(cond) == 0u) return;
+        if (cond_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(cond_count, 1u);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     for (int n = wave; n < N; n += nwaves) {
@@ -96,22 +100,22 @@ extern "C" int acmil_gated_scores(const float* h, int N, int L, int Da, int K, c
     rc = gemm(0, 1, N, Da, L, 1.0f, h, L, 0, Wu, ACMIL_DTYPE_F32, L, 0, 0.0f, G + Da, 2 * Da, 0, bu, 0, nullptr, 1, gws, st);
     if (rc != ACMIL_OK) return rc;
     int blocks = (N + 3) / 4; if (blocks > 2048) blocks = 2048;
-    if (K == 1) hipLaunchKernelGGL(ag_gate_scores_kernel<1>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr);
-    else if (K <= 5) hipLaunchKernelGGL(ag_gate_scores_kernel<5>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr);
-    else hipLaunchKernelGGL(ag_gate_scores_kernel<ACMIL_MAX_TOKENS>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr);
+    if (K == 1) hipLaunchKernelGGL(ag_gate_scores_kernel<1>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr, (unsigned*)nullptr);
+    else if (K <= 5) hipLaunchKernelGGL(ag_gate_scores_kernel<5>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr, (unsigned*)nullptr);
+    else hipLaunchKernelGGL(ag_gate_scores_kernel<ACMIL_MAX_TOKENS>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, (const unsigned*)nullptr, (unsigned*)nullptr);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 
 // Exact-fp32 gated scores on the CONCATENATED attention weights, predicated on *cond (ga_forward.hip: the repeat of a flagged wide bag):
 // G = h wcat^T + bcat ([N, 2 Da], one fp32 MFMA GEMM), then the gate pass.  G: [N, 2 Da] scratch, gws: acmil_gemm_workspace_bytes(N, 2 Da, L, 1).
 int ag_gated_scores_cond(const float* h, int N, int L, int Da, int K, const float* wcat, const float* bcat, const float* Ww, const float* bw,
-                         float* A, float* G, void* gws, hipStream_t st, const unsigned* cond) {
+                         float* A, float* G, void* gws, hipStream_t st, const unsigned* cond, unsigned* cond_count) {
     int rc = gemm_f32_cond(0, 1, N, 2 * Da, L, 1.0f, h, L, wcat, ACMIL_DTYPE_F32, L, G, 2 * Da, bcat, 0, gws, st, cond);
     if (rc != ACMIL_OK) return rc;
     int blocks = (N + 3) / 4; if (blocks > 2048) blocks = 2048;
-    if (K == 1) hipLaunchKernelGGL(ag_gate_scores_kernel<1>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond);
-    else if (K <= 5) hipLaunchKernelGGL(ag_gate_scores_kernel<5>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond);
-    else hipLaunchKernelGGL(ag_gate_scores_kernel<ACMIL_MAX_TOKENS>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond);
+    if (K == 1) hipLaunchKernelGGL(ag_gate_scores_kernel<1>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond, cond_count);
+    else if (K <= 5) hipLaunchKernelGGL(ag_gate_scores_kernel<5>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond, cond_count);
+    else hipLaunchKernelGGL(ag_gate_scores_kernel<ACMIL_MAX_TOKENS>, dim3(blocks), dim3(256), 0, st, G, N, Da, K, Ww, bw, A, cond, cond_count);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 

@@ -415,6 +415,49 @@ extern "C" int acmil_ga_forward_guarded(int nbags, const void* const* xs, const 
                                  afeat, bag_feat, has_bag_head, workspace, stream, packed_fp32, fallback_count);
 }
 
+// The same predicated repeat for the COMPOSED path (D_inner = 768, n_token > 5: projection kernel -> gated scores -> pooling as separate
+// calls): after the split-f16 projection (whose launch left `cond`, its range status word) and the gated-score pass, this call OVERWRITES
+// h [N, Di] and A [K, N] with their exact-fp32 values if -- and only if -- *cond != 0; the caller's pooling / merge / heads then run on
+// whichever values are there.  Eval only: a training step must know on the host which arithmetic its backward has to use.
+extern "C" size_t acmil_ga_rescore_fp32_cond_scratch_bytes(int N, int D, int Di, int x_dtype) {
+    if (N <= 0 || D <= 0 || Di <= 0) return 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t g1 = acmil_gemm_workspace_bytes(N, Di, D, 1), g2 = acmil_gemm_workspace_bytes(N, 2 * GA_DA, Di, 1);
+    return (x_dtype == ACMIL_DTYPE_F32 ? 0 : al((size_t)N * D * 4)) + al((size_t)N * 2 * GA_DA * 4) + al(g1 > g2 ? g1 : g2);
+}
+
+extern "C" int acmil_ga_rescore_fp32_cond(const void* x, int x_dtype, int N, const void* packed, const float* W1, int D, int Di, int Da, int K,
+                                          int C, int mode, float* h, float* A, const unsigned* cond, unsigned* fallback_count, void* scratch,
+                                          void* stream) {
+    int rc0 = ga_check_dims(D, Di, Da, K, C);
+    if (rc0 != ACMIL_OK) return rc0;
+    if (N <= 0) return ACMIL_ERR_SHAPE;
+    if (!x || !packed || !W1 || !h || !A || !cond || !scratch) return ACMIL_ERR_NULL;
+    // the raw fp32 copies inside the packed buffer (ga_common.h: wcat = [Wv; Wu] [2 Da, Di], bcat, the Ww rows of the table, bw)
+    const GaLayout L = ga_layout(D, Di, K, C, mode);
+    const float* wcat = (const float*)((const char*)packed + L.wcat_off);
+    const float* bcat = (const float*)((const char*)packed + L.bcat_off);
+    const float* Ww = (const float*)((const char*)packed + L.tab_off) + 2 * GA_DA;
+    const float* bw = (const float*)((const char*)packed + L.bw_off);
+    if (((size_t)scratch & 255) != 0) return ACMIL_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    char* sc = (char*)scratch;
+    size_t off = 0;
+    const float* x32 = (const float*)x;
+    if (x_dtype != ACMIL_DTYPE_F32) {
+        hipLaunchKernelGGL(ga_widen_cond_kernel, dim3(1024), dim3(256), 0, st, x, x_dtype, (long long)N * D, (float*)sc, cond);
+        if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;
+        x32 = (const float*)sc;
+        off += al((size_t)N * D * 4);
+    }
+    float* G = (float*)(sc + off); off += al((size_t)N * 2 * Da * 4);
+    void* gws = sc + off;
+    int rc = gemm_f32_cond(0, 1, N, Di, D, 1.0f, x32, D, W1, ACMIL_DTYPE_F32, D, h, Di, nullptr, 1 /* relu */, gws, st, cond);
+    if (rc != ACMIL_OK) return rc;
+    return ag_gated_scores_cond(h, N, Di, Da, K, wcat, bcat, Ww, bw, A, G, gws, st, cond, fallback_count);
+}
+
 extern "C" size_t acmil_ga_forward_guarded_wide_scratch_bytes(int N, int D, int Di, int K, int x_dtype, int need_scores) {
     if (N <= 0 || D <= 0 || Di <= 0 || K <= 0) return 0;
     return ga_wide_scratch(N, D, Di, K, x_dtype, need_scores != 0).total;

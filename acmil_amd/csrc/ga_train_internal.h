@@ -22,7 +22,7 @@ int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* 
 
 // attn_generic.hip: exact-fp32 gated scores on the concatenated attention weights, predicated on *cond
 int ag_gated_scores_cond(const float* h, int N, int L, int Da, int K, const float* wcat, const float* bcat, const float* Ww, const float* bw,
-                         float* A, float* G, void* gws, hipStream_t st, const unsigned* cond);
+                         float* A, float* G, void* gws, hipStream_t st, const unsigned* cond, unsigned* cond_count = nullptr);
 
 // ga_backward.hip
 struct GbWs { size_t G, dpre, d_afeat, ck, stats, part, wcat, bcat, dwcat, gemm, gemm2, wg, total; };

@@ -265,6 +265,24 @@ def ga_forward_guarded_wide(x: torch.Tensor, packed: torch.Tensor, W1: torch.Ten
     return out
 
 
+def ga_rescore_fp32_cond(x: torch.Tensor, packed: torch.Tensor, W1: torch.Tensor, dims: GaDims, h: torch.Tensor, A: torch.Tensor,
+                         status: torch.Tensor, fallback_count: Optional[torch.Tensor] = None) -> None:
+    """acmil_ga_rescore_fp32_cond (composed path, eval): if the device word `status` (the range status a split-f16 projection launch
+    left) is non-zero, h [N, Di] and A [K, N] are overwritten IN PLACE with their exact-fp32 values; nothing happens otherwise.  No
+    host read-back: every launch of the repeat is predicated on the device."""
+    lib = _lib.load()
+    _check_x(x, dims)
+    _need_cuda(packed, W1, h, A, status, fallback_count)
+    N = x.shape[0]
+    if tuple(h.shape) != (N, dims.Di) or tuple(A.shape) != (dims.K, N) or not h.is_contiguous() or not A.is_contiguous():
+        raise RuntimeError("acmil_amd: h [N, D_inner] and A [K, N] of this bag, contiguous fp32")
+    nsc = lib.acmil_ga_rescore_fp32_cond_scratch_bytes(N, dims.D, dims.Di, _DT[x.dtype])
+    scratch = torch.empty(nsc, dtype=torch.uint8, device=x.device)
+    rc = lib.acmil_ga_rescore_fp32_cond(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), W1.data_ptr(), *dims.args(), dims.mode,
+                                        h.data_ptr(), A.data_ptr(), status.data_ptr(), _ptr(fallback_count), scratch.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_rescore_fp32_cond")
+
+
 def ga_scores(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, with_status: bool = False):
     """Score pass of a training step: raw scores A [K,N] and h [N,Di] (kept for pooling + backward);
     with_status: also the device view of the split-f16 range status (see _range_status)."""

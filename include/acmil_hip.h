@@ -153,6 +153,17 @@ int acmil_ga_forward_guarded_wide(const void* x, int x_dtype, int N, const void*
                                   int K, int C, float* A_out, float* sub_preds, float* slide_pred, float* afeat, float* bag_feat,
                                   int has_bag_head, unsigned* fallback_count, void* scratch, void* workspace, void* stream);
 
+/* The predicated repeat for the COMPOSED path (D_inner = 768, n_token > 5: acmil_linear_f16x3 -> acmil_gated_scores_packed -> acmil_ga_pool
+ * as separate calls; Step3_WSI_classification_ACMIL.py:78-87, :39): if -- and only if -- *cond != 0 (cond = the range status word the
+ * projection launch left in its workspace), h [N, Di] and A [K, N] are OVERWRITTEN with their exact-fp32 values (h = relu(x W1^T),
+ * A = gated scores on the raw fp32 copies of [Wv; Wu], [bv; bu], Ww, bw inside `packed` = acmil_ga_pack_weights(..., mode)); the caller's
+ * pooling / merge / heads then run on whichever values are there.  W1 [Di, D] raw fp32.  Eval forward only.  scratch: 256-byte aligned, acmil_ga_rescore_fp32_cond_scratch_bytes (Da = 128). */
+size_t acmil_ga_rescore_fp32_cond_scratch_bytes(int N, int D, int Di, int x_dtype);
+
+int acmil_ga_rescore_fp32_cond(const void* x, int x_dtype, int N, const void* packed, const float* W1, int D, int Di, int Da, int K, int C,
+                               int mode, float* h, float* A, const unsigned* cond, unsigned* fallback_count, void* scratch, void* stream);
+
+
 
 /* ---------------------------------------------------------------------------------------------
  * Masked pooling pass of a training step.  Replaces transformer.py:318-330 given the scores and h of the

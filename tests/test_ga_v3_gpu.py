@@ -297,3 +297,34 @@ def test_wide_device_side_guard_repeats_a_flagged_bag_in_fp32(d, di, k, xdt):
     assert (f1.cpu() - ref["bag_feat"]).abs().max().item() < 1e-3 * max(1.0, ref["bag_feat"].abs().max().item())
     refg = O.acmil_ga_forward(good.float(), sd, n_token=k)
     assert (a0.cpu() - refg["A_out"]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("d,di,k", [(1536, 768, 5), (512, 256, 8), (1024, 512, 10)])
+@pytest.mark.parametrize("xdt", ["float32", "bfloat16"])
+def test_composed_path_device_side_guard(d, di, k, xdt):
+    """The composed eval path (GigaPath width; n_token > 5 at any width) resolves its range guard on the device too
+    (acmil_ga_rescore_fp32_cond: h and A are overwritten with their exact-fp32 values iff the projection's status word is set, every
+    launch predicated): an in-range bag is untouched (same bits as with the guard switched off), a flagged one gets the fp32 result
+    and is counted once; no host synchronisation in either case."""
+    from oracle import ga_oracle as O
+    model, sd = _model(d, di, k, 2, seed=k)
+    assert not model._is_fused() and not model._is_wide_fused()
+    good = O.synthetic_bag(1300, d, slide_idx=8).to(getattr(torch, xdt))
+    bad = good.clone()
+    bad[0, 77, 3] = 1.0e5
+    with torch.no_grad():
+        s0, b0, a0 = model(good.cuda())
+        assert model.range_fallbacks == 0
+        s1, b1, a1 = model(bad.cuda())
+        assert model.range_fallbacks == 1
+        s2, b2, a2 = model(good.cuda())
+        model.range_guard = False
+        s3, b3, a3 = model(good.cuda())
+        model.range_guard = True
+    assert torch.equal(s0, s2) and torch.equal(a0, a2) and torch.equal(s0, s3) and torch.equal(a0, a3)
+    ref = O.acmil_ga_forward(bad.float(), sd, n_token=k)
+    assert torch.isfinite(a1).all() and torch.isfinite(s1).all()
+    assert (a1.cpu() - ref["A_out"]).abs().max().item() < 1e-5 * ref["A_out"].abs().max().item() + TOL
+    assert (s1.cpu() - ref["sub_preds"]).abs().max().item() < 1e-3 and (b1.cpu() - ref["slide_pred"]).abs().max().item() < 1e-3
+    refg = O.acmil_ga_forward(good.float(), sd, n_token=k)
+    assert (a0.cpu() - refg["A_out"]).abs().max().item() < TOL and (s0.cpu() - refg["sub_preds"]).abs().max().item() < TOL
