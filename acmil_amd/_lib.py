@@ -106,6 +106,10 @@ SIGNATURES = {
     "acmil_ga_train_step_rng": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
                             [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
                                 [C.c_ulonglong, C.c_ulonglong]),
+    "acmil_ga_train_step_adamw": (_i, [_vp, _i, _i, _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
+                                  [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
+                                  [C.c_ulonglong, C.c_ulonglong] +
+                                  [_vp, C.c_longlong, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong, _vp, _vp]),
 }
 
 _lib = None

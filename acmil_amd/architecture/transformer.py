@@ -215,6 +215,7 @@ class _GatedBase(nn.Module):
     def invalidate_packed(self):
         """Drop the packed-weight caches (for optimizers that update the parameters outside torch's version counters)."""
         self._pack_cache = None
+        self._step_pack_key = None
         self._w1_cache = None
         self._gate_cache = None
         self.__dict__.pop("_pack_cache_alt", None)
@@ -225,6 +226,8 @@ class _GatedBase(nn.Module):
     # 1024/512): fully fused in split-f16 arithmetic (csrc/ga_forward_kernel_v3.h, one 512-register wave per SIMD; round 5) -- eval
     # forward and the score pass of a training step.  Their fp32 mode, GigaPath (1536/768) and n_token > 5 take the composed path.
     FUSED_WIDE_D_INNER = (384, 512)
+
+    supports_in_step_optimizer = True      # train_step(optimizer=...): see there
 
     FUSED_MAX_TOKENS = 5      # n_token above (Step3_WSI_classification_ACMIL.py:39 takes any) runs the composed kernels, K <= 16
 
@@ -471,7 +474,7 @@ class ACMIL_GA(_GatedBase):
 
     @torch.no_grad()
     def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None, guard_flag: Optional[torch.Tensor] = None,
-                   precision: Optional[str] = None):
+                   precision: Optional[str] = None, optimizer=None, track_flag: bool = False):
         """One training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), the ACMIL loss and the HIP
         backward, writing the gradients into `p.grad` (allocated on first use, overwritten) -- ONE library call
         (acmil_ga_train_step) at the fused widths D_inner 128 / 256, the stand-alone kernels op by op at 384 / 512 / 768.
@@ -482,7 +485,12 @@ class ACMIL_GA(_GatedBase):
         synchronisation) and a flagged step is repeated in fp32 before it returns.  guard_flag (a device float, e.g.
         FlatAdamW.guard_flag): no read-back at all -- the step leaves 1.0 / 0.0 there for the optimizer launch to act on
         (it skips a flagged step; train.train_one_epoch repeats the bag in fp32 two steps later).  precision overrides the
-        module's arithmetic for this call ("fp32": the repeat)."""
+        module's arithmetic for this call ("fp32": the repeat).
+        optimizer (a FlatAdamW over exactly this module's parameters, single-GPU runs): where the one-call step can, it applies the
+        update ITSELF -- its last launch finishes the gradients, runs AdamW and re-packs the weights (acmil_ga_train_step_adamw: three
+        launches fewer per step) -- and the outputs carry `opt_step_id` (what optimizer.step(track_flag) would have returned); where it
+        cannot (fp32 arithmetic, no guard_flag, frozen parameters, a direct peer reduction, the wide / composed families),
+        `opt_step_id` is None and the caller steps the optimizer as before."""
         self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
@@ -494,7 +502,7 @@ class ACMIL_GA(_GatedBase):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
         if self._is_fused() and getattr(self, "fused_step", True):
-            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision)
+            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision, optimizer, track_flag)
         else:
             if precision is not None and precision != self.precision:
                 raise NotImplementedError("acmil_amd: per-call precision is a feature of the one-call step")
@@ -504,7 +512,7 @@ class ACMIL_GA(_GatedBase):
         self._last = out
         return losses, out
 
-    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None):
+    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None, optimizer=None, track_flag=False):
         """The whole step enqueued by one library call (csrc/ga_step.hip: 8 launches).  The packed weights are rebuilt inside
         the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
         after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
@@ -520,8 +528,29 @@ class ACMIL_GA(_GatedBase):
             if st is None:
                 packed, dims = self._packed(precision) if precision != self.precision else self._packed()
                 st = cache[(precision, dev)] = (packed.clone(), dims)      # a private buffer: the call rewrites it every step
-            return ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=True,
-                                     guard_flag=guard_flag, rng=self._step_rng)
+            in_step = (optimizer is not None and precision == "f16x3" and guard_flag is not None and not self.__dict__.get("_opt_in_step_refused")
+                       and getattr(optimizer, "can_run_in_step", lambda: False)())
+            if not in_step:
+                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=True,
+                                        guard_flag=guard_flag, rng=self._step_rng)
+                out["opt_step_id"] = None
+                return out
+            # the step's private packed buffer stays current as long as nothing but the in-step update touches the parameters
+            key = (precision, dev, id(optimizer), self._param_key(params))
+            valid = self.__dict__.get("_step_pack_key") == key + (optimizer.mutations,)
+            args = optimizer.in_step_args(track_flag)
+            try:
+                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
+                                        guard_flag=guard_flag, rng=self._step_rng, adamw=args)
+            except RuntimeError as e:
+                optimizer.in_step_abort()
+                if "(-2)" not in str(e) and "(-1)" not in str(e):     # anything but "unsupported" / "shape": a real failure
+                    raise
+                self._opt_in_step_refused = True                       # e.g. parameters not 16-byte aligned in the flat buffer: nothing was launched
+                return run(precision)
+            out["opt_step_id"] = optimizer.in_step_done()             # (calls invalidate_packed through on_step: the eval caches are stale now)
+            self._step_pack_key = key + (optimizer.mutations,)
+            return out
 
         prec = precision or self.precision
         out = run(prec)

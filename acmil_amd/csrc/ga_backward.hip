@@ -257,7 +257,7 @@ extern "C" size_t acmil_ga_backward_workspace_bytes(int N, int D, int Di, int K,
 // ACMIL_GA_BWD_TILE=0 keeps launches 3-5 separate (A/B measurements); read once
 static bool gb_use_tile() { static const bool v = [] { const char* e = ACMIL_AB_ENV("ACMIL_GA_BWD_TILE"); return !(e && e[0] == '0'); }(); return v; }
 
-int gb_run(const GbRun& r) {
+int gb_run(const GbRun& r, GbDefer* defer) {
     const int N = r.N, D = r.D, Di = r.Di, K = r.K;
     if (Di != 128 && Di != 256 && Di != 384 && Di != 512 && Di != 768) return ACMIL_ERR_UNSUPPORTED;   // gate pass instances (FPL = Di/64)
     const int x_fwd = (r.mode == ACMIL_MODE_F32) ? 0 : 1, x_grad = (r.mode == ACMIL_MODE_F32) ? 0 : 2;
@@ -347,8 +347,11 @@ int gb_run(const GbRun& r) {
     job.off[1] = KP * GA_DA;                 job.cnt[1] = K;         job.dst[1] = r.dbw;
     job.off[2] = KP * GA_DA + KP;            job.cnt[2] = GA_DA;     job.dst[2] = r.dbv;
     job.off[3] = KP * GA_DA + KP + GA_DA;    job.cnt[3] = GA_DA;     job.dst[3] = r.dbu;
-    rc = gemm_finish(&g1, &g2, &job, st);
-    if (rc != ACMIL_OK) return rc;
+    if (defer) { defer->g_vu = g1; defer->g_w1 = g2; defer->job = job; }
+    else {
+        rc = gemm_finish(&g1, &g2, &job, st);
+        if (rc != ACMIL_OK) return rc;
+    }
     if (!g_adj && g1.splits <= 1) {
         hipLaunchKernelGGL(gb_split_kernel, dim3(64), dim3(256), 0, st, (const float*)(ws + L.dwcat), GA_DA * Di, r.dWv, r.dWu);
         if (hipGetLastError() != hipSuccess) return ACMIL_ERR_LAUNCH;

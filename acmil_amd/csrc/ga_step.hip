@@ -400,17 +400,23 @@ extern "C" size_t acmil_ga_train_step_workspace_bytes(int N, int D, int Di, int 
     return gs_layout(N, D, Di, K, C, k_top).total;
 }
 
-extern "C" int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* packed, int repack,
-                                   const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
-                                   const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
-                                   const float* Ws, const float* bs,
-                                   float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
-                                   float* const* dWc, float* const* dbc, float* dWs, float* dbs,
-                                   int D, int Di, int Da, int K, int C, int mode,
-                                   const int64_t* label, const float* uniforms, int k_top, int m_mask,
-                                   float* losses, float* sub_preds, float* slide_pred, float* A_out,
-                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
-                                       unsigned long long rng_seed, unsigned long long rng_offset) {
+// the optimizer inside the step (acmil_ga_train_step_adamw), or null: the caller's own launch follows
+struct GsOpt {
+    const float* flat; long long n_flat; float *exp_avg, *exp_avg_sq;
+    float lr; double beta1, beta2; float eps, wd; long long step; int* skipped; float* flag_report;
+};
+
+static int gs_step(const void* x, int x_dtype, int N, void* packed, int repack,
+                   const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                   const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                   const float* Ws, const float* bs,
+                   float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                   float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                   int D, int Di, int Da, int K, int C, int mode,
+                   const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                   float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                   unsigned long long rng_seed, unsigned long long rng_offset, const GsOpt* opt) {
     int rc = ga_check_dims(D, Di, Da, K, C);
     if (rc != ACMIL_OK) return rc;
     if (K > GS_MAXK) return ACMIL_ERR_UNSUPPORTED;       // the one-call step exists for the fused families (K <= 5); K above: op by op
@@ -424,6 +430,18 @@ extern "C" int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* 
     for (int k = 0; k < K; ++k)
         if (!Wc[k] || !bc[k] || !dWc[k] || !dbc[k]) return ACMIL_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
+    // the optimizer inside the step: everything that can refuse does so BEFORE the first launch
+    GoTensors gt;
+    if (opt) {
+        memset(&gt, 0, sizeof(gt));
+        gt.W1 = (float*)W1; gt.Wv = (float*)Wv; gt.bv = (float*)bv; gt.Wu = (float*)Wu; gt.bu = (float*)bu; gt.Ww = (float*)Ww; gt.bw = (float*)bw;
+        gt.Ws = (float*)Ws; gt.bs = (float*)bs;
+        gt.dW1 = dW1; gt.dWv = dWv; gt.dbv = dbv; gt.dWu = dWu; gt.dbu = dbu; gt.dWw = dWw; gt.dbw = dbw; gt.dWs = dWs; gt.dbs = dbs;
+        for (int k = 0; k < K; ++k) { gt.Wc[k] = (float*)Wc[k]; gt.bc[k] = (float*)bc[k]; gt.dWc[k] = dWc[k]; gt.dbc[k] = dbc[k]; }
+        if (opt->step < 1 || !(opt->beta1 >= 0.0 && opt->beta1 < 1.0) || !(opt->beta2 >= 0.0 && opt->beta2 < 1.0)) return ACMIL_ERR_SHAPE;
+        rc = go_check(gt, D, Di, K, C, mode, opt->flat, opt->n_flat, opt->exp_avg, opt->exp_avg_sq);
+        if (rc != ACMIL_OK) return rc;
+    }
     char* ws = (char*)workspace;
     const GsWs W = gs_layout(N, D, Di, K, C, k_top);
     unsigned* ctrl = (unsigned*)ws;
@@ -478,7 +496,57 @@ extern "C" int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* 
     r.dA_ext = nullptr; r.coef = (K > 1) ? coef : nullptr; r.d_afeat = t.d_afeat; r.ck = t.ck; r.stats = t.stats;
     r.dW1 = dW1; r.dWv = dWv; r.dbv = dbv; r.dWu = dWu; r.dbu = dbu; r.dWw = dWw; r.dbw = dbw;
     r.D = D; r.Di = Di; r.K = K; r.mode = mode; r.ws = bws; r.st = st;
-    return gb_run(r);
+    if (!opt) return gb_run(r);
+    // 8 (instead of 8, 9 and the next step's 1): finish + AdamW + re-pack of what the update changed, one launch (ga_opt_step.hip)
+    GbDefer df;
+    rc = gb_run(r, &df);
+    if (rc != ACMIL_OK) return rc;
+    return go_launch(gt, df.g_vu, df.g_w1, df.job, KP, packed, t.L, opt->flat, opt->exp_avg, opt->exp_avg_sq, opt->lr, opt->beta1, opt->beta2,
+                     opt->eps, opt->wd, opt->step, guard_flag, opt->skipped, opt->flag_report, st);
+}
+
+extern "C" int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* packed, int repack,
+                                   const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu,
+                                   const float* Ww, const float* bw, const float* const* Wc, const float* const* bc,
+                                   const float* Ws, const float* bs,
+                                   float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                                   float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                                   int D, int Di, int Da, int K, int C, int mode,
+                                   const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                                   float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                                   int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                                       unsigned long long rng_seed, unsigned long long rng_offset) {
+    return gs_step(x, x_dtype, N, packed, repack, W1, Wv, bv, Wu, bu, Ww, bw, Wc, bc, Ws, bs, dW1, dWv, dbv, dWu, dbu, dWw, dbw, dWc, dbc, dWs,
+                   dbs, D, Di, Da, K, C, mode, label, uniforms, k_top, m_mask, losses, sub_preds, slide_pred, A_out, topk_idx, masked_idx,
+                   guard_flag, workspace, stream, rng_seed, rng_offset, nullptr);
+}
+
+// One training step INCLUDING torch.optim.AdamW's update (Step3_WSI_classification_ACMIL.py:200-219 with :139's optimizer) for a
+// single-GPU run: the step's last launch finishes the weight gradients, applies AdamW to every parameter (moments at the same
+// offsets of exp_avg / exp_avg_sq as the parameters have in flat_params; skipped on the device when the step's range flag is set, as
+// acmil_adamw_step_report does) and rewrites `packed` for the updated values -- so the NEXT call passes repack = 0 unless something
+// else changed the parameters.  Gradients are left in the gradient tensors as acmil_ga_train_step leaves them.  Results are
+// bit-identical to acmil_ga_train_step_rng + acmil_adamw_step_report + acmil_ga_pack_weights.  ACMIL_ERR_UNSUPPORTED (nothing was
+// launched): mode != f16x3, or the parameters are not 16-byte aligned inside the flat buffer; ACMIL_ERR_SHAPE: the parameters do
+// not cover flat_params exactly.
+extern "C" int acmil_ga_train_step_adamw(const void* x, int x_dtype, int N, void* packed, int repack,
+                                     float* W1, float* Wv, float* bv, float* Wu, float* bu, float* Ww, float* bw, float* const* Wc,
+                                     float* const* bc, float* Ws, float* bs,
+                                     float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                                     float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                                     int D, int Di, int Da, int K, int C, int mode,
+                                     const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                                     float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                                     int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                                     unsigned long long rng_seed, unsigned long long rng_offset,
+                                     const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
+                                     double beta2, float eps, float weight_decay, long long step, int* skipped, float* flag_report) {
+    GsOpt o;
+    o.flat = flat_params; o.n_flat = n_flat; o.exp_avg = exp_avg; o.exp_avg_sq = exp_avg_sq; o.lr = lr; o.beta1 = beta1; o.beta2 = beta2;
+    o.eps = eps; o.wd = weight_decay; o.step = step; o.skipped = skipped; o.flag_report = flag_report;
+    return gs_step(x, x_dtype, N, packed, repack, W1, Wv, bv, Wu, bu, Ww, bw, (const float* const*)Wc, (const float* const*)bc, Ws, bs, dW1, dWv,
+                   dbv, dWu, dbu, dWw, dbw, dWc, dbc, dWs, dbs, D, Di, Da, K, C, mode, label, uniforms, k_top, m_mask, losses, sub_preds,
+                   slide_pred, A_out, topk_idx, masked_idx, guard_flag, workspace, stream, rng_seed, rng_offset, &o);
 }
 
 extern "C" int acmil_ga_train_step(const void* x, int x_dtype, int N, void* packed, int repack,

@@ -42,7 +42,21 @@ struct GbRun {
     char* ws;                // acmil_ga_backward_workspace_bytes
     hipStream_t st;
 };
-int gb_run(const GbRun& r);
+// defer (or null): the finishing launch is left to the caller, who receives what it would have worked on -- the training step with
+// the optimizer inside (ga_step.hip) closes with ONE launch for finish + AdamW + re-pack (ga_opt_step.hip)
+struct GbDefer { GemmArgs g_vu, g_w1; RowSumJob job; };
+int gb_run(const GbRun& r, GbDefer* defer = nullptr);
+
+// ga_opt_step.hip: split-K finish + AdamW + weight re-pack of a single-GPU training step in one launch
+struct GoTensors {
+    float *W1, *Wv, *bv, *Wu, *bu, *Ww, *bw, *Ws, *bs; float* Wc[ACMIL_MAX_TOKENS_FUSED]; float* bc[ACMIL_MAX_TOKENS_FUSED];
+    float *dW1, *dWv, *dbv, *dWu, *dbu, *dWw, *dbw, *dWs, *dbs; float* dWc[ACMIL_MAX_TOKENS_FUSED]; float* dbc[ACMIL_MAX_TOKENS_FUSED];
+};
+int go_check(const GoTensors& t, int D, int Di, int K, int C, int mode, const float* flat, long long n_flat, const float* exp_avg,
+             const float* exp_avg_sq);
+int go_launch(const GoTensors& t, const GemmArgs& g_vu, const GemmArgs& g_w1, const RowSumJob& job, int KP, void* packed, const GaLayout& L,
+              const float* flat, const float* exp_avg, const float* exp_avg_sq, float lr, double beta1, double beta2, float eps, float wd,
+              long long step, const float* skip_flag, int* skipped, float* flag_report, hipStream_t st);
 
 // wgrad.hip: both weight-gradient products (contraction over the patches) in one launch; *_bytes == 0 / ACMIL_ERR_UNSUPPORTED
 // when the shapes do not fit its 128 x 128 tiles or the bag is tiny (callers then use the generic GEMM)

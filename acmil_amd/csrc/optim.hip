@@ -5,6 +5,7 @@
 //   p *= 1 - lr * wd ;  m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
 // with bc1 = 1 - b1^t, bc2 = 1 - b2^t formed on the device in double (t = the caller's launch ordinal minus the skipped launches).
 #include "ga_common.h"
+#include "optim_kernel.h"
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long long n, float lr, double beta1, double beta2, float eps,
@@ -24,19 +25,15 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     }
     if (threadIdx.x == 0) {
         const long long t = launch - (skipped ? (long long)*skipped : 0);
-        s_bc[0] = (float)(1.0 / (1.0 - pow(beta1, (double)t)));
-        s_bc[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+        adamw_bias(beta1, beta2, t, s_bc[0], s_bc[1]);
     }
     __syncthreads();
     const float inv_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
     const float b1 = (float)beta1, b2 = (float)beta2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float gi = g[i];
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float pi = p[i] * (1.0f - lr * wd);
-        p[i] = pi - (lr * inv_bc1) * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_update(pi, g[i], mi, vi, lr, wd, inv_bc1, inv_sqrt_bc2, eps, b1, b2);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 

@@ -12,6 +12,7 @@
 // seen every peer's flag of step t, i.e. every peer has finished reading the slots of step t-1.
 // torch.distributed / RCCL stays the fallback and the default (acmil_amd/peer.py decides); the mapping is torch's CUDA IPC.
 #include "ga_common.h"
+#include "optim_kernel.h"
 
 #define PEER_MAX 8      // ranks of one node
 
@@ -78,8 +79,7 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
     if (skip && skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
     if (threadIdx.x == 0) {
         const long long t = launch - (skipped ? (long long)*skipped : 0);      // (only used by launches that are applied)
-        s_bc[0] = (float)(1.0 / (1.0 - pow(beta1, (double)t)));
-        s_bc[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, (double)t)));
+        adamw_bias(beta1, beta2, t, s_bc[0], s_bc[1]);
     }
     __syncthreads();
     const float inv_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
@@ -90,11 +90,9 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
         gi = gi / (float)world;
         if (reduced_out) reduced_out[i] = gi;
         if (skip) continue;
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        const float pi = p[i] * (1.0f - lr * wd);
-        p[i] = pi - (lr * inv_bc1) * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_update(pi, gi, mi, vi, lr, wd, inv_bc1, inv_sqrt_bc2, eps, b1, b2);      // (optim_kernel.h: the flat launch's arithmetic, bit for bit)
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
 

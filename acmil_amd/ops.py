@@ -425,8 +425,12 @@ _TRAIN_STEP_CHECKED_MAX = 8
 
 def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
                   grads: Sequence[torch.Tensor], label: torch.Tensor, uniforms: Optional[torch.Tensor], k_top: int, m_mask: int,
-                  repack: bool = True, guard_flag: Optional[torch.Tensor] = None, rng: Optional[Tuple[int, int]] = None):
+                  repack: bool = True, guard_flag: Optional[torch.Tensor] = None, rng: Optional[Tuple[int, int]] = None,
+                  adamw: Optional[tuple] = None):
     """acmil_ga_train_step: forward with STKIM masking + ACMIL loss + backward of one slide, enqueued by ONE library call.
+    adamw (single-GPU runs): (flat_params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, skipped_dev, flag_report_ptr)
+    of a FlatAdamW -- the call then goes to acmil_ga_train_step_adamw, whose last launch finishes the gradients, applies the update
+    and rewrites `packed` for the new values (so the next call may pass repack=False).
     params / grads = [W1, Wv, bv, Wu, bu, Ww, bw, Wc_0.., bc_0.., (Ws, bs)] (gradients are overwritten).
     Returns a dict: losses [4] (loss0, loss1, diff, total), sub_preds [K,C], slide_pred [C] or None, A_out [K,N] (masked raw
     scores), topk_idx, masked_idx, range_status (device int32 view, see _range_status).
@@ -477,7 +481,7 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
     ws = _ws_bytes(lib.acmil_ga_train_step_workspace_bytes(N, dims.D, dims.Di, K, Cc, k_top), dev)
     vpK = ctypes.c_void_p * K
     has_bag = dims.has_bag_head
-    rc = lib.acmil_ga_train_step_rng(
+    common = (
         x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), int(repack),
         *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
         *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
@@ -485,7 +489,14 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
         losses.data_ptr(), sub.data_ptr(), slide.data_ptr() if has_bag else None, A.data_ptr(),
         topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, _ptr(guard_flag), ws.data_ptr(), _stream(),
         seed & (2 ** 64 - 1), offset & (2 ** 64 - 1))
-    _lib.check(rc, "acmil_ga_train_step_rng")
+    if adamw is None:
+        rc = lib.acmil_ga_train_step_rng(*common)
+        _lib.check(rc, "acmil_ga_train_step_rng")
+    else:
+        flat, m1, m2, lr, b1, b2, eps, wd, step, skipped, report = adamw
+        rc = lib.acmil_ga_train_step_adamw(*common, flat.data_ptr(), flat.numel(), m1.data_ptr(), m2.data_ptr(), float(lr), float(b1),
+                                           float(b2), float(eps), float(wd), int(step), skipped.data_ptr(), report)
+        _lib.check(rc, "acmil_ga_train_step_adamw")
     return {"losses": losses, "sub_preds": sub, "slide_pred": slide if has_bag else None, "A_out": A,
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 

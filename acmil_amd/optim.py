@@ -62,6 +62,8 @@ class FlatAdamW:
         if peer is not None:
             peer.owner = self      # tells train.GradBucket.allreduce_mean that the reduction now happens inside this optimizer's launch
         self._frozen = []          # (offset, numel) ranges that receive no gradient this run: skipped like torch skips grad=None
+        self.mutations = 0         # counts every change this object makes to the parameters (owners of derived buffers compare it)
+        self._in_step = None
 
     def set_frozen(self, params: Iterable[torch.nn.Parameter]):
         """Parameters that never receive a gradient (e.g. the branch head of an n_token = 1 ACMIL model, whose loss term is not
@@ -76,6 +78,46 @@ class FlatAdamW:
 
     def zero_grad(self, set_to_none: bool = False):
         self.grad.zero_()
+
+    # ---- the update issued INSIDE the training step's own library call (acmil_ga_train_step_adamw: the step's last launch finishes
+    # the gradients, applies AdamW and re-packs the weights).  Single-GPU runs only: a data-parallel reduction sits between the
+    # gradients and the update.  Protocol: in_step_args() -> the call -> in_step_done() (or in_step_abort() if the call refused).
+    def can_run_in_step(self) -> bool:
+        return self.peer is None and not self._frozen and self.guard_flag is not None
+
+    def in_step_args(self, track_flag: bool = False) -> tuple:
+        g = self.param_groups[0]
+        if self._in_step is not None:
+            raise RuntimeError("acmil_amd.FlatAdamW: in_step_args() without in_step_done()")
+        track = bool(track_flag)
+        if track and len(self._pending) >= 12:
+            raise RuntimeError("acmil_amd.FlatAdamW: poll_skipped() must be called while steps are tracked")
+        self.step_count += 1
+        self._step_id += 1
+        self._launches += 1
+        slot = self._step_id % 16
+        self._in_step = (track, slot)
+        b1, b2 = g["betas"]
+        return (self.flat, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                self._launches, self._skipped_dev, self._host_flags.data_ptr() + 4 * slot if track else None)
+
+    def in_step_abort(self):
+        self._in_step = None
+        self.step_count -= 1
+        self._step_id -= 1
+        self._launches -= 1
+
+    def in_step_done(self) -> int:
+        track, slot = self._in_step
+        self._in_step = None
+        self.mutations += 1
+        if self.on_step is not None:
+            self.on_step()
+        if track:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending.append((self._step_id, ev, slot))
+        return self._step_id
 
     @torch.no_grad()
     def step(self, track_flag: bool = False) -> int:
@@ -101,6 +143,7 @@ class FlatAdamW:
             self._plain_launch(lib, g, b1, b2, track, slot)
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
+        self.mutations += 1
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
             self.on_step()
         if track:
@@ -214,6 +257,7 @@ class FlatAdamW:
     def load_state_dict(self, sd):
         """Accepts torch.optim.AdamW's layout (also one written by the reference) or this class's earlier flat layout."""
         self._pending.clear()      # flags of steps taken before the load belong to the discarded state
+        self.mutations += 1
         self.skipped_steps = 0
         if "state" in sd:
             off, steps = 0, []

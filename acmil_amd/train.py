@@ -247,6 +247,7 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     lagged = (use_fused and getattr(optimizer, "guard_flag", None) is not None and getattr(model, "range_guard", False)
               and getattr(model, "precision", "") == "f16x3")
     recent: Dict[int, tuple] = {}
+    in_step = lagged and world == 1 and hasattr(optimizer, "in_step_args") and getattr(model, "supports_in_step_optimizer", False)
 
     def reduce_and_step(track):
         if bucket is not None:
@@ -275,8 +276,12 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
         x = item["input"]                                      # fp16 stays fp16: converted inside the kernel
         labels = label_dev[item["label"]:item["label"] + 1]
         adjust_learning_rate(optimizer, epoch + it / len(order), conf)
+        sid = None
         if use_fused:
-            losses, _ = model.train_step(x.unsqueeze(0), labels, guard_flag=optimizer.guard_flag if lagged else None)
+            # single GPU: the step applies the optimizer itself (its closing launch = gradient finish + AdamW + weight re-pack) where it can
+            losses, out = model.train_step(x.unsqueeze(0), labels, guard_flag=optimizer.guard_flag if lagged else None,
+                                           **({"optimizer": optimizer, "track_flag": True} if in_step else {}))
+            sid = out.get("opt_step_id") if in_step else None
             if not lagged:
                 acc += losses
         else:
@@ -291,7 +296,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
             optimizer.zero_grad(set_to_none=False)
             loss.backward()
             acc += torch.stack([loss0.detach(), loss1.detach(), diff_loss.detach(), loss.detach()])
-        sid = reduce_and_step(lagged)
+        if sid is None:
+            sid = reduce_and_step(lagged)
         if lagged:
             recent[sid] = (item["index"], losses)
             settle(2)

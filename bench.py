@@ -313,10 +313,14 @@ def other_workloads(args, ctx):
 
     def make_step(bucket, opt):
         def step(i):      # as train.train_one_epoch: range flag left on the device, looked at two steps late (no host read-back per step)
-            model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag)
-            bucket.sync_from_grads()
-            bucket.allreduce_mean(world)
-            opt.step(track_flag=True)
+            # one GPU: the step applies AdamW itself -- its closing launch finishes the gradients, updates and re-packs (7 launches per
+            # step); data parallel: the bucket all-reduce sits between the gradients and the optimizer's own launch (9 launches + RCCL)
+            _, out = model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag,
+                                      **({"optimizer": opt, "track_flag": True} if world == 1 and not args.train_separate_opt else {}))
+            if out.get("opt_step_id") is None:
+                bucket.sync_from_grads()
+                bucket.allreduce_mean(world)
+                opt.step(track_flag=True)
             if opt.poll_skipped(2):
                 raise SystemExit("bench: a synthetic bag left the split-f16 range")
         return step
@@ -392,7 +396,8 @@ def other_workloads(args, ctx):
         "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
                                "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,
                    "sharding": "slide-level data parallel: one bag per rank, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)"},
-        "roofline": {"kernel": "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
+        "roofline": {"kernel": "whole step (7 launches: acmil_ga_train_step_adamw, optimizer and weight re-pack in the closing launch)" if world == 1 and not args.train_separate_opt
+                     else "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
                      "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
                      "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4),
                      # PMC summaries of the step: tools/pmc_ga.py --workload train --whole-step with --batch 1 (N = 10 000) / --batch 50
@@ -553,6 +558,8 @@ def main(argv=None):
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload only: skip the nested `secondary` lines (configs[2], [3], [4])")
+    ap.add_argument("--train-separate-opt", action="store_true",
+                    help="train workload on one GPU: keep the optimizer as its own launch (the data-parallel launch sequence) -- A/B of the in-step optimizer")
     ap.add_argument("--direct-leg", action="store_true", help=argparse.SUPPRESS)      # child mode of the train workload (direct gradient reduction)
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check on CPU with gloo: no GPU, no compute, no metric value")

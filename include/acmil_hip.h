@@ -291,6 +291,33 @@ int acmil_ga_train_step_rng(const void* x, int x_dtype, int N, void* packed, int
                         int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
                             unsigned long long rng_seed, unsigned long long rng_offset);
 
+/* One training step INCLUDING the optimizer, for a single-GPU run: acmil_ga_train_step_rng + torch.optim.AdamW's update
+ * (Step3_WSI_classification_ACMIL.py:139 builds it, :219 steps it once per slide) + the re-pack of the updated weights, with the
+ * step's LAST launch doing all three closing jobs at once (split-K finish of the weight gradients, AdamW on every parameter, the
+ * new values written to every place of `packed` that holds them).  Replaces three launches at the end of a step and the pack
+ * launch at the start of the next one; results (gradients, parameters, moments, packed buffer) are bit-identical to
+ * acmil_ga_train_step_rng -> acmil_adamw_step_report -> acmil_ga_pack_weights.
+ *   W1 .. bs        the parameters, NOT const here: views of one flat fp32 buffer flat_params [n_flat] that they cover exactly
+ *   exp_avg, exp_avg_sq [n_flat]  AdamW moments, element i belongs to flat_params[i]
+ *   lr .. weight_decay, step, skipped, flag_report   as acmil_adamw_step_report; the skip flag is guard_flag (NULL: never skipped)
+ *   repack          1: `packed` is rebuilt first (first step, or the parameters were changed by anything but this entry)
+ * A skipped step (range flag set) leaves parameters, moments and `packed` untouched.
+ * Returns ACMIL_ERR_UNSUPPORTED before anything is launched when mode != ACMIL_MODE_F16X3 or W1 / Wv / Wu (their gradients,
+ * their moments) are not 16-byte aligned; ACMIL_ERR_SHAPE when the parameters do not tile flat_params.  Data-parallel runs keep
+ * the separate entries (their all-reduce sits between the gradients and the update). */
+int acmil_ga_train_step_adamw(const void* x, int x_dtype, int N, void* packed, int repack,
+                        float* W1, float* Wv, float* bv, float* Wu, float* bu, float* Ww, float* bw, float* const* Wc,
+                        float* const* bc, float* Ws, float* bs,
+                        float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                        float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                        int D, int Di, int Da, int K, int C, int mode,
+                        const int64_t* label, const float* uniforms, int k_top, int m_mask,
+                        float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                        int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                        unsigned long long rng_seed, unsigned long long rng_offset,
+                        const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
+                        double beta2, float eps, float weight_decay, long long step, int* skipped, float* flag_report);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216
  * (loss0 = CE(sub_preds, label x K) [0 if K == 1], loss1 = CE(slide_pred, label), diff_loss = mean pairwise cosine

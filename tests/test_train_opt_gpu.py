@@ -1,0 +1,191 @@
+"""The training step with the optimizer inside (acmil_ga_train_step_adamw, csrc/ga_opt_step.hip): its closing launch -- split-K finish
+of the weight gradients + AdamW + re-pack of the updated weights -- against the sequence it replaces (acmil_ga_train_step_rng ->
+acmil_adamw_step_report -> acmil_ga_pack_weights), BIT FOR BIT: gradients, parameters, moments, losses, and the packed buffer the next
+step reads.  The loop is Step3_WSI_classification_ACMIL.py:189-227 (forward, three losses, backward, optimizer.step())."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(D=512, Di=256, K=5, C=7, n_mask=10, seed=3):
+    from acmil_amd import train as T
+    conf = T.Struct(train_epoch=3, warmup_epoch=0, wd=1e-2, lr=1e-3, min_lr=0, n_class=C, n_token=K, n_masked_patch=n_mask,
+                    mask_drop=0.6, arch="ga", precision="f16x3", seed=1, D_feat=D, D_inner=Di)
+    dev = torch.device("cuda", 0)
+    T.set_seed(seed)
+    model = T.build_model(conf).to(dev).train()
+    bucket = T.GradBucket(list(model.parameters()))
+    opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)
+    return T, conf, dev, model, bucket, opt
+
+
+def _bags(n, N, D, seed=0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(N + 37 * i, D, generator=g) * 0.5).to(dtype) for i in range(n)]
+
+
+def _frag_off(row, k, nks, plane):
+    return ((((row >> 5) * nks + (k >> 4)) * 2 + plane) * 64 + ((k >> 3) & 1) * 32 + (row & 31)) * 8 + (k & 7)
+
+
+def _layout(D, Di, K, C):
+    """Byte ranges the pack kernel defines in the f16x3 packed buffer, the offset of wT16 and the total (csrc/ga_common.h ga_layout,
+    restated; the gaps are alignment padding nobody writes)."""
+    ND, off, regions = Di // 32, 0, []
+
+    def take(n, pad_to=None):
+        nonlocal off
+        regions.append((off, n))
+        off += n if pad_to is None else pad_to
+    take((D // 64) * 8 * ND * 1024 + ND * 32 * 1024)
+    take((2 + K) * 128 * 4)
+    take(16 * 4)
+    take(K * C * Di * 4)
+    take(K * C * 4, ((K * C + 3) // 4) * 16)
+    take(C * Di * 4)
+    take(C * 4, ((C + 3) // 4) * 16)
+    off = (off + 255) & ~255
+    take(2 * 128 * Di * 4 + 2 * 128 * 4 + 2 * 128 * Di * 4 + 2 * 2 * 128 * Di * 2)
+    wT = off
+    take(2 * Di * 288 * 2)
+    return regions, wT, (off + 255) & ~255
+
+
+def _packed_equal_where_the_pack_kernel_writes(model, dev):
+    """The step's private packed buffer (maintained by the closing launch) against a fresh acmil_ga_pack_weights of the current
+    parameters, byte for byte -- except the d_afeat columns of the backward tile kernel's operand, which the step's tail kernel owns."""
+    (kept, dims), = [v for k, v in model._step_packed.items() if k[0] == "f16x3"]
+    fresh, _ = model._pack_now("f16x3")
+    a = kept.view(torch.uint8).cpu().numpy()
+    b = fresh.view(torch.uint8).cpu().numpy()
+    regions, off, total = _layout(dims.D, dims.Di, dims.K, dims.C)
+    assert a.shape == b.shape == (total,)
+    m = np.zeros(total, dtype=bool)
+    for o, n in regions:
+        m[o:o + n] = True
+    rows = np.arange(dims.Di)[:, None]
+    cols = np.arange(256, 288)[None, :]
+    for plane in (0, 1):
+        idx = (off + 2 * _frag_off(rows, cols, 18, plane)).ravel()
+        m[idx] = False
+        m[idx + 1] = False
+    bad = np.nonzero((a != b) & m)[0]
+    assert bad.size == 0, "packed buffer of the in-step optimizer differs from a fresh pack at %d bytes, first at byte %d" % (bad.size, bad[0])
+
+
+@pytest.mark.parametrize("D,Di,K,C,N", [(512, 256, 5, 7, 3000), (384, 128, 5, 2, 1500), (512, 256, 1, 2, 900), (512, 256, 3, 4, 700)])
+def test_in_step_optimizer_is_bit_identical_to_the_three_launch_sequence(D, Di, K, C, N):
+    T, conf, dev, ref_model, ref_bucket, ref_opt = _setup(D, Di, K, C)
+    _, _, _, model, bucket, opt = _setup(D, Di, K, C)
+    model.load_state_dict(ref_model.state_dict())
+    if not opt.can_run_in_step():
+        pytest.skip("n_token = 1 freezes the branch head (torch skips grad=None parameters): the in-step path is not taken")
+    bags = _bags(4, N, D)
+    for i, x in enumerate(bags):
+        y = torch.tensor([i % C], device=dev)
+        xb = x.to(dev).unsqueeze(0)
+        for g in ref_opt.param_groups + opt.param_groups:
+            g["lr"] = 1e-3 * (1.0 + 0.25 * i)
+        l_ref, o_ref = ref_model.train_step(xb, y, guard_flag=ref_opt.guard_flag)
+        sid_ref = ref_opt.step(track_flag=True)
+        l_new, o_new = model.train_step(xb, y, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True)
+        assert o_new["opt_step_id"] == sid_ref, "the step did not apply the optimizer itself"
+        assert torch.equal(l_ref, l_new)
+        assert torch.equal(o_ref["A_out"], o_new["A_out"])
+        assert torch.equal(ref_bucket.flat, bucket.flat), "gradients"
+        assert torch.equal(ref_opt.flat, opt.flat), "parameters after AdamW (step %d)" % i
+        assert torch.equal(ref_opt.exp_avg, opt.exp_avg) and torch.equal(ref_opt.exp_avg_sq, opt.exp_avg_sq)
+        _packed_equal_where_the_pack_kernel_writes(model, dev)
+    assert opt.poll_skipped(0) == [] and ref_opt.poll_skipped(0) == []
+    assert opt.step_count == ref_opt.step_count == 4
+    # only the first step packed from scratch
+    assert model._step_pack_key is not None
+
+
+def test_in_step_optimizer_skips_a_flagged_step_on_the_device_and_carries_on():
+    T, conf, dev, model, bucket, opt = _setup(384, 128, 5, 3, n_mask=0)
+    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3, n_mask=0)
+    ref_model.load_state_dict(model.state_dict())
+    good = _bags(3, 600, 384)
+    bad = good[1].float().clone(); bad[17, 3] = 1.0e5
+    y = torch.tensor([1], device=dev)
+    seq = [good[0], bad, good[2]]
+    ids, ref_ids = [], []
+    for x in seq:
+        before = opt.flat.clone()
+        _, out = model.train_step(x.to(dev).unsqueeze(0), y, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True)
+        ids.append(out["opt_step_id"])
+        ref_model.train_step(x.to(dev).unsqueeze(0), y, guard_flag=ref_opt.guard_flag)
+        ref_ids.append(ref_opt.step(track_flag=True))
+        if x is bad:
+            assert float(opt.guard_flag) == 1.0 and torch.equal(opt.flat, before)
+        assert torch.equal(opt.flat, ref_opt.flat) and torch.equal(opt.exp_avg, ref_opt.exp_avg)
+    assert ids == ref_ids and None not in ids
+    assert opt.poll_skipped(0) == [ids[1]] and ref_opt.poll_skipped(0) == [ref_ids[1]]
+    assert opt.step_count == ref_opt.step_count == 2 and opt.skipped_steps == 1
+    _packed_equal_where_the_pack_kernel_writes(model, dev)
+
+
+def test_anything_else_touching_the_parameters_forces_a_repack():
+    """The step's packed buffer is trusted only while the in-step update is the sole writer: a plain optimizer.step(), a
+    load_state_dict or an in-place edit in between must be seen (the next step packs from scratch) -- checked through the results."""
+    T, conf, dev, model, bucket, opt = _setup(384, 128, 5, 3)
+    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3)
+    ref_model.load_state_dict(model.state_dict())
+    bags = _bags(5, 500, 384, seed=4)
+    y = torch.tensor([2], device=dev)
+
+    def both(i, disturb=None):
+        xb = bags[i].to(dev).unsqueeze(0)
+        if disturb:
+            disturb(model); disturb(ref_model)
+        ref_model.train_step(xb, y, guard_flag=ref_opt.guard_flag)
+        ref_opt.step(track_flag=True)
+        _, out = model.train_step(xb, y, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True)
+        assert out["opt_step_id"] is not None
+        assert torch.equal(opt.flat, ref_opt.flat), "step %d" % i
+
+    both(0)
+    both(1)
+
+    def edit(m):
+        with torch.no_grad():
+            m.dimreduction.fc1.weight.mul_(1.01)
+    both(2, edit)
+
+    def reload(m):
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd["attention.attention_weights.weight"] *= 0.5
+        m.load_state_dict(sd)
+    both(3, reload)
+    # a plain optimizer step between two in-step ones (what train_one_epoch's fp32 repeat of a skipped bag does)
+    for o in (opt, ref_opt):
+        o.grad.fill_(1e-3)
+        o.guard_flag.zero_()      # (the flag is the bucket's last slot)
+        o.step()
+    both(4)
+    opt.poll_skipped(0); ref_opt.poll_skipped(0)
+
+
+def test_train_one_epoch_takes_the_in_step_path_on_one_gpu_and_matches_the_old_loop():
+    from acmil_amd import train as T
+    results = []
+    for in_step in (True, False):
+        _, conf, dev, model, bucket, opt = _setup(384, 128, 5, 3, seed=9)
+        if not in_step:
+            model.supports_in_step_optimizer = False
+        data = T.SyntheticBags(6, 700, 384, 3, seed=5)
+        calls = {"n": 0}
+        orig = opt.step
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        opt.step = counting
+        stats = T.train_one_epoch(model, data, opt, dev, 0, conf, bucket, 0, 1, log_every=0)
+        assert calls["n"] == (0 if in_step else 6)
+        results.append((opt.flat.clone(), stats))
+    assert torch.equal(results[0][0], results[1][0])
+    assert results[0][1] == results[1][1]
