@@ -41,19 +41,32 @@ struct GoCoef { float lr, wd, inv_bc1, inv_sqrt_bc2, eps, b1, b2; };
 __device__ __forceinline__ go_f4 go_sum4(const float* src, long long per, int splits) {
     go_f4 s = {0.0f, 0.0f, 0.0f, 0.0f};
     int sp = 0;
-    for (; sp + 8 <= splits; sp += 8) {
-        go_f4 v[8];
+    for (; sp + 16 <= splits; sp += 16) {          // 16 loads in flight, summed in index order
+        go_f4 v[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = *(const go_f4*)(src + (long long)(sp + j) * per);
+        for (int j = 0; j < 16; ++j) v[j] = *(const go_f4*)(src + (long long)(sp + j) * per);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += v[j];
+        for (int j = 0; j < 16; ++j) s += v[j];
+    }
+    for (; sp + 4 <= splits; sp += 4) {
+        go_f4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *(const go_f4*)(src + (long long)(sp + j) * per);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += v[j];
     }
     for (; sp < splits; ++sp) s += *(const go_f4*)(src + (long long)sp * per);
     return s;
 }
 
-__device__ __forceinline__ void go_adamw4(float* p, go_f4 g, long long m_off, long long v_off, const GoCoef& c, go_f4& out) {
-    go_f4 pv = *(go_f4*)p, mv = *(go_f4*)(p + m_off), vv = *(go_f4*)(p + v_off);
+struct GoState4 { go_f4 p, m, v; };
+__device__ __forceinline__ GoState4 go_load4(const float* p, long long m_off, long long v_off) {
+    GoState4 s;
+    s.p = *(const go_f4*)p; s.m = *(const go_f4*)(p + m_off); s.v = *(const go_f4*)(p + v_off);
+    return s;
+}
+__device__ __forceinline__ void go_adamw4(float* p, const GoState4& st, go_f4 g, long long m_off, long long v_off, const GoCoef& c, go_f4& out) {
+    go_f4 pv = st.p, mv = st.m, vv = st.v;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         float pi = pv[t], mi = mv[t], vi = vv[t];
@@ -89,53 +102,71 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
     if (a.flag_report && blk == 0 && tid == 0) __builtin_nontemporal_store(flag, a.flag_report);
     const bool skip = !(flag == 0.0f);      // (a NaN flag skips as well) -- gradients are still written, parameters / moments / packed stay
     if (skip && a.skipped && blk == 0 && tid == 0) atomicAdd(a.skipped, 1);
+    // the bias corrections (two double pow: ~1.5 us of one lane) are formed while the other waves already load; every region
+    // below issues its global reads first and meets this lane at ONE barrier (go_coef) before the update
     if (tid == 0 && !skip) {
         const long long t = a.launch - (a.skipped ? (long long)*a.skipped : 0);
         adamw_bias(a.beta1, a.beta2, t, s_bc[0], s_bc[1]);
     }
-    __syncthreads();
-    GoCoef c;
-    c.lr = a.lr; c.wd = a.wd; c.eps = a.eps; c.b1 = (float)a.beta1; c.b2 = (float)a.beta2;
-    c.inv_bc1 = skip ? 0.0f : s_bc[0]; c.inv_sqrt_bc2 = skip ? 0.0f : s_bc[1];
+    auto go_coef = [&]() {
+        __syncthreads();
+        GoCoef c;
+        c.lr = a.lr; c.wd = a.wd; c.eps = a.eps; c.b1 = (float)a.beta1; c.b2 = (float)a.beta2;
+        c.inv_bc1 = skip ? 0.0f : s_bc[0]; c.inv_sqrt_bc2 = skip ? 0.0f : s_bc[1];
+        return c;
+    };
     const int Di = L.Di, D = L.D, ND = L.ND;
+    const go_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     if (blk < a.blkA) {
         // ---- W1 [Di][D]: elements (r, k .. k+3)
         const long long per = (long long)Di * D;
         const long long e = ((long long)blk * 256 + tid) * 4;
-        if (e >= per) return;
-        go_f4 g;
-        if (a.splits_w1 > 1) { g = go_sum4(a.ws_w1 + e, per, a.splits_w1); *(go_f4*)(a.dW1 + e) = g; }
-        else g = *(const go_f4*)(a.dW1 + e);
+        const bool on = e < per;
+        GoState4 st = {zero4, zero4, zero4};
+        go_f4 g = zero4;
+        if (on) {
+            if (!skip) st = go_load4(a.W1 + e, a.m_off, a.v_off);
+            g = a.splits_w1 > 1 ? go_sum4(a.ws_w1 + e, per, a.splits_w1) : *(const go_f4*)(a.dW1 + e);
+        }
+        const GoCoef c = go_coef();
+        if (!on) return;
+        if (a.splits_w1 > 1) *(go_f4*)(a.dW1 + e) = g;
         if (skip) return;
         go_f4 w;
-        go_adamw4(a.W1 + e, g, a.m_off, a.v_off, c, w);
+        go_adamw4(a.W1 + e, st, g, a.m_off, a.v_off, c, w);
         // GEMM1 stream (F16X3): row (st*2 + part)*ND + d, lane i + 32 hi holds W1[32d + i][16 st + 8 hi + j], j < 8
         const int r = (int)(e / D), k = (int)(e % D);
-        const int d = r >> 5, i = r & 31, st = k >> 4, hi = (k >> 3) & 1, jh = (k >> 2) & 1;
+        const int d = r >> 5, i = r & 31, stp = k >> 4, hi = (k >> 3) & 1, jh = (k >> 2) & 1;
         go_u2 h2, l2;
         go_split_f16(w, h2, l2);
         char* dst = a.out + L.g1_off + (size_t)(i + 32 * hi) * 16 + jh * 8;
-        *(go_u2*)(dst + ((size_t)(st * 2 + 0) * ND + d) * GA_FRAG_ROW) = h2;
-        *(go_u2*)(dst + ((size_t)(st * 2 + 1) * ND + d) * GA_FRAG_ROW) = l2;
+        *(go_u2*)(dst + ((size_t)(stp * 2 + 0) * ND + d) * GA_FRAG_ROW) = h2;
+        *(go_u2*)(dst + ((size_t)(stp * 2 + 1) * ND + d) * GA_FRAG_ROW) = l2;
         return;
     }
     if (blk < a.blkA + a.blkB) {
         // ---- [Wv; Wu] [2 Da][Di]: elements (u, di .. di+3), u < Da tanh branch, else sigmoid branch
         const long long per = (long long)2 * GA_DA * Di;
         const long long e = ((long long)(blk - a.blkA) * 256 + tid) * 4;
-        if (e >= per) return;
-        const int u = (int)(e / Di), di = (int)(e % Di);
+        const bool on = e < per;
+        const int u = on ? (int)(e / Di) : 0, di = on ? (int)(e % Di) : 0;
         const int al = u >= GA_DA ? 1 : 0, unit = u - al * GA_DA;
         const size_t loc = (size_t)unit * Di + di;
         float* p = (al ? a.Wu : a.Wv) + loc;
         float* gd = (al ? a.dWu : a.dWv) + loc;
-        go_f4 g;
-        if (a.splits_vu > 1) { g = go_sum4(a.ws_vu + e, per, a.splits_vu); *(go_f4*)gd = g; }
-        else g = *(const go_f4*)gd;
+        GoState4 st = {zero4, zero4, zero4};
+        go_f4 g = zero4;
+        if (on) {
+            if (!skip) st = go_load4(p, a.m_off, a.v_off);
+            g = a.splits_vu > 1 ? go_sum4(a.ws_vu + e, per, a.splits_vu) : *(const go_f4*)gd;
+        }
+        const GoCoef c = go_coef();
+        if (!on) return;
+        if (a.splits_vu > 1) *(go_f4*)gd = g;
         if (skip) return;
         go_f4 w;
-        go_adamw4(p, g, a.m_off, a.v_off, c, w);
+        go_adamw4(p, st, g, a.m_off, a.v_off, c, w);
         go_u2 h2, l2;
         go_split_f16(w, h2, l2);
         {   // GEMM2 stream: step j = 4 g4 + st, local row (dd*2 + part)*4 + e2*2 + al; slot jj of lane (i, hi) <-> di = 32 d + (jj&3) + 8 (2 e2 + (jj>>2)) + 4 hi
@@ -143,8 +174,8 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
             const int g4 = unit >> 5, i = unit & 31;
             const int d = di >> 5, q = (di >> 3) & 3, hi = (di >> 2) & 1;
             const int e2 = q >> 1, jq = q & 1;
-            const int st = d / DD, dd = d % DD;
-            const size_t j = (size_t)4 * g4 + st;
+            const int stp = d / DD, dd = d % DD;
+            const size_t j = (size_t)4 * g4 + stp;
             char* dst = a.out + L.g2_off + (size_t)(i + 32 * hi) * 16 + jq * 8;
             *(go_u2*)(dst + (j * per_rows + (size_t)(dd * 2 + 0) * 4 + e2 * 2 + al) * GA_FRAG_ROW) = h2;
             *(go_u2*)(dst + (j * per_rows + (size_t)(dd * 2 + 1) * 4 + e2 * 2 + al) * GA_FRAG_ROW) = l2;
@@ -170,12 +201,13 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
     if (blk < a.blkA + a.blkB + a.blkC) {
         // ---- gate-pass records: one wave per element, lanes stride the records (gemm_finish_kernel's order)
         const int e = (blk - a.blkA - a.blkB) * 4 + (tid >> 6), lane = tid & 63;
-        if (e >= a.rec_stride) return;
         float s = 0.0f;
-        for (int r = lane; r < a.records; r += 64) s += a.rec[(size_t)r * a.rec_stride + e];
+        if (e < a.rec_stride)
+            for (int r = lane; r < a.records; r += 64) s += a.rec[(size_t)r * a.rec_stride + e];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        if (lane != 0) return;
+        const GoCoef c = go_coef();
+        if (lane != 0 || e >= a.rec_stride) return;
         const int o1 = KP * GA_DA, o2 = o1 + KP, o3 = o2 + GA_DA;
         float* bcat = (float*)(a.out + L.bcat_off);
         if (e < K * GA_DA) {
@@ -197,6 +229,7 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
         return;
     }
     // ---- heads (their gradients were written by the step's tail kernel): Wc [K][C][Di], bc [K][C], Ws [C][Di], bs [C]
+    const GoCoef c = go_coef();
     if (skip) return;
     const int CD = C * Di;
     const int n_wc = K * CD, n_bc = K * C, n_ws = a.Ws ? CD : 0, n_bs = a.Ws ? C : 0;

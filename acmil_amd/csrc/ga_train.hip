@@ -4,8 +4,6 @@
 //   masked softmax + attention-weighted sum   architecture/transformer.py:322-324 (on the saved h)
 // plus their C entry points (include/acmil_hip.h).  All of it is HBM-bound streaming / selection work:
 // coalesced float4 row reads, LDS for the per-tile probabilities, wave shuffles for reductions.
-#include <stdlib.h>
-
 #include "ga_common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -195,87 +193,6 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     }
 }
 
-// ---- one workgroup per branch (round 5): 16 waves hold the whole score row in registers (E keys per lane); every wave extracts ITS k
-// best with DPP maxima only (no barrier, no atomics), ONE barrier, then wave 0 merges the 16 k candidates and ranks the uniforms.
-// Same keys, same total order => the same indices as stkim_fused_kernel; no candidate workspace, no arrival ticket, and the
-// serial section (chunk extraction -> ticket -> last block's merge) of the multi-block form shrinks to two DPP phases:
-// 20 -> 15 us per launch at N = 10 000 / 50 000 (K = 5, k = 10).  Rows longer than 1024 * 50 scores keep the multi-block kernel.
-#define STKIM_B_THREADS 1024
-template <int E, int E2>
-__global__ __launch_bounds__(STKIM_B_THREADS) void stkim_branch_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, int N, int k, int m,
-                                                                       const float* __restrict__ uniforms, unsigned long long rng_seed,
-                                                                       unsigned long long rng_offset, int64_t* __restrict__ topk_idx,
-                                                                       int64_t* __restrict__ masked_idx) {
-    __shared__ unsigned long long cand[16 * 64];
-    __shared__ unsigned sel[64];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = scores + (size_t)b * N;
-    {
-        unsigned long long keys[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const unsigned idx = (unsigned)e * STKIM_B_THREADS + tid;
-            keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
-        }
-        for (int j = 0; j < k; ++j) {
-            unsigned long long best = 0ull;
-#pragma unroll
-            for (int e = 0; e < E; ++e) best = keys[e] > best ? keys[e] : best;
-            best = wave_max_key(best);
-            if (lane == 0) cand[wave * k + j] = best;
-#pragma unroll
-            for (int e = 0; e < E; ++e)
-                if (keys[e] == best) keys[e] = 0ull;      // unique keys; 0 = taken / padding
-        }
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const int ncand = 16 * k;
-    unsigned long long keys[E2];
-#pragma unroll
-    for (int e = 0; e < E2; ++e) {
-        const int i = e * 64 + lane;
-        keys[e] = i < ncand ? cand[i] : 0ull;
-    }
-    int64_t* trow = topk_idx + (size_t)b * k;
-    for (int j = 0; j < k; ++j) {
-        unsigned long long best = 0ull;
-#pragma unroll
-        for (int e = 0; e < E2; ++e) best = keys[e] > best ? keys[e] : best;
-        best = wave_max_key(best);
-        if (lane == 0) {
-            const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
-            sel[j] = idx;
-            trow[j] = (int64_t)idx;
-        }
-#pragma unroll
-        for (int e = 0; e < E2; ++e)
-            if (keys[e] == best) keys[e] = 0ull;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // sel[] written by lane 0 is visible to the wave
-    if (m > 0) {
-        const float mine = lane < k ? (uniforms ? uniforms[(size_t)b * k + lane] : stkim_uniform(rng_seed, rng_offset, (unsigned)b, (unsigned)lane)) : 2.0f;
-        int rank = 0;
-        for (int j = 0; j < k; ++j) {
-            const float uj = __shfl(mine, j);
-            rank += (uj < mine || (uj == mine && j < lane)) ? 1 : 0;
-        }
-        if (lane < k && rank < m) {
-            const unsigned n = sel[lane];
-            masked_idx[(size_t)b * m + rank] = (int64_t)n;
-            if (A_mask && n < (unsigned)N) A_mask[(size_t)b * N + n] = -1e9f;
-        }
-    }
-}
-
-template <int E>
-static void stkim_branch_launch(int K, int k, hipStream_t st, const float* scores, float* A_mask, int N, int m, const float* uniforms,
-                                unsigned long long rng_seed, unsigned long long rng_offset, int64_t* topk_idx, int64_t* masked_idx) {
-    if (k <= 16) hipLaunchKernelGGL((stkim_branch_kernel<E, 4>), dim3(K), dim3(STKIM_B_THREADS), 0, st, scores, A_mask, N, k, m, uniforms, rng_seed, rng_offset, topk_idx, masked_idx);
-    else hipLaunchKernelGGL((stkim_branch_kernel<E, 16>), dim3(K), dim3(STKIM_B_THREADS), 0, st, scores, A_mask, N, k, m, uniforms, rng_seed, rng_offset, topk_idx, masked_idx);
-}
-
 // workspace: [256-byte control block: arrival counter][candidates]
 extern "C" size_t acmil_stkim_workspace_bytes(int N, int K, int k) {
     if (N <= 0 || K <= 0 || k <= 0) return 0;
@@ -289,18 +206,6 @@ int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m,
                  unsigned long long rng_offset) {
     if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
     if (!scores || !topk_idx || !cand || !arrive || (m > 0 && !masked_idx)) return ACMIL_ERR_NULL;      // uniforms null = device draw
-    static const int form = [] { const char* e = ACMIL_AB_ENV("ACMIL_STKIM_BLOCKS"); return e ? atoi(e) : 0; }();      // A/B: 1 = the multi-block kernel
-    const int per_lane = (N + STKIM_B_THREADS - 1) / STKIM_B_THREADS;
-    if (per_lane <= 50 && form != 1) {
-#define STKIM_B_ARGS K, k, st, scores, A_mask, N, m, uniforms, rng_seed, rng_offset, topk_idx, masked_idx
-        if (per_lane <= 4) stkim_branch_launch<4>(STKIM_B_ARGS);
-        else if (per_lane <= 10) stkim_branch_launch<10>(STKIM_B_ARGS);
-        else if (per_lane <= 20) stkim_branch_launch<20>(STKIM_B_ARGS);
-        else if (per_lane <= 32) stkim_branch_launch<32>(STKIM_B_ARGS);
-        else stkim_branch_launch<50>(STKIM_B_ARGS);
-#undef STKIM_B_ARGS
-        return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
-    }
     const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
     if ((size_t)nch * k > 64 * STKIM_MERGE_E) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
     hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, N, K, k, m, uniforms, rng_seed, rng_offset,

@@ -41,7 +41,7 @@ SOURCES_OF = {     # kernel sources whose change invalidates a workload's PMC su
     "transmil": ("transmil.hip", "transmil_attn.hip", "transmil_pinv.hip", "linear_kernel.h", "linear.hip", "gemm_f32.hip", "gemm_internal.h"),
     "wide": ("ga_common.h", "linear_kernel.h", "linear.hip", "ga_forward_kernel_v2.h", "ga_train.hip"),
     "train": ("ga_common.h", "ga_forward_kernel.h", "ga_forward_kernel_v2.h", "ga_step.hip", "ga_train.hip", "ga_bwd_tile.hip", "ga_backward.hip",
-              "ga_pack.hip", "wgrad.hip", "optim.hip"),
+              "ga_pack.hip", "wgrad.hip", "optim.hip", "optim_kernel.h", "ga_opt_step.hip"),
 }
 
 
