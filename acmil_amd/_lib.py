@@ -110,6 +110,9 @@ SIGNATURES = {
                                   [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
                                   [C.c_ulonglong, C.c_ulonglong] +
                                   [_vp, C.c_longlong, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong, _vp, _vp]),
+    "acmil_ga_adamw_pack": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] +
+                            [_i] * 6 + [_vp] + [_vp, C.c_longlong, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong,
+                                                _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -474,7 +474,7 @@ class ACMIL_GA(_GatedBase):
 
     @torch.no_grad()
     def train_step(self, x, label, uniforms: Optional[torch.Tensor] = None, guard_flag: Optional[torch.Tensor] = None,
-                   precision: Optional[str] = None, optimizer=None, track_flag: bool = False):
+                   precision: Optional[str] = None, optimizer=None, track_flag: bool = False, in_step: bool = True):
         """One training step WITHOUT autograd: HIP forward (score pass, STKIM, masked pooling), the ACMIL loss and the HIP
         backward, writing the gradients into `p.grad` (allocated on first use, overwritten) -- ONE library call
         (acmil_ga_train_step) at the fused widths D_inner 128 / 256, the stand-alone kernels op by op at 384 / 512 / 768.
@@ -490,7 +490,9 @@ class ACMIL_GA(_GatedBase):
         update ITSELF -- its last launch finishes the gradients, runs AdamW and re-packs the weights (acmil_ga_train_step_adamw: three
         launches fewer per step) -- and the outputs carry `opt_step_id` (what optimizer.step(track_flag) would have returned); where it
         cannot (fp32 arithmetic, no guard_flag, frozen parameters, a direct peer reduction, the wide / composed families),
-        `opt_step_id` is None and the caller steps the optimizer as before."""
+        `opt_step_id` is None and the caller steps the optimizer as before.  in_step=False (data-parallel runs: the gradient
+        all-reduce sits between this call and the update) only tells the step whose updates to trust: with `adamw_pack_hook`
+        installed the optimizer's own launch re-packs the weights (acmil_ga_adamw_pack) and this call skips its pack launch."""
         self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
@@ -502,7 +504,7 @@ class ACMIL_GA(_GatedBase):
             if p.grad is None:
                 p.grad = torch.empty_like(p)
         if self._is_fused() and getattr(self, "fused_step", True):
-            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision, optimizer, track_flag)
+            losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision, optimizer, track_flag, in_step)
         else:
             if precision is not None and precision != self.precision:
                 raise NotImplementedError("acmil_amd: per-call precision is a feature of the one-call step")
@@ -512,7 +514,7 @@ class ACMIL_GA(_GatedBase):
         self._last = out
         return losses, out
 
-    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None, optimizer=None, track_flag=False):
+    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None, optimizer=None, track_flag=False, in_step=True):
         """The whole step enqueued by one library call (csrc/ga_step.hip: 8 launches).  The packed weights are rebuilt inside
         the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
         after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
@@ -528,16 +530,20 @@ class ACMIL_GA(_GatedBase):
             if st is None:
                 packed, dims = self._packed(precision) if precision != self.precision else self._packed()
                 st = cache[(precision, dev)] = (packed.clone(), dims)      # a private buffer: the call rewrites it every step
-            in_step = (optimizer is not None and precision == "f16x3" and guard_flag is not None and not self.__dict__.get("_opt_in_step_refused")
-                       and getattr(optimizer, "can_run_in_step", lambda: False)())
-            if not in_step:
-                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=True,
+            # the step's private packed buffer stays current as long as nothing but this optimizer's fused launches (the in-step closing
+            # launch, acmil_ga_adamw_pack through adamw_pack_hook) touches the parameters: (storages, versions, the optimizer's count)
+            opt_ok = (optimizer is not None and precision == "f16x3" and hasattr(optimizer, "mutations")
+                      and not self.__dict__.get("_opt_in_step_refused"))
+            key = (precision, dev, id(optimizer), self._param_key(params)) if opt_ok else None
+            valid = opt_ok and self.__dict__.get("_step_pack_key") == key + (optimizer.mutations,)
+            use_in_step = opt_ok and in_step and guard_flag is not None and optimizer.can_run_in_step()
+            if not use_in_step:
+                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
                                         guard_flag=guard_flag, rng=self._step_rng)
+                if opt_ok:
+                    self._step_pack_key = key + (optimizer.mutations,)      # packed now holds exactly the values this step ran on
                 out["opt_step_id"] = None
                 return out
-            # the step's private packed buffer stays current as long as nothing but the in-step update touches the parameters
-            key = (precision, dev, id(optimizer), self._param_key(params))
-            valid = self.__dict__.get("_step_pack_key") == key + (optimizer.mutations,)
             args = optimizer.in_step_args(track_flag)
             try:
                 out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
@@ -558,6 +564,11 @@ class ACMIL_GA(_GatedBase):
             out = run("fp32")
             out["range_fallback"] = True
         return out["losses"], out
+
+    def adamw_pack_hook(self, optimizer):
+        """For FlatAdamW.pack_hook: lets the optimizer's launch re-pack this module's weights (acmil_ga_adamw_pack) so that the next
+        training step needs no pack launch.  Used where the update cannot ride in the step's own closing launch (data parallel)."""
+        return _AdamwPackHook(self, optimizer)
 
     def _train_step_composed(self, xb, label, uniforms, params, masking):
         """Op-by-op step (the wide D_inner families, and the fused step's cross-check in the tests)."""
@@ -623,6 +634,45 @@ class ACMIL_GA(_GatedBase):
         else:
             out = self._eval_forward(xb, packed, dims, want_scores=False, want_preds=False, want_bag_feat=True)
         return out["bag_feat"].unsqueeze(0)
+
+
+class _AdamwPackHook:
+    """FlatAdamW.pack_hook of one ACMIL_GA module (see ACMIL_GA.adamw_pack_hook)."""
+
+    def __init__(self, model, optimizer):
+        import weakref
+        self.model = weakref.ref(model)
+        self.optimizer = weakref.ref(optimizer)
+        self._pending = None
+
+    def launch(self, adamw_args, skip_flag) -> bool:
+        m, opt = self.model(), self.optimizer()
+        self._pending = None
+        if m is None or opt is None or m.precision != "f16x3" or not m._is_fused() or m.__dict__.get("_opt_in_step_refused"):
+            return False
+        params = m._all_params()
+        dev = params[0].device
+        st = m.__dict__.get("_step_packed", {}).get(("f16x3", dev))
+        if st is None or any(p.grad is None for p in params):
+            return False
+        key = ("f16x3", dev, id(opt), m._param_key(params))
+        was_valid = m.__dict__.get("_step_pack_key") == key + (opt.mutations,)
+        try:
+            ops.ga_adamw_pack(st[0], st[1], params, [p.grad for p in params], adamw_args, skip_flag)
+        except RuntimeError as e:
+            if "(-2)" not in str(e) and "(-1)" not in str(e):
+                raise
+            m._opt_in_step_refused = True      # e.g. parameters not 16-byte aligned inside the flat buffer: nothing was launched
+            return False
+        # an applied launch rewrites every packed copy; a launch the device skips (range flag) leaves the buffer as it was
+        self._pending = key if (was_valid or skip_flag is None) else None
+        return True
+
+    def committed(self):
+        m, opt = self.model(), self.optimizer()
+        if m is not None and opt is not None and self._pending is not None:
+            m._step_pack_key = self._pending + (opt.mutations,)
+        self._pending = None
 
 
 class MutiHeadAttention(nn.Module):

@@ -22,7 +22,8 @@
 
 struct GoArgs {
     const float *ws_vu, *ws_w1; int splits_vu, splits_w1;     // split-K partials [split][2 Da][Di] / [split][Di][D]; splits <= 1: the gradient tensor already holds the product
-    const float* rec; int records, rec_stride, KP;            // gate-pass records (dWw | dbw | dbv | dbu per record)
+    const float* rec; int records, rec_stride, KP;            // gate-pass records (dWw | dbw | dbv | dbu per record); rec == null: the
+                                                              // gradient tensors are final (acmil_ga_adamw_pack: after a data-parallel all-reduce)
     float *W1, *Wv, *bv, *Wu, *bu, *Ww, *bw, *Ws, *bs; float* Wc[GO_MAXK]; float* bc[GO_MAXK];
     float *dW1, *dWv, *dbv, *dWu, *dbu, *dWw, *dbw, *dWs, *dbs; float* dWc[GO_MAXK]; float* dbc[GO_MAXK];
     long long m_off, v_off;                                   // the moments of parameter element p live at p + m_off / p + v_off
@@ -199,31 +200,46 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
     const int K = L.K, C = L.C, KP = a.KP;
     float* tab = (float*)(a.out + L.tab_off);
     if (blk < a.blkA + a.blkB + a.blkC) {
-        // ---- gate-pass records: one wave per element, lanes stride the records (gemm_finish_kernel's order)
-        const int e = (blk - a.blkA - a.blkB) * 4 + (tid >> 6), lane = tid & 63;
-        float s = 0.0f;
-        if (e < a.rec_stride)
-            for (int r = lane; r < a.records; r += 64) s += a.rec[(size_t)r * a.rec_stride + e];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        const GoCoef c = go_coef();
-        if (lane != 0 || e >= a.rec_stride) return;
+        // ---- Ww [K][Da], bw [K], bv [Da], bu [Da]
         const int o1 = KP * GA_DA, o2 = o1 + KP, o3 = o2 + GA_DA;
+        int e; float s = 0.0f; bool mine;
+        if (a.rec) {
+            // gradients = sums of the gate-pass records: one wave per element, lanes stride the records (gemm_finish_kernel's order)
+            const int lane = tid & 63;
+            e = (blk - a.blkA - a.blkB) * 4 + (tid >> 6);
+            if (e < a.rec_stride)
+                for (int r = lane; r < a.records; r += 64) s += a.rec[(size_t)r * a.rec_stride + e];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            mine = lane == 0 && e < a.rec_stride;
+        } else {
+            // final gradients: one lane per element of the same index space
+            e = (blk - a.blkA - a.blkB) * 256 + tid;
+            mine = e < o3 + GA_DA;
+            const float* g = nullptr;
+            if (e < K * GA_DA) g = a.dWw + e;
+            else if (e >= o1 && e < o1 + K) g = a.dbw + (e - o1);
+            else if (e >= o2 && e < o3) g = a.dbv + (e - o2);
+            else if (e >= o3 && e < o3 + GA_DA) g = a.dbu + (e - o3);
+            if (mine && g) s = *g;
+        }
+        const GoCoef c = go_coef();
+        if (!mine) return;
         float* bcat = (float*)(a.out + L.bcat_off);
         if (e < K * GA_DA) {
-            a.dWw[e] = s;
+            if (a.rec) a.dWw[e] = s;
             if (!skip) tab[2 * GA_DA + e] = go_adamw1(a.Ww + e, s, a.m_off, a.v_off, c);      // tab[(2 + k) Da + col], e = k Da + col
         } else if (e >= o1 && e < o1 + K) {
             const int k = e - o1;
-            a.dbw[k] = s;
+            if (a.rec) a.dbw[k] = s;
             if (!skip) ((float*)(a.out + L.bw_off))[k] = go_adamw1(a.bw + k, s, a.m_off, a.v_off, c);
         } else if (e >= o2 && e < o3) {
             const int cc = e - o2;
-            a.dbv[cc] = s;
+            if (a.rec) a.dbv[cc] = s;
             if (!skip) { const float w = go_adamw1(a.bv + cc, s, a.m_off, a.v_off, c); tab[cc] = w; bcat[cc] = w; }
         } else if (e >= o3 && e < o3 + GA_DA) {
             const int cc = e - o3;
-            a.dbu[cc] = s;
+            if (a.rec) a.dbu[cc] = s;
             if (!skip) { const float w = go_adamw1(a.bu + cc, s, a.m_off, a.v_off, c); tab[GA_DA + cc] = w; bcat[GA_DA + cc] = w; }
         }
         return;
@@ -284,13 +300,16 @@ int go_check(const GoTensors& t, int D, int Di, int K, int C, int mode, const fl
     return ACMIL_OK;
 }
 
-int go_launch(const GoTensors& t, const GemmArgs& g_vu, const GemmArgs& g_w1, const RowSumJob& job, int KP, void* packed, const GaLayout& L,
+// g_vu / g_w1 / job null: the gradient tensors are final (AdamW + re-pack only)
+int go_launch(const GoTensors& t, const GemmArgs* g_vu, const GemmArgs* g_w1, const RowSumJob* job, int KP, void* packed, const GaLayout& L,
               const float* flat, const float* exp_avg, const float* exp_avg_sq, float lr, double beta1, double beta2, float eps, float wd,
               long long step, const float* skip_flag, int* skipped, float* flag_report, hipStream_t st) {
     GoArgs a;
     memset(&a, 0, sizeof(a));
-    a.ws_vu = g_vu.ws; a.splits_vu = g_vu.splits; a.ws_w1 = g_w1.ws; a.splits_w1 = g_w1.splits;
-    a.rec = job.part; a.records = job.records; a.rec_stride = job.stride; a.KP = KP;
+    if (g_vu) { a.ws_vu = g_vu->ws; a.splits_vu = g_vu->splits; }
+    if (g_w1) { a.ws_w1 = g_w1->ws; a.splits_w1 = g_w1->splits; }
+    if (job) { a.rec = job->part; a.records = job->records; a.rec_stride = job->stride; }
+    a.KP = KP;
     a.W1 = t.W1; a.Wv = t.Wv; a.bv = t.bv; a.Wu = t.Wu; a.bu = t.bu; a.Ww = t.Ww; a.bw = t.bw; a.Ws = t.Ws; a.bs = t.bs;
     a.dW1 = t.dW1; a.dWv = t.dWv; a.dbv = t.dbv; a.dWu = t.dWu; a.dbu = t.dbu; a.dWw = t.dWw; a.dbw = t.dbw; a.dWs = t.dWs; a.dbs = t.dbs;
     for (int k = 0; k < GO_MAXK; ++k) { a.Wc[k] = t.Wc[k]; a.bc[k] = t.bc[k]; a.dWc[k] = t.dWc[k]; a.dbc[k] = t.dbc[k]; }
@@ -299,9 +318,42 @@ int go_launch(const GoTensors& t, const GemmArgs& g_vu, const GemmArgs& g_w1, co
     a.skip_flag = skip_flag; a.skipped = skipped; a.flag_report = flag_report;
     a.out = (char*)packed; a.L = L;
     const long long nA = (long long)L.Di * L.D / 4, nB = (long long)2 * GA_DA * L.Di / 4;
-    a.blkA = (int)((nA + 255) / 256); a.blkB = (int)((nB + 255) / 256); a.blkC = (job.stride + 3) / 4;
+    a.blkA = (int)((nA + 255) / 256); a.blkB = (int)((nB + 255) / 256); a.blkC = job ? (job->stride + 3) / 4 : (KP * GA_DA + KP + 2 * GA_DA + 255) / 256;
     const int nD = L.K * L.C * L.Di + L.K * L.C + (t.Ws ? L.C * L.Di + L.C : 0);
     const int blkD = (nD + 255) / 256;
     hipLaunchKernelGGL(ga_opt_step_kernel, dim3(a.blkA + a.blkB + a.blkC + blkD), dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
+}
+
+// torch.optim.AdamW's update over the flat parameter buffer of ONE ACMIL_GA / ABMIL module AND the re-pack of its weights, one launch:
+// acmil_adamw_step_report + acmil_ga_pack_weights for callers whose gradients are final when the optimizer runs (data-parallel steps:
+// the bucket all-reduce sits between acmil_ga_train_step and this call).  Same arithmetic, bit for bit.
+extern "C" int acmil_ga_adamw_pack(float* W1, float* Wv, float* bv, float* Wu, float* bu, float* Ww, float* bw, float* const* Wc, float* const* bc,
+                                   float* Ws, float* bs,
+                                   const float* dW1, const float* dWv, const float* dbv, const float* dWu, const float* dbu, const float* dWw,
+                                   const float* dbw, const float* const* dWc, const float* const* dbc, const float* dWs, const float* dbs,
+                                   int D, int Di, int Da, int K, int C, int mode, void* packed,
+                                   const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
+                                   double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
+                                   float* flag_report, void* stream) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (K > GO_MAXK) return ACMIL_ERR_UNSUPPORTED;
+    if (step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return ACMIL_ERR_SHAPE;
+    if (!W1 || !Wv || !bv || !Wu || !bu || !Ww || !bw || !Wc || !bc || !packed) return ACMIL_ERR_NULL;
+    if (!dW1 || !dWv || !dbv || !dWu || !dbu || !dWw || !dbw || !dWc || !dbc) return ACMIL_ERR_NULL;
+    if ((Ws == nullptr) != (bs == nullptr) || (Ws && (!dWs || !dbs))) return ACMIL_ERR_NULL;
+    GoTensors t;
+    memset(&t, 0, sizeof(t));
+    t.W1 = W1; t.Wv = Wv; t.bv = bv; t.Wu = Wu; t.bu = bu; t.Ww = Ww; t.bw = bw; t.Ws = Ws; t.bs = bs;
+    t.dW1 = (float*)dW1; t.dWv = (float*)dWv; t.dbv = (float*)dbv; t.dWu = (float*)dWu; t.dbu = (float*)dbu; t.dWw = (float*)dWw; t.dbw = (float*)dbw;
+    t.dWs = (float*)dWs; t.dbs = (float*)dbs;
+    for (int k = 0; k < K; ++k) {
+        if (!Wc[k] || !bc[k] || !dWc[k] || !dbc[k]) return ACMIL_ERR_NULL;
+        t.Wc[k] = Wc[k]; t.bc[k] = bc[k]; t.dWc[k] = (float*)dWc[k]; t.dbc[k] = (float*)dbc[k];
+    }
+    rc = go_check(t, D, Di, K, C, mode, flat_params, n_flat, exp_avg, exp_avg_sq);
+    if (rc != ACMIL_OK) return rc;
+    return go_launch(t, nullptr, nullptr, nullptr, ga_kp(K), packed, ga_layout(D, Di, K, C, mode), flat_params, exp_avg, exp_avg_sq, lr, beta1, beta2,
+                     eps, weight_decay, step, skip_flag, skipped, flag_report, (hipStream_t)stream);
 }

@@ -501,7 +501,7 @@ static int gs_step(const void* x, int x_dtype, int N, void* packed, int repack,
     GbDefer df;
     rc = gb_run(r, &df);
     if (rc != ACMIL_OK) return rc;
-    return go_launch(gt, df.g_vu, df.g_w1, df.job, KP, packed, t.L, opt->flat, opt->exp_avg, opt->exp_avg_sq, opt->lr, opt->beta1, opt->beta2,
+    return go_launch(gt, &df.g_vu, &df.g_w1, &df.job, KP, packed, t.L, opt->flat, opt->exp_avg, opt->exp_avg_sq, opt->lr, opt->beta1, opt->beta2,
                      opt->eps, opt->wd, opt->step, guard_flag, opt->skipped, opt->flag_report, st);
 }
 

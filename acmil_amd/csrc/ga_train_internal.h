@@ -54,7 +54,7 @@ struct GoTensors {
 };
 int go_check(const GoTensors& t, int D, int Di, int K, int C, int mode, const float* flat, long long n_flat, const float* exp_avg,
              const float* exp_avg_sq);
-int go_launch(const GoTensors& t, const GemmArgs& g_vu, const GemmArgs& g_w1, const RowSumJob& job, int KP, void* packed, const GaLayout& L,
+int go_launch(const GoTensors& t, const GemmArgs* g_vu, const GemmArgs* g_w1, const RowSumJob* job, int KP, void* packed, const GaLayout& L,
               const float* flat, const float* exp_avg, const float* exp_avg_sq, float lr, double beta1, double beta2, float eps, float wd,
               long long step, const float* skip_flag, int* skipped, float* flag_report, hipStream_t st);
 

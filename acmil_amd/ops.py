@@ -501,6 +501,25 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 
 
+def ga_adamw_pack(packed: torch.Tensor, dims: GaDims, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], adamw: tuple,
+                  skip_flag: Optional[torch.Tensor]):
+    """acmil_ga_adamw_pack: AdamW over the module's flat parameter buffer + re-pack of the f16x3 packed buffer, one launch (final
+    gradients: the data-parallel step).  params / grads as ga_train_step; adamw as there."""
+    lib = _lib.load()
+    K = dims.K
+    pp = [p.data_ptr() for p in params]
+    gp = [g.data_ptr() for g in grads]
+    vpK = ctypes.c_void_p * K
+    has_bag = dims.has_bag_head
+    flat, m1, m2, lr, b1, b2, eps, wd, step, skipped, report = adamw
+    rc = lib.acmil_ga_adamw_pack(
+        *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
+        *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
+        *dims.args(), mode_id("f16x3"), packed.data_ptr(), flat.data_ptr(), flat.numel(), m1.data_ptr(), m2.data_ptr(), float(lr), float(b1),
+        float(b2), float(eps), float(wd), int(step), _ptr(skip_flag), skipped.data_ptr(), report, _stream())
+    _lib.check(rc, "acmil_ga_adamw_pack")
+
+
 _TM_SIDE: Dict[tuple, tuple] = {}
 _TM_SIDE_LOCK = threading.Lock()
 

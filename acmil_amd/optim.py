@@ -64,6 +64,9 @@ class FlatAdamW:
         self._frozen = []          # (offset, numel) ranges that receive no gradient this run: skipped like torch skips grad=None
         self.mutations = 0         # counts every change this object makes to the parameters (owners of derived buffers compare it)
         self._in_step = None
+        # or an object with launch(adamw_args, skip_flag) -> bool and committed(): the owner of a packed copy of the parameters (ACMIL_GA)
+        # issues the AdamW launch itself, fused with its re-pack (acmil_ga_adamw_pack); False = not now, use the plain launch
+        self.pack_hook = None
 
     def set_frozen(self, params: Iterable[torch.nn.Parameter]):
         """Parameters that never receive a gradient (e.g. the branch head of an n_token = 1 ACMIL model, whose loss term is not
@@ -139,13 +142,21 @@ class FlatAdamW:
         elif self.peer is not None:
             # direct data-parallel reduction: bucket -> own slot + flags at the peers, then wait + reduce (rank order) + AdamW in ONE launch
             self._peer_launch(lib, g, b1, b2, track, slot, None)
+        hooked = False
         if self.peer is None:
-            self._plain_launch(lib, g, b1, b2, track, slot)
+            if self.pack_hook is not None and not self._frozen:
+                hooked = self.pack_hook.launch((self.flat, self.exp_avg, self.exp_avg_sq, float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                                float(g["weight_decay"]), self._launches, self._skipped_dev,
+                                                self._host_flags.data_ptr() + 4 * slot if track else None), self.guard_flag)
+            if not hooked:
+                self._plain_launch(lib, g, b1, b2, track, slot)
         for o, v in kept:
             self.flat[o:o + v.numel()].copy_(v)
         self.mutations += 1
         if self.on_step is not None:      # the update bypasses torch's version counters: owners of derived caches are told
             self.on_step()
+        if hooked:
+            self.pack_hook.committed()
         if track:
             ev = torch.cuda.Event()
             ev.record()

@@ -247,7 +247,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     lagged = (use_fused and getattr(optimizer, "guard_flag", None) is not None and getattr(model, "range_guard", False)
               and getattr(model, "precision", "") == "f16x3")
     recent: Dict[int, tuple] = {}
-    in_step = lagged and world == 1 and hasattr(optimizer, "in_step_args") and getattr(model, "supports_in_step_optimizer", False)
+    opt_aware = use_fused and hasattr(optimizer, "in_step_args") and getattr(model, "supports_in_step_optimizer", False)
+    in_step = opt_aware and lagged and world == 1
 
     def reduce_and_step(track):
         if bucket is not None:
@@ -280,7 +281,7 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
         if use_fused:
             # single GPU: the step applies the optimizer itself (its closing launch = gradient finish + AdamW + weight re-pack) where it can
             losses, out = model.train_step(x.unsqueeze(0), labels, guard_flag=optimizer.guard_flag if lagged else None,
-                                           **({"optimizer": optimizer, "track_flag": True} if in_step else {}))
+                                           **({"optimizer": optimizer, "track_flag": True, "in_step": in_step} if opt_aware else {}))
             sid = out.get("opt_step_id") if in_step else None
             if not lagged:
                 acc += losses
@@ -412,6 +413,8 @@ def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, l
             # n_token == 1: the branch-head loss is not built (Step3_WSI_classification_ACMIL.py:201-204), its parameters keep
             # grad None in the reference and torch's AdamW leaves them untouched (no weight decay)
             opt.set_frozen(list(model.classifier[0].parameters()))
+        if hasattr(model, "adamw_pack_hook"):
+            opt.pack_hook = model.adamw_pack_hook(opt)      # the optimizer launch also re-packs the module's weights (acmil_ga_adamw_pack)
         return opt
     if bucket is not None and bucket.peer is not None:
         # the direct reduction lives inside FlatAdamW's launch: with torch's optimizer the bucket goes back to the collective

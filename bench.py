@@ -316,7 +316,7 @@ def other_workloads(args, ctx):
             # one GPU: the step applies AdamW itself -- its closing launch finishes the gradients, updates and re-packs (7 launches per
             # step); data parallel: the bucket all-reduce sits between the gradients and the optimizer's own launch (9 launches + RCCL)
             _, out = model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag,
-                                      **({"optimizer": opt, "track_flag": True} if world == 1 and not args.train_separate_opt else {}))
+                                      optimizer=opt, track_flag=True, in_step=(world == 1 and not args.train_separate_opt))
             if out.get("opt_step_id") is None:
                 bucket.sync_from_grads()
                 bucket.allreduce_mean(world)

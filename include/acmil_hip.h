@@ -318,6 +318,21 @@ int acmil_ga_train_step_adamw(const void* x, int x_dtype, int N, void* packed, i
                         const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
                         double beta2, float eps, float weight_decay, long long step, int* skipped, float* flag_report);
 
+/* torch.optim.AdamW's update over the flat parameter buffer of ONE ACMIL_GA / ABMIL module AND the re-pack of its weights in one
+ * launch: acmil_adamw_step_report followed by acmil_ga_pack_weights, for steps whose gradients are final when the optimizer runs --
+ * data-parallel training (Step3_WSI_classification_ACMIL.py:219's optimizer.step() behind a gradient all-reduce): the next
+ * acmil_ga_train_step then passes repack = 0.  Arguments as acmil_ga_train_step_adamw (parameters tile flat_params; moments at the
+ * same offsets; skip_flag / skipped / flag_report as acmil_adamw_step_report); mode must be ACMIL_MODE_F16X3.  Same error behaviour:
+ * ACMIL_ERR_UNSUPPORTED / ACMIL_ERR_SHAPE before anything is launched. */
+int acmil_ga_adamw_pack(float* W1, float* Wv, float* bv, float* Wu, float* bu, float* Ww, float* bw, float* const* Wc, float* const* bc,
+                        float* Ws, float* bs,
+                        const float* dW1, const float* dWv, const float* dbv, const float* dWu, const float* dbu, const float* dWw,
+                        const float* dbw, const float* const* dWc, const float* const* dbc, const float* dWs, const float* dbs,
+                        int D, int Di, int Da, int K, int C, int mode, void* packed,
+                        const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
+                        double beta2, float eps, float weight_decay, long long step, const float* skip_flag, int* skipped,
+                        float* flag_report, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused ACMIL loss + its gradient w.r.t. the aggregator outputs.  Replaces Step3_WSI_classification_ACMIL.py:201-216
  * (loss0 = CE(sub_preds, label x K) [0 if K == 1], loss1 = CE(slide_pred, label), diff_loss = mean pairwise cosine

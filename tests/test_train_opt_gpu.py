@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(D=512, Di=256, K=5, C=7, n_mask=10, seed=3):
+def _setup(D=512, Di=256, K=5, C=7, n_mask=10, seed=3, plain=False):
     from acmil_amd import train as T
     conf = T.Struct(train_epoch=3, warmup_epoch=0, wd=1e-2, lr=1e-3, min_lr=0, n_class=C, n_token=K, n_masked_patch=n_mask,
                     mask_drop=0.6, arch="ga", precision="f16x3", seed=1, D_feat=D, D_inner=Di)
@@ -18,6 +18,8 @@ def _setup(D=512, Di=256, K=5, C=7, n_mask=10, seed=3):
     model = T.build_model(conf).to(dev).train()
     bucket = T.GradBucket(list(model.parameters()))
     opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)
+    if plain:
+        opt.pack_hook = None      # the reference sequence: acmil_ga_train_step_rng (packs first) -> acmil_adamw_step_report
     return T, conf, dev, model, bucket, opt
 
 
@@ -77,7 +79,7 @@ def _packed_equal_where_the_pack_kernel_writes(model, dev):
 
 @pytest.mark.parametrize("D,Di,K,C,N", [(512, 256, 5, 7, 3000), (384, 128, 5, 2, 1500), (512, 256, 1, 2, 900), (512, 256, 3, 4, 700)])
 def test_in_step_optimizer_is_bit_identical_to_the_three_launch_sequence(D, Di, K, C, N):
-    T, conf, dev, ref_model, ref_bucket, ref_opt = _setup(D, Di, K, C)
+    T, conf, dev, ref_model, ref_bucket, ref_opt = _setup(D, Di, K, C, plain=True)
     _, _, _, model, bucket, opt = _setup(D, Di, K, C)
     model.load_state_dict(ref_model.state_dict())
     if not opt.can_run_in_step():
@@ -106,7 +108,7 @@ def test_in_step_optimizer_is_bit_identical_to_the_three_launch_sequence(D, Di, 
 
 def test_in_step_optimizer_skips_a_flagged_step_on_the_device_and_carries_on():
     T, conf, dev, model, bucket, opt = _setup(384, 128, 5, 3, n_mask=0)
-    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3, n_mask=0)
+    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3, n_mask=0, plain=True)
     ref_model.load_state_dict(model.state_dict())
     good = _bags(3, 600, 384)
     bad = good[1].float().clone(); bad[17, 3] = 1.0e5
@@ -132,7 +134,7 @@ def test_anything_else_touching_the_parameters_forces_a_repack():
     """The step's packed buffer is trusted only while the in-step update is the sole writer: a plain optimizer.step(), a
     load_state_dict or an in-place edit in between must be seen (the next step packs from scratch) -- checked through the results."""
     T, conf, dev, model, bucket, opt = _setup(384, 128, 5, 3)
-    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3)
+    _, _, _, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3, plain=True)
     ref_model.load_state_dict(model.state_dict())
     bags = _bags(5, 500, 384, seed=4)
     y = torch.tensor([2], device=dev)
@@ -189,3 +191,48 @@ def test_train_one_epoch_takes_the_in_step_path_on_one_gpu_and_matches_the_old_l
         results.append((opt.flat.clone(), stats))
     assert torch.equal(results[0][0], results[1][0])
     assert results[0][1] == results[1][1]
+
+
+@pytest.mark.parametrize("D,Di,K,C", [(512, 256, 5, 7), (384, 128, 3, 2)])
+def test_optimizer_launch_that_also_repacks_matches_the_plain_sequence(D, Di, K, C):
+    """The data-parallel shape of the step (the update cannot ride in the step's closing launch: an all-reduce sits in between):
+    FlatAdamW.step() goes through ACMIL_GA.adamw_pack_hook -> acmil_ga_adamw_pack (AdamW + re-pack, one launch) and the next
+    train_step(optimizer=opt, in_step=False) skips its pack launch.  Bit-identical to pack -> step -> plain AdamW, incl. a skipped
+    (range-flagged) step and a foreign edit of the parameters in between."""
+    T, conf, dev, ref_model, ref_bucket, ref_opt = _setup(D, Di, K, C, plain=True)
+    _, _, _, model, bucket, opt = _setup(D, Di, K, C)
+    assert opt.pack_hook is not None
+    model.load_state_dict(ref_model.state_dict())
+    bags = _bags(5, 800, D, seed=2)
+    bad = bags[2].float().clone(); bad[11, 5] = 2.0e5
+    seq = [bags[0], bags[1], bad, bags[3], bags[4]]
+    packs = {"n": 0}
+    from acmil_amd import ops
+    orig = ops.ga_train_step
+
+    def spy(*a, **k):
+        packs["n"] += int(bool(k.get("repack", True)))
+        return orig(*a, **k)
+    ops.ga_train_step = spy
+    try:
+        for i, x in enumerate(seq):
+            y = torch.tensor([i % C], device=dev)
+            xb = x.to(dev).unsqueeze(0)
+            if i == 3:
+                for m in (model, ref_model):
+                    with torch.no_grad():
+                        m.attention.attention_V[0].weight.mul_(0.99)
+            ref_model.train_step(xb, y, guard_flag=ref_opt.guard_flag)
+            ref_opt.step(track_flag=True)
+            n0 = packs["n"]
+            _, out = model.train_step(xb, y, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True, in_step=False)
+            repacked = packs["n"] - n0
+            assert out["opt_step_id"] is None
+            opt.step(track_flag=True)
+            assert torch.equal(ref_bucket.flat, bucket.flat), "gradients (step %d)" % i
+            assert torch.equal(ref_opt.flat, opt.flat) and torch.equal(ref_opt.exp_avg, opt.exp_avg) and torch.equal(ref_opt.exp_avg_sq, opt.exp_avg_sq)
+            assert repacked == (1 if i in (0, 3) else 0), "step %d: %d pack launches" % (i, repacked)      # first step, and after the foreign edit
+            _packed_equal_where_the_pack_kernel_writes(model, dev)
+    finally:
+        ops.ga_train_step = orig
+    assert opt.poll_skipped(0) == ref_opt.poll_skipped(0) and opt.skipped_steps == 1
