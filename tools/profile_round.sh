@@ -16,7 +16,9 @@ run_stats() {   # name, bench args...
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
 }
+# ONLY_TRAIN=1: the training-step evidence alone (PMC of both step sizes, the driver-style default line, the two train lines + traces)
 # PMC first (their summaries stamp the kernel source; the bench lines below then carry `traffic`)
+if [ -z "$ONLY_TRAIN" ]; then
 python tools/pmc_ga.py --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_b64.log 2>&1
 python tools/pmc_ga.py --batch 1 --steps 100 --out $OUT/pmc > $OUT/pmc_ga_eval_b1.log 2>&1
 python tools/pmc_ga.py --precision fp32 --batch 16 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_fp32.log 2>&1
@@ -24,11 +26,13 @@ python tools/pmc_ga.py --workload ga_cfg3 --batch 64 --steps 12 --out $OUT/pmc >
 python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
 for w in ga_uni ga_clip_l; do python tools/pmc_ga.py --workload $w --batch 64 --steps 8 --out $OUT/pmc > $OUT/pmc_$w.log 2>&1; done      # fused since round 5
 python tools/pmc_ga.py --workload ga_gigapath --batch 1 --whole-step --steps 30 --out $OUT/pmc > $OUT/pmc_ga_gigapath.log 2>&1
+fi
 python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
 python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --extra "--train-n 50000" --out $OUT/pmc > $OUT/pmc_train50k.log 2>&1
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
 for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
+if [ -z "$ONLY_TRAIN" ]; then
 python bench.py --no-secondary > $OUT/bench_default.json 2>> $OUT/bench_default.log
 python bench.py --batch 16 --no-cpu-baseline --no-secondary > $OUT/bench_b16.json 2>> $OUT/bench_default.log
 python bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/bench_b1.json 2>> $OUT/bench_default.log
@@ -37,6 +41,7 @@ python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cf
 for w in ga_uni ga_clip_l; do python bench.py --workload $w --steps 20 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.log; done
 python bench.py --workload ga_gigapath --steps 50 > $OUT/bench_ga_gigapath.json 2> $OUT/bench_ga_gigapath.log
 python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
+fi
 # the training lines are host-sensitive (0.11 ms of Python per step against 0.16 ms of GPU time at N = 10 000; the boxes' hosts are
 # shared): three runs each, the fastest is kept, all three values go to bench_train_runs.log
 best_of3() {   # out-file, bench args...
@@ -54,12 +59,14 @@ PY
 }
 best_of3 $OUT/bench_train_n10k.json --workload train > $OUT/bench_train_runs.log
 best_of3 $OUT/bench_train_n50k.json --workload train --train-n 50000 >> $OUT/bench_train_runs.log
+if [ -z "$ONLY_TRAIN" ]; then
 run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline --no-secondary
 run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
 run_stats bench_ga_uni_f16x3_b64 --workload ga_uni --steps 10 --warmup 3 --no-b1 --no-cpu-baseline
 run_stats bench_ga_clip_l_f16x3_b64 --workload ga_clip_l --steps 10 --warmup 3 --no-b1 --no-cpu-baseline
 run_stats bench_ga_gigapath --workload ga_gigapath --steps 50 --warmup 5 --no-cpu-baseline
 run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
+fi
 run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
 run_stats bench_train_n50k --workload train --train-n 50000 --steps 200 --warmup 20 --no-cpu-baseline
 tail -c 1500 $OUT/bench_driver_args.json; echo
