@@ -236,3 +236,30 @@ def test_optimizer_launch_that_also_repacks_matches_the_plain_sequence(D, Di, K,
     finally:
         ops.ga_train_step = orig
     assert opt.poll_skipped(0) == ref_opt.poll_skipped(0) and opt.skipped_steps == 1
+
+
+@pytest.mark.parametrize("extra_numel", [3, 16])
+def test_in_step_optimizer_refuses_a_flat_buffer_it_cannot_serve_and_the_caller_steps_as_before(extra_numel):
+    """acmil_ga_train_step_adamw needs the module's parameters to tile the optimizer's flat buffer, 16-byte aligned: an optimizer that
+    also owns a foreign parameter in front of them (3 floats: misaligned -> ACMIL_ERR_UNSUPPORTED; 16 floats: aligned but not covered
+    -> ACMIL_ERR_SHAPE) is refused BEFORE anything is launched; train_step then returns opt_step_id None, the plain sequence runs and
+    gives the same parameters as an optimizer over the module alone (the foreign parameter has zero gradient: untouched but for decay)."""
+    from acmil_amd.optim import FlatAdamW
+    T, conf, dev, ref_model, ref_bucket, ref_opt = _setup(384, 128, 5, 3, plain=True)
+    _, _, _, model, _, _ = _setup(384, 128, 5, 3)
+    model.load_state_dict(ref_model.state_dict())
+    extra = torch.nn.Parameter(torch.zeros(extra_numel, device=dev))
+    opt = FlatAdamW([extra] + list(model.parameters()), lr=conf.lr, weight_decay=conf.wd, on_step=model.invalidate_packed)
+    opt.pack_hook = model.adamw_pack_hook(opt)
+    bags = _bags(3, 500, 384, seed=7)
+    for i, x in enumerate(bags):
+        y = torch.tensor([i % 3], device=dev)
+        xb = x.to(dev).unsqueeze(0)
+        ref_model.train_step(xb, y, guard_flag=ref_opt.guard_flag)
+        ref_opt.step(track_flag=True)
+        _, out = model.train_step(xb, y, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True)
+        assert out["opt_step_id"] is None
+        opt.step(track_flag=True)
+        assert torch.equal(opt.flat[extra_numel:], ref_opt.flat), "step %d" % i
+    assert model._opt_in_step_refused
+    assert opt.poll_skipped(0) == [] and float(extra.detach().abs().sum()) == 0.0
