@@ -536,7 +536,9 @@ class ACMIL_GA(_GatedBase):
                       and not self.__dict__.get("_opt_in_step_refused"))
             key = (precision, dev, id(optimizer), self._param_key(params)) if opt_ok else None
             valid = opt_ok and self.__dict__.get("_step_pack_key") == key + (optimizer.mutations,)
-            use_in_step = opt_ok and in_step and guard_flag is not None and optimizer.can_run_in_step()
+            # (never inside a multi-rank job: the update would run on this rank's local gradients, ahead of the all-reduce)
+            use_in_step = (opt_ok and in_step and guard_flag is not None and optimizer.can_run_in_step()
+                           and not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1))
             if not use_in_step:
                 out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
                                         guard_flag=guard_flag, rng=self._step_rng)

@@ -53,7 +53,11 @@ def main():
     for step in range(3):
         bad = (step == 1 and rank == 1)
         x, y = bag_of(rank, step, bad)
-        model.train_step(x.to(dev).unsqueeze(0), torch.tensor([y], device=dev), uniforms=uniforms[step], guard_flag=opt.guard_flag)
+        # optimizer handed over as train_one_epoch does: inside a multi-rank job the step must NOT apply the update itself (it would run
+        # on this rank's local gradients), whatever in_step says -- it only learns whose fused launches keep its packed weights current
+        _, out = model.train_step(x.to(dev).unsqueeze(0), torch.tensor([y], device=dev), uniforms=uniforms[step], guard_flag=opt.guard_flag,
+                                  optimizer=opt, track_flag=True, in_step=(step != 2))
+        assert out["opt_step_id"] is None, "the step applied the optimizer ahead of the all-reduce"
         bucket.sync_from_grads()
         bucket.allreduce_mean(world)
         sid = opt.step(track_flag=True)

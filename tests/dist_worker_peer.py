@@ -46,7 +46,10 @@ def main():
     for step in range(3):
         bad = (step == 1 and rank == 1)
         x, y = bag_of(rank, step, bad)
-        model.train_step(x.to(dev).unsqueeze(0), torch.tensor([y], device=dev), uniforms=uniforms[step], guard_flag=opt.guard_flag)
+        # (optimizer handed over as train_one_epoch does: in a multi-rank job the step never applies the update itself)
+        _, out = model.train_step(x.to(dev).unsqueeze(0), torch.tensor([y], device=dev), uniforms=uniforms[step], guard_flag=opt.guard_flag,
+                                  optimizer=opt, track_flag=True)
+        assert out["opt_step_id"] is None, "the step applied the optimizer ahead of the gradient reduction"
         bucket.sync_from_grads()
         before = bucket.flat.clone()
         bucket.allreduce_mean(world)                               # no-op: the optimizer launch reduces
