@@ -576,13 +576,29 @@ __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restric
     const int cb = blockIdx.x * 64;
     const int tiles_x = (side + TM_PT - 1) / TM_PT;
     const int ty0 = (blockIdx.y / tiles_x) * TM_PT, tx0 = (blockIdx.y % tiles_x) * TM_PT;
-#pragma unroll 4
-    for (int idx = threadIdx.x; idx < (TM_PT + 6) * (TM_PT + 6) * 16; idx += 256) {
-        const int e = idx >> 4, c4 = idx & 15;
-        const int yy = ty0 + e / (TM_PT + 6) - 3, xx = tx0 + e % (TM_PT + 6) - 3;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (yy >= 0 && yy < side && xx >= 0 && xx < side) v = *(const f32x4*)(in + ((size_t)yy * side + xx) * C + cb + 4 * c4);
-        *(f32x4*)(tile + e * 64 + 4 * c4) = v;
+    // ALL of a thread's 13 halo quads in flight at once (round 5).  The loop used to be unrolled by 4: four dependent memory round trips
+    // per tile, most of the ~9 us a workgroup spent on a tile with only three workgroups per CU to overlap them -- 136.5 -> 109.0 us
+    // per launch on one box; with the next row's weight quads requested before a row is computed (below) 107.3 us.  Halo element
+    // e = (tid >> 4) + 16 it: its (row, column) advance by one row + 2 columns per iteration (no division by 14 per element).
+    {
+        constexpr int HW = TM_PT + 6, HN = HW * HW * 16, HIT = (HN + 255) / 256;
+        f32x4 hv[HIT];
+        const int c4 = (int)threadIdx.x & 15;
+        int hr = (int)(threadIdx.x >> 4) / HW, hc = (int)(threadIdx.x >> 4) % HW;
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            const int yy = ty0 + hr - 3, xx = tx0 + hc - 3;
+            hv[it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx < HN && yy >= 0 && yy < side && xx >= 0 && xx < side) hv[it] = *(const f32x4*)(in + ((size_t)yy * side + xx) * C + cb + 4 * c4);
+            hr += 1; hc += 16 - HW;
+            if (hc >= HW) { hc -= HW; hr += 1; }
+        }
+#pragma unroll
+        for (int it = 0; it < HIT; ++it) {
+            const int idx = (int)threadIdx.x + 256 * it;
+            if (idx < HN) *(f32x4*)(tile + (idx >> 4) * 64 + 4 * (idx & 15)) = hv[it];
+        }
     }
     __syncthreads();
     const int c = cb + 4 * cq, y = ty0 + py, px0 = 4 * ph;
@@ -591,12 +607,15 @@ __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restric
     f32x2 acc[4][2];
 #pragma unroll
     for (int px = 0; px < 4; ++px) { acc[px][0] = f32x2{b[0], b[1]}; acc[px][1] = f32x2{b[2], b[3]}; }
-    // one kernel row at a time: its 7 weight quads (L1-resident: 49 x C floats per launch) and the 10 halo quads this half row needs
-#pragma unroll 1
-    for (int ky = 0; ky < 7; ++ky) {
-        f32x4 w[7];
+    // one kernel row at a time: its 7 weight quads (L1-resident: 49 x C floats per launch) and the 10 halo quads this half row needs.
+    // Two register sets: the quads of row ky + 1 are requested before row ky is computed (rolled in pairs -- fully unrolled, hipcc
+    // hoisted all 49 loads: 168 VGPRs and 1.3 KB of scratch per lane)
+    f32x4 w0[7], w1[7];
+    auto load_w = [&](f32x4 (&w)[7], int ky) {
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) w[kx] = *(const f32x4*)(weff + (size_t)(ky * 7 + kx) * C + c);
+    };
+    auto row = [&](const f32x4 (&w)[7], int ky) {
         f32x4 v[10];
 #pragma unroll
         for (int i = 0; i < 10; ++i) v[i] = *(const f32x4*)(tile + ((py + ky) * (TM_PT + 6) + px0 + i) * 64 + 4 * cq);
@@ -607,7 +626,20 @@ __global__ __launch_bounds__(256, 3) void tm_ppeg2_kernel(const float* __restric
                 acc[px][0] = __builtin_elementwise_fma(f32x2{w[kx][0], w[kx][1]}, f32x2{v[px + kx][0], v[px + kx][1]}, acc[px][0]);
                 acc[px][1] = __builtin_elementwise_fma(f32x2{w[kx][2], w[kx][3]}, f32x2{v[px + kx][2], v[px + kx][3]}, acc[px][1]);
             }
+    };
+    load_w(w0, 0);
+#pragma unroll 1
+    for (int kp = 0; kp < 3; ++kp) {
+        load_w(w1, 2 * kp + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        row(w0, 2 * kp);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(w0, 2 * kp + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        row(w1, 2 * kp + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    row(w0, 6);
 #pragma unroll
     for (int px = 0; px < 4; ++px)
         if (tx0 + px0 + px < side)
