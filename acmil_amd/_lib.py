@@ -110,10 +110,26 @@ SIGNATURES = {
                                   [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
                                   [C.c_ulonglong, C.c_ulonglong] +
                                   [_vp, C.c_longlong, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong, _vp, _vp]),
+    "acmil_ga_train_step_group_workspace_bytes": (_sz, [_i] * 7),
+    # x, x_dtype, nbags, bag_rows (host), packed, repack | parameters | gradients | D Di Da K C mode | labels uniforms k_top m_mask |
+    # losses sub slide A_out topk midx guard_flag | workspace stream | seed offset | adamw (struct acmil_adamw_args* or NULL)
+    "acmil_ga_train_step_group": (_i, [_vp, _i, _i, C.POINTER(_i), _vp, _i] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 +
+                                  [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_i] * 6 + [_vp, _vp, _i, _i] + [_vp] * 7 + [_vp, _vp] +
+                                  [C.c_ulonglong, C.c_ulonglong, _vp]),
+    "acmil_ga_adamw_supported": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 3 + [_i] * 6 + [_vp, C.c_longlong, _vp, _vp]),
     "acmil_ga_adamw_pack": (_i, [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] + [_vp] * 7 + [C.POINTER(_vp), C.POINTER(_vp), _vp, _vp] +
                             [_i] * 6 + [_vp] + [_vp, C.c_longlong, _vp, _vp, C.c_float, C.c_double, C.c_double, C.c_float, C.c_float, C.c_longlong,
                                                 _vp, _vp, _vp, _vp]),
 }
+
+
+
+class AdamwArgs(C.Structure):
+    """struct acmil_adamw_args (include/acmil_hip.h)"""
+    _fields_ = [("flat_params", _vp), ("n_flat", C.c_longlong), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("lr", C.c_float),
+                ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("weight_decay", C.c_float), ("step", C.c_longlong),
+                ("skipped", _vp), ("flag_report", _vp)]
+
 
 _lib = None
 

@@ -514,17 +514,27 @@ class ACMIL_GA(_GatedBase):
         self._last = out
         return losses, out
 
-    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None, optimizer=None, track_flag=False, in_step=True):
+    def _train_step_fused(self, xb, label, uniforms, params, k_top, guard_flag=None, precision=None, optimizer=None, track_flag=False, in_step=True,
+                          rows=None):
         """The whole step enqueued by one library call (csrc/ga_step.hip: 8 launches).  The packed weights are rebuilt inside
         the call every step (the parameters change between steps); the range status of the split-f16 score pass is read once,
-        after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients."""
+        after the call -- a flagged step is repeated in fp32 arithmetic before anybody sees its gradients.
+        rows (train_step_batch): xb holds a GROUP of bags back to back, rows = their patch counts, label [G] -- one step on the mean
+        gradient of the group (acmil_ga_train_step_group); its exact-fp32 form runs bag by bag (_train_step_group_fp32)."""
         dev = xb.device
         m_mask = int(k_top * self.mask_drop)
         grads = [p.grad for p in params]
         if label.dtype != torch.int64:
             label = label.to(torch.int64)
 
+        def step_call(precision, st, **kw):
+            if rows is None:
+                return ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, **kw)
+            return ops.ga_train_step_group(xb, rows, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, **kw)
+
         def run(precision):
+            if rows is not None and precision == "fp32":
+                return self._train_step_group_fp32(xb, rows, label, uniforms, params, grads, k_top, guard_flag)
             cache = self.__dict__.setdefault("_step_packed", {})
             st = cache.get((precision, dev))
             if st is None:
@@ -539,23 +549,22 @@ class ACMIL_GA(_GatedBase):
             # (never inside a multi-rank job: the update would run on this rank's local gradients, ahead of the all-reduce)
             use_in_step = (opt_ok and in_step and guard_flag is not None and optimizer.can_run_in_step()
                            and not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1))
+            if use_in_step and not self._in_step_supported(optimizer, params, grads, st[1]):
+                use_in_step = False
             if not use_in_step:
-                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
-                                        guard_flag=guard_flag, rng=self._step_rng)
+                out = step_call(precision, st, repack=not valid, guard_flag=guard_flag, rng=self._step_rng)
                 if opt_ok:
                     self._step_pack_key = key + (optimizer.mutations,)      # packed now holds exactly the values this step ran on
                 out["opt_step_id"] = None
                 return out
+            # (whether the closing launch can serve this parameter set was asked BEFORE anything is enqueued -- _in_step_supported,
+            # acmil_ga_adamw_supported -- so an error from the call itself is a real failure and propagates: ADVICE r5)
             args = optimizer.in_step_args(track_flag)
             try:
-                out = ops.ga_train_step(xb, st[0], st[1], precision, params, grads, label, uniforms, k_top, m_mask, repack=not valid,
-                                        guard_flag=guard_flag, rng=self._step_rng, adamw=args)
-            except RuntimeError as e:
+                out = step_call(precision, st, repack=not valid, guard_flag=guard_flag, rng=self._step_rng, adamw=args)
+            except Exception:
                 optimizer.in_step_abort()
-                if "(-2)" not in str(e) and "(-1)" not in str(e):     # anything but "unsupported" / "shape": a real failure
-                    raise
-                self._opt_in_step_refused = True                       # e.g. parameters not 16-byte aligned in the flat buffer: nothing was launched
-                return run(precision)
+                raise
             out["opt_step_id"] = optimizer.in_step_done()             # (calls invalidate_packed through on_step: the eval caches are stale now)
             self._step_pack_key = key + (optimizer.mutations,)
             return out
@@ -566,6 +575,116 @@ class ACMIL_GA(_GatedBase):
             out = run("fp32")
             out["range_fallback"] = True
         return out["losses"], out
+
+    def _in_step_supported(self, optimizer, params, grads, dims) -> bool:
+        """Can the step's closing launch (finish + AdamW + re-pack, csrc/ga_opt_step.hip) serve this parameter set?  A side-effect-free
+        query of the library (alignment of the three matrices / gradients / moments, the parameters tiling the optimizer's flat
+        buffer), remembered per set of storages; a refusal is permanent for that set and nothing has been launched."""
+        key = (id(optimizer), tuple(p.data_ptr() for p in params), tuple(g.data_ptr() for g in grads))
+        hit = self.__dict__.get("_in_step_ok")
+        if hit is None or hit[0] != key:
+            ok = ops.ga_adamw_supported(dims, params, grads, optimizer.flat, optimizer.exp_avg, optimizer.exp_avg_sq)
+            hit = self.__dict__["_in_step_ok"] = (key, ok)
+            if not ok:
+                self._opt_in_step_refused = True
+        return hit[1]
+
+    def _train_step_group_fp32(self, xb, rows, labels, uniforms, params, grads, k_top, guard_flag):
+        """The exact-fp32 form of a group step (the repeat of a range-flagged group; precision='fp32' models): the one-call step bag
+        by bag, gradients averaged -- same mathematics as acmil_ga_train_step_group, op for op the reference's arithmetic."""
+        G = len(rows)
+        acc = [torch.zeros_like(g) for g in grads]
+        outs, off = [], 0
+        cache = self.__dict__.setdefault("_step_packed", {})
+        st = cache.get(("fp32", xb.device))
+        if st is None:
+            packed, dims = self._packed("fp32") if self.precision != "fp32" else self._packed()
+            st = cache[("fp32", xb.device)] = (packed.clone(), dims)
+        m_mask = int(k_top * self.mask_drop)
+        for b, n in enumerate(rows):
+            o = ops.ga_train_step(xb[off:off + n], st[0], st[1], "fp32", params, grads, labels[b:b + 1],
+                                  None if uniforms is None else uniforms[b], k_top, m_mask, repack=(b == 0), guard_flag=guard_flag,
+                                  rng=None if self._step_rng is None else (self._step_rng[0], self._step_rng[1] * 65536 + b))
+            torch._foreach_add_(acc, grads, alpha=1.0 / G)
+            outs.append(o)
+            off += n
+        torch._foreach_copy_(grads, acc)
+        offs = [0]
+        for n in rows:
+            offs.append(offs[-1] + n)
+        has_slide = outs[0]["slide_pred"] is not None
+        return {"losses": torch.stack([o["losses"] for o in outs]), "sub_preds": torch.stack([o["sub_preds"] for o in outs]),
+                "slide_pred": torch.stack([o["slide_pred"] for o in outs]) if has_slide else None,
+                "A_out": torch.cat([o["A_out"] for o in outs], dim=1), "offsets": offs,
+                "topk_idx": torch.stack([o["topk_idx"] for o in outs]) if k_top > 0 else None,
+                "masked_idx": torch.stack([o["masked_idx"] for o in outs]) if m_mask > 0 else None,
+                "range_status": outs[-1]["range_status"], "opt_step_id": None}
+
+    @torch.no_grad()
+    def train_step_batch(self, bags, labels, uniforms: Optional[torch.Tensor] = None, guard_flag: Optional[torch.Tensor] = None,
+                         precision: Optional[str] = None, optimizer=None, track_flag: bool = False, in_step: bool = True):
+        """ONE training step on a GROUP of G <= 16 slides: the parameter gradients are the MEAN of the slides' per-slide gradients --
+        exactly what G data-parallel ranks compute per step, on one GPU, and under data parallelism `bags per rank`
+        (one all-reduce per G slides).  Not in the reference, whose loop is B = 1 (Step3_WSI_classification_ACMIL.py:189-221);
+        per slide the forward (STKIM included), the three losses and the backward are the same as `train_step`.
+        bags: a list of [N_b, D_feat] CUDA tensors of one dtype (concatenated here: one copy), or a pair (x [sum N_b, D_feat], rows)
+        with the bags' rows already back to back (staging.staged_train_groups delivers that: no copy).  labels [G] int64 on the GPU;
+        uniforms [G, K, k] to inject the STKIM draws (a list of per-bag [K, k_b] tensors where a bag is smaller than n_masked_patch).
+        Everything else as `train_step`.  Returns (losses [G, 4], outputs dict:
+        sub_preds [G,K,C], slide_pred [G,C], A_out [K, sum N_b] with `offsets`, topk_idx / masked_idx [G,K,.] bag-local)."""
+        self._check_dropout()
+        if isinstance(bags, tuple) and len(bags) == 2 and torch.is_tensor(bags[0]):
+            xb, rows = bags[0], [int(r) for r in bags[1]]
+        else:
+            bags = [b[0] if b.dim() == 3 else b for b in bags]
+            rows = [int(b.shape[0]) for b in bags]
+            if any(b.dtype != bags[0].dtype for b in bags):
+                bags = [b.float() for b in bags]
+            xb = bags[0] if len(bags) == 1 else torch.cat(bags, dim=0)
+        if not xb.is_contiguous():
+            xb = xb.contiguous()
+        G = len(rows)
+        if not 1 <= G <= ops.MAX_GROUP:
+            raise RuntimeError("acmil_amd: train_step_batch takes 1 .. %d bags per step" % ops.MAX_GROUP)
+        params = self._all_params()
+        masking = self.n_masked_patch > 0 and self.training
+        k_top = min(self.n_masked_patch, min(rows)) if masking else 0
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+        fused = self._is_fused() and getattr(self, "fused_step", True)
+        # bags smaller than n_masked_patch clamp k per bag (transformer.py:313) and the wide / composed families have no group kernel:
+        # those groups run bag by bag with the gradients averaged -- the same mathematics
+        if not fused or (masking and min(rows) < self.n_masked_patch):
+            return self._train_step_group_serial(xb, rows, labels, uniforms, params, guard_flag, precision)
+        self._step_rng = self._next_rng() if (masking and uniforms is None) else None
+        losses, out = self._train_step_fused(xb, labels, uniforms, params, k_top, guard_flag, precision, optimizer, track_flag, in_step, rows=rows)
+        self._last = out
+        return losses, out
+
+    def _train_step_group_serial(self, xb, rows, labels, uniforms, params, guard_flag, precision):
+        """A group step as G single-slide steps with averaged gradients (families / bag sizes the group kernels do not take)."""
+        G = len(rows)
+        grads = [p.grad for p in params]
+        acc = [torch.zeros_like(g) for g in grads]
+        outs, ls, off = [], [], 0
+        flagged = None
+        for b, n in enumerate(rows):
+            l, o = self.train_step(xb[off:off + n].unsqueeze(0), labels[b:b + 1], None if uniforms is None else uniforms[b], guard_flag=guard_flag,
+                                   precision=precision)
+            if guard_flag is not None:
+                flagged = guard_flag.clone() if flagged is None else torch.maximum(flagged, guard_flag)
+            torch._foreach_add_(acc, [p.grad for p in params], alpha=1.0 / G)
+            outs.append(o); ls.append(l)
+            off += n
+        torch._foreach_copy_(grads, acc)
+        for p, g in zip(params, grads):
+            p.grad = g
+        if guard_flag is not None and flagged is not None:
+            guard_flag.copy_(flagged)
+        out = {"per_bag": outs, "opt_step_id": None}
+        self._last = out
+        return torch.stack(ls), out
 
     def adamw_pack_hook(self, optimizer):
         """For FlatAdamW.pack_hook: lets the optimizer's launch re-pack this module's weights (acmil_ga_adamw_pack) so that the next
@@ -659,13 +778,10 @@ class _AdamwPackHook:
             return False
         key = ("f16x3", dev, id(opt), m._param_key(params))
         was_valid = m.__dict__.get("_step_pack_key") == key + (opt.mutations,)
-        try:
-            ops.ga_adamw_pack(st[0], st[1], params, [p.grad for p in params], adamw_args, skip_flag)
-        except RuntimeError as e:
-            if "(-2)" not in str(e) and "(-1)" not in str(e):
-                raise
-            m._opt_in_step_refused = True      # e.g. parameters not 16-byte aligned inside the flat buffer: nothing was launched
+        grads = [p.grad for p in params]
+        if not m._in_step_supported(opt, params, grads, st[1]):      # asked before anything is launched; any error below is a real one
             return False
+        ops.ga_adamw_pack(st[0], st[1], params, grads, adamw_args, skip_flag)
         # an applied launch rewrites every packed copy; a launch the device skips (range flag) leaves the buffer as it was
         self._pending = key if (was_valid or skip_flag is None) else None
         return True

@@ -285,10 +285,11 @@ int gb_run(const GbRun& r, GbDefer* defer) {
     int blocks = 0;
     // 3-5 as ONE kernel per 64-patch tile when the caller holds the pre-split operands (training step, split arithmetic)
     rc = ACMIL_ERR_UNSUPPORTED;
-    if (r.w16 && r.wT16 && !r.dA_ext && r.mode != ACMIL_MODE_F32 && gb_use_tile())
-        rc = ga_bwd_tile_launch(r.h, r.A_out, r.stats, r.ck, r.coef, r.Ww, r.d_afeat, bcat, r.w16, r.wT16, G, dpre, part, N, K, Di, st, &blocks);
+    if (r.w16 && r.wT16 && !r.dA_ext && r.mode != ACMIL_MODE_F32 && (gb_use_tile() || r.seg))
+        rc = ga_bwd_tile_launch(r.h, r.A_out, r.stats, r.ck, r.coef, r.Ww, r.d_afeat, bcat, r.w16, r.wT16, G, dpre, part, N, K, Di, st, &blocks,
+                                r.seg, r.wT_ext);
     if (rc == ACMIL_OK) {
-    } else if (rc != ACMIL_ERR_UNSUPPORTED) {
+    } else if (rc != ACMIL_ERR_UNSUPPORTED || r.seg) {       // (a group of bags has no three-launch form)
         return rc;
     } else {
         // 3 G = h [Wv;Wu]^T + [bv;bu]

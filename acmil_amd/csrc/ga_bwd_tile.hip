@@ -40,7 +40,13 @@ struct GbTileArgs {
     const _Float16* w16;                  // f16 hi / lo of [Wv;Wu] [256][Di], fragment order (ga_common.h::ga_frag_off)
     const __bf16* wT16;                   // bf16 hi / lo of [[Wv;Wu]^T | d_afeat^T | 0] [Di][288], fragment order
     float *dS, *dpre, *part;
-    int N, K;
+    int N, K;                             // N: rows of ALL bags of the launch (= the row stride of A)
+    // a GROUP of bags (multi-bag training step; one bag: seg = ga_seg_single(N), strides unused): tiles are cut per bag, and what
+    // depends on the bag's softmax / loss comes per bag: stats [bag][16], ck [bag][16], coef [bag][64], d_afeat [bag][K][Di],
+    // and the d_afeat K slots of the third product's B operand: wT_ext [bag][Di / 32][2 planes][64 lanes][8] bf16 (ga_frag_off
+    // with one K step; null: the slots inside wT16 itself)
+    GaSeg seg;
+    const __bf16* wT_ext;
 };
 
 #define BT_THREADS 512
@@ -63,8 +69,13 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     constexpr int REC_OFF = MASK_OFF + ROWS * MASK_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i31 = lane & 31, hi = lane >> 5;
-    const int N = a.N, K = a.K;
-    const int n0 = blockIdx.x * ROWS;
+    const int K = a.K, ldA = a.N;
+    const GaSegTile sg = ga_seg_find<ROWS>(a.seg, blockIdx.x);
+    const int n0 = sg.n0, N = sg.nend, bag = sg.bag;          // N: end row of this tile's bag
+    const float* const stats_b = a.stats + 16 * bag;
+    const float* const ck_b = a.ck + 16 * bag;
+    const float* const coef_b = a.coef ? a.coef + 64 * bag : nullptr;
+    const float* const daf_b = a.d_afeat + (size_t)bag * K * DI;
     unsigned char* const mask_lds = (unsigned char*)(smem + MASK_OFF);
 #ifdef BT_PROF
     const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
@@ -181,26 +192,26 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             const int n = n0 + RPW * wave + lr;
             const bool ok = lk < K && n < N;
             const int kc = lk < K ? lk : 0;
-            const float s = a.A[(size_t)kc * N + (n < N ? n : N - 1)];
-            const float M = a.stats[2 * kc], Lsum = a.stats[2 * kc + 1];
+            const float s = a.A[(size_t)kc * ldA + (n < N ? n : N - 1)];
+            const float M = stats_b[2 * kc], Lsum = stats_b[2 * kc + 1];
             const bool masked = !ok || !(s > -5e8f);                  // masked_fill(-1e9) positions, padded branches, rows past the bag
             P_all = masked ? 0.0f : __expf(s - M) * __builtin_amdgcn_rcpf(Lsum);
-            if (a.coef) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (rows / columns >= K are zero in the table)
+            if (coef_b) {      // d diff_loss / dA[i][n] = p_i[n] * sum_j coef[i][j] p_j[n]   (rows / columns >= K are zero in the table)
                 float sdiv = 0.0f;
 #pragma unroll
                 for (int j = 0; j < KP; ++j) {
                     const float Pj = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (RPW * j + lr), __builtin_bit_cast(int, P_all)));
-                    sdiv = fmaf(lk < KP ? a.coef[lk * KP + j] : 0.0f, Pj, sdiv);
+                    sdiv = fmaf(lk < KP ? coef_b[lk * KP + j] : 0.0f, Pj, sdiv);
                 }
                 Q_all = P_all * sdiv;
             }
         }
-        const float ckv = lane < K ? a.ck[lane] : 0.0f;
+        const float ckv = lane < K ? ck_b[lane] : 0.0f;
         float daf[KP][FPL], ww[KP][2], ck[KP];
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const int kc = k < K ? k : 0;
-            const bt_fv dv = *(const bt_fv*)(a.d_afeat + (size_t)kc * DI + FPL * lane);
+            const bt_fv dv = *(const bt_fv*)(daf_b + (size_t)kc * DI + FPL * lane);
 #pragma unroll
             for (int f = 0; f < FPL; ++f) daf[k][f] = dv[f];
             typedef float bt_f2 __attribute__((ext_vector_type(2)));
@@ -317,6 +328,8 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[m][r] = 0.0f;
         const __bf16* tb = a.wT16 + (size_t)ct * (BT_KX / 16) * 1024 + lane * 8;
+        // the last K step (d_afeat slots) of a group launch comes from the bag's own fragment pair
+        const __bf16* te = a.wT_ext ? a.wT_ext + ((size_t)bag * NCT + ct) * 1024 + lane * 8 : tb + 1024 * (NKS3 - 1);
         u32x4 bq[BT_PF][2];
 #pragma unroll
         for (int j = 0; j < BT_PF; ++j) {
@@ -341,8 +354,9 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 acc3[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl, acc3[m], 0, 0, 0);
             }
             if (ks + BT_PF < NKS3) {
-                bq[ks % BT_PF][0] = *(const u32x4*)(tb + 1024 * (ks + BT_PF));
-                bq[ks % BT_PF][1] = *(const u32x4*)(tb + 1024 * (ks + BT_PF) + 512);
+                const __bf16* src = (ks + BT_PF == NKS3 - 1) ? te : tb + 1024 * (ks + BT_PF);
+                bq[ks % BT_PF][0] = *(const u32x4*)src;
+                bq[ks % BT_PF][1] = *(const u32x4*)(src + 512);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -382,7 +396,7 @@ static int bt_rows(int N) {
     if (forced == 32 || forced == 64) return forced;
     return (N + 63) / 64 <= 320 ? 32 : 64;
 }
-size_t ga_bwd_tile_part_records(int N) { return (size_t)(N + 31) / 32; }        // upper bound (workspace sizing)
+size_t ga_bwd_tile_part_records(int N) { return (size_t)(N + 31) / 32 + GA_SEG_MAX; }        // upper bound (workspace sizing; every bag of a group may end on a partial tile)
 
 template <int KP, int DI, int ROWS>
 static int bt_launch(const GbTileArgs& a, int tiles, hipStream_t st) {
@@ -405,13 +419,15 @@ static int bt_launch(const GbTileArgs& a, int tiles, hipStream_t st) {
 // *records = partial records written (one per tile)
 int ga_bwd_tile_launch(const float* h, const float* A, const float* stats, const float* ck, const float* coef, const float* Ww,
                        const float* d_afeat, const float* bcat, const void* w16, const void* wT16, float* dS, float* dpre,
-                       float* part, int N, int K, int Di, hipStream_t st, int* records) {
+                       float* part, int N, int K, int Di, hipStream_t st, int* records, const GaSeg* seg, const void* wT_ext) {
     const int KP = (K <= 1) ? 1 : (K <= 5) ? 5 : 8;
     if (KP == 8 || (Di != 128 && Di != 256)) return ACMIL_ERR_UNSUPPORTED;
+    if (seg && (seg->n < 1 || seg->n > GA_SEG_MAX || seg->row0[seg->n] != N || !wT_ext)) return ACMIL_ERR_SHAPE;
     GbTileArgs a;
     a.h = h; a.A = A; a.stats = stats; a.ck = ck; a.coef = coef; a.Ww = Ww; a.d_afeat = d_afeat; a.bcat = bcat;
     a.w16 = (const _Float16*)w16; a.wT16 = (const __bf16*)wT16; a.dS = dS; a.dpre = dpre; a.part = part; a.N = N; a.K = K;
-    const int rows = bt_rows(N), tiles = (N + rows - 1) / rows;
+    a.seg = seg ? *seg : ga_seg_single(N); a.wT_ext = seg ? (const __bf16*)wT_ext : nullptr;
+    const int rows = bt_rows(N), tiles = ga_seg_tiles(a.seg, rows);
     *records = tiles;
 #define BT_PICK(KP_, DI_) (rows == 32 ? bt_launch<KP_, DI_, 32>(a, tiles, st) : bt_launch<KP_, DI_, 64>(a, tiles, st))
     if (KP == 1) return Di == 128 ? BT_PICK(1, 128) : BT_PICK(1, 256);

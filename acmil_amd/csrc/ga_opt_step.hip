@@ -357,3 +357,25 @@ extern "C" int acmil_ga_adamw_pack(float* W1, float* Wv, float* bv, float* Wu, f
     return go_launch(t, nullptr, nullptr, nullptr, ga_kp(K), packed, ga_layout(D, Di, K, C, mode), flat_params, exp_avg, exp_avg_sq, lr, beta1, beta2,
                      eps, weight_decay, step, skip_flag, skipped, flag_report, (hipStream_t)stream);
 }
+
+// The refusal of the closing launch as a QUERY (nothing is launched): ACMIL_OK when acmil_ga_train_step_adamw / acmil_ga_train_step_group
+// (adamw) / acmil_ga_adamw_pack would accept this parameter set, else the code they would return before their first launch.
+extern "C" int acmil_ga_adamw_supported(const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* Ww,
+                                        const float* bw, const float* const* Wc, const float* const* bc, const float* Ws, const float* bs,
+                                        const float* dW1, const float* dWv, const float* dWu, int D, int Di, int Da, int K, int C, int mode,
+                                        const float* flat_params, long long n_flat, const float* exp_avg, const float* exp_avg_sq) {
+    int rc = ga_check_dims(D, Di, Da, K, C);
+    if (rc != ACMIL_OK) return rc;
+    if (K > GO_MAXK) return ACMIL_ERR_UNSUPPORTED;
+    if (!W1 || !Wv || !bv || !Wu || !bu || !Ww || !bw || !Wc || !bc || !dW1 || !dWv || !dWu) return ACMIL_ERR_NULL;
+    if ((Ws == nullptr) != (bs == nullptr)) return ACMIL_ERR_NULL;
+    GoTensors t;
+    memset(&t, 0, sizeof(t));
+    t.W1 = (float*)W1; t.Wv = (float*)Wv; t.bv = (float*)bv; t.Wu = (float*)Wu; t.bu = (float*)bu; t.Ww = (float*)Ww; t.bw = (float*)bw;
+    t.Ws = (float*)Ws; t.bs = (float*)bs; t.dW1 = (float*)dW1; t.dWv = (float*)dWv; t.dWu = (float*)dWu;
+    for (int k = 0; k < K; ++k) {
+        if (!Wc[k] || !bc[k]) return ACMIL_ERR_NULL;
+        t.Wc[k] = (float*)Wc[k]; t.bc[k] = (float*)bc[k];
+    }
+    return go_check(t, D, Di, K, C, mode, flat_params, n_flat, exp_avg, exp_avg_sq);
+}

@@ -5,6 +5,7 @@
 // plus their C entry points (include/acmil_hip.h).  All of it is HBM-bound streaming / selection work:
 // coalesced float4 row reads, LDS for the per-tile probabilities, wave shuffles for reductions.
 #include "ga_common.h"
+#include "ga_train_internal.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-k.  Order-preserving key: (monotone uint32 image of the fp32 score) << 32 | (0xFFFFFFFF - index),
@@ -113,7 +114,10 @@ __device__ static inline float stkim_uniform(unsigned long long seed, unsigned l
 #else
 #define STKIM_STAMP(slot, cond) do { } while (0)
 #endif
-__global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, int N, int K,
+// seg: the bags of the launch (one for the stand-alone selection; a group for the multi-bag training step): chunk c of the grid
+// belongs to bag seg-find(c); scores / A_mask are [K][ldA] with bag b in columns row0[b] .. (indices in the keys and in the outputs
+// are LOCAL to the bag, as the reference's are); one arrival word per bag, the last block of a BAG finishes that bag's K branches.
+__global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restrict__ scores, float* __restrict__ A_mask, GaSeg seg, int ldA, int K,
                                                           int k, int m, const float* __restrict__ uniforms,
                                                           unsigned long long rng_seed, unsigned long long rng_offset,
                                                           unsigned long long* __restrict__ cand, unsigned* __restrict__ arrive,
@@ -121,19 +125,21 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     __shared__ unsigned long long red[2][4];
     __shared__ unsigned sel[4][64];
     __shared__ int is_last;
-    const int chunk = blockIdx.x, br = blockIdx.y, nch = gridDim.x;
+    const int br = blockIdx.y, nch_all = gridDim.x;
+    const GaSegTile sg = ga_seg_find<STKIM_CHUNK>(seg, blockIdx.x);
+    const int bag = sg.bag, N = sg.nend - sg.row0, chunk = blockIdx.x - sg.tile0, nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = blockIdx.x == 0 && blockIdx.y == 0;
     STKIM_STAMP(0, first);
     {
-        const float* row = scores + (size_t)br * N;
+        const float* row = scores + (size_t)br * ldA + sg.row0;
         unsigned long long keys[STKIM_EPT];
 #pragma unroll
         for (int e = 0; e < STKIM_EPT; ++e) {
             const unsigned idx = (unsigned)chunk * STKIM_CHUNK + e * 256 + tid;
             keys[e] = idx < (unsigned)N ? stkim_key(row[idx], idx) : 0ull;
         }
-        unsigned long long* out = cand + ((size_t)br * nch + chunk) * k;
+        unsigned long long* out = cand + ((size_t)br * nch_all + blockIdx.x) * k;
 #ifdef STKIM_PROF
         if (first && keys[0] == 1ull) out[0] = 0ull;      // (the stamp below waits for the loads)
 #endif
@@ -155,9 +161,9 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     STKIM_STAMP(2, first);
     if (tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = atomicAdd(arrive, 1u);
-        is_last = (t == (unsigned)(gridDim.x * gridDim.y) - 1u) ? 1 : 0;
-        if (is_last) atomicExch(arrive, 0u);
+        const unsigned t = atomicAdd(arrive + bag, 1u);
+        is_last = (t == (unsigned)(nch * K) - 1u) ? 1 : 0;
+        if (is_last) atomicExch(arrive + bag, 0u);
     }
     __syncthreads();
     STKIM_STAMP(3, first);
@@ -165,8 +171,9 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
     STKIM_STAMP(4, true);
     const int ncand = nch * k;
     for (int b = wave; b < K; b += 4) {
-        const unsigned long long* c = cand + (size_t)b * ncand;
-        int64_t* trow = topk_idx + (size_t)b * k;
+        const unsigned long long* c = cand + ((size_t)b * nch_all + sg.tile0) * k;
+        const size_t orow = (size_t)bag * K + b;      // output / uniform row of (bag, branch); the Philox stream is keyed on it as well
+        int64_t* trow = topk_idx + orow * k;
         if (ncand <= 64) stkim_merge_wave<1>(c, ncand, k, lane, sel[wave], trow);
         else if (ncand <= 128) stkim_merge_wave<2>(c, ncand, k, lane, sel[wave], trow);
         else if (ncand <= 256) stkim_merge_wave<4>(c, ncand, k, lane, sel[wave], trow);
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
         STKIM_STAMP(5, b == 0);
         if (m > 0) {
             // this lane's uniform: injected (parity tests) or drawn here (uniforms == null); rank = position in argsort ascending
-            const float mine = lane < k ? (uniforms ? uniforms[(size_t)b * k + lane] : stkim_uniform(rng_seed, rng_offset, (unsigned)b, (unsigned)lane)) : 2.0f;
+            const float mine = lane < k ? (uniforms ? uniforms[orow * k + lane] : stkim_uniform(rng_seed, rng_offset, (unsigned)orow, (unsigned)lane)) : 2.0f;
             int rank = 0;
             for (int j = 0; j < k; ++j) {
                 const float uj = __shfl(mine, j);
@@ -185,8 +192,8 @@ __global__ __launch_bounds__(256) void stkim_fused_kernel(const float* __restric
             }
             if (lane < k && rank < m) {
                 const unsigned n = sel[wave][lane];
-                masked_idx[(size_t)b * m + rank] = (int64_t)n;
-                if (A_mask && n < (unsigned)N) A_mask[(size_t)b * N + n] = -1e9f;
+                masked_idx[orow * m + rank] = (int64_t)n;
+                if (A_mask && n < (unsigned)N) A_mask[(size_t)b * ldA + sg.row0 + n] = -1e9f;
             }
         }
         STKIM_STAMP(6, b == 0);
@@ -200,15 +207,28 @@ extern "C" size_t acmil_stkim_workspace_bytes(int N, int K, int k) {
     return 256 + (((size_t)K * nch * k * sizeof(unsigned long long) + 255) & ~(size_t)255);
 }
 
-// shared by acmil_stkim_select and the fused training step (ga_step.hip): one launch; `arrive` must be zero and is left zero
+// candidate scratch of a launch: K rows of (chunks of all bags) x k keys
+size_t stkim_cand_bytes(int N, int nbags, int K, int k) {
+    const size_t nch = (size_t)(N + STKIM_CHUNK - 1) / STKIM_CHUNK + (size_t)(nbags > 1 ? nbags : 0);      // every bag of a group may end on a partial chunk
+    return (((size_t)K * nch * (k > 0 ? k : 1) * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+}
+
+// shared by acmil_stkim_select and the fused training step (ga_step.hip): one launch; `arrive` (one word per bag) must be zero and is left zero
 int stkim_launch(const float* scores, float* A_mask, int N, int K, int k, int m, const float* uniforms, int64_t* topk_idx,
                  int64_t* masked_idx, unsigned long long* cand, unsigned* arrive, hipStream_t st, unsigned long long rng_seed,
-                 unsigned long long rng_offset) {
+                 unsigned long long rng_offset, const GaSeg* seg) {
     if (N <= 0 || K <= 0 || k <= 0 || k > 64 || k > N || m < 0 || m > k) return ACMIL_ERR_SHAPE;
     if (!scores || !topk_idx || !cand || !arrive || (m > 0 && !masked_idx)) return ACMIL_ERR_NULL;      // uniforms null = device draw
-    const int nch = (N + STKIM_CHUNK - 1) / STKIM_CHUNK;
-    if ((size_t)nch * k > 64 * STKIM_MERGE_E) return ACMIL_ERR_UNSUPPORTED;  // N up to ~131k at k=64, ~800k at k=10
-    hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, N, K, k, m, uniforms, rng_seed, rng_offset,
+    const GaSeg one = ga_seg_single(N);
+    const GaSeg& S = seg ? *seg : one;
+    if (S.n < 1 || S.n > GA_SEG_MAX || S.row0[0] != 0 || S.row0[S.n] != N) return ACMIL_ERR_SHAPE;
+    for (int b = 0; b < S.n; ++b) {
+        const int nb = S.row0[b + 1] - S.row0[b];
+        if (nb < k) return ACMIL_ERR_SHAPE;                                            // every bag holds its own top-k
+        if ((size_t)((nb + STKIM_CHUNK - 1) / STKIM_CHUNK) * k > 64 * STKIM_MERGE_E) return ACMIL_ERR_UNSUPPORTED;  // a bag up to ~131k rows at k=64, ~800k at k=10
+    }
+    const int nch = ga_seg_tiles(S, STKIM_CHUNK);
+    hipLaunchKernelGGL(stkim_fused_kernel, dim3(nch, K), dim3(256), 0, st, scores, A_mask, S, N, K, k, m, uniforms, rng_seed, rng_offset,
                        cand, arrive, topk_idx, masked_idx);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
@@ -251,8 +271,9 @@ __global__ void ga_apply_mask_kernel(float* __restrict__ A, int N, int K, const 
 // gram != nullptr (training step): also the tile's Gram partial of the UNNORMALISED probabilities, gram[tile][i*KP+j] =
 // sum_n e_i(n) e_j(n), i <= j, e_k(n) = exp(s_k(n) - m_tile,k) -- rescaled by the tail kernel (ga_step.hip) for the
 // diversity loss (Step3_WSI_classification_ACMIL.py:207-212).
+// seg: one bag, or a group of bags whose tiles are cut per bag (tile blockIdx.x -> ga_seg_find); A is [K][N] over ALL rows.
 template <int KP>
-__global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ h, const float* __restrict__ A, int N,
+__global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ h, const float* __restrict__ A, GaSeg seg, int N,
                                                       int K, int Di, float* __restrict__ part, float* __restrict__ gram,
                                                       const unsigned* __restrict__ cond, unsigned* __restrict__ cond_count) {
     if (cond) {      // predicated launch: the exact-fp32 repeat of a flagged bag (ga_forward.hip); counted once per launch that ran
@@ -264,8 +285,9 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
     float* stat = p_lds + 128 * KP;                  // [KP][2] : m, l
     float* red = stat + 2 * KP;                      // [RPI][KP][Di] cross-row-group reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * GA_POOL_ROWS;
-    const int rows = min(GA_POOL_ROWS, N - n0);
+    const GaSegTile sg = ga_seg_find<GA_POOL_ROWS>(seg, blockIdx.x);
+    const int n0 = sg.n0;
+    const int rows = min(GA_POOL_ROWS, sg.nend - n0);
     // ---- tile statistics: wave w handles branches w, w+4, ...; 64 lanes x 2 rows each
     for (int k = wave; k < KP; k += 4) {
         float s0 = -INFINITY, s1 = -INFINITY;
@@ -333,18 +355,21 @@ __global__ __launch_bounds__(256) void ga_pool_kernel(const float* __restrict__ 
 
 // one workgroup per 128-row tile; gram: see the kernel.  Shared by acmil_ga_pool, acmil_attn_pool and the fused step.
 int ga_pool_launch(const float* h, const float* A, int N, int K, int Di, float* part, float* gram, hipStream_t st, const unsigned* cond,
-                   unsigned* cond_count) {
+                   unsigned* cond_count, const GaSeg* seg) {
     if (Di % 64 != 0 || Di / 4 > 256 || Di > 1024) return ACMIL_ERR_UNSUPPORTED;
     if (K > ACMIL_MAX_TOKENS) return ACMIL_ERR_UNSUPPORTED;
     const int KP = ga_kp(K);
     const int RPI = 256 / (Di / 4) > 0 ? 256 / (Di / 4) : 1;
     const size_t lds = (size_t)(128 * KP + 2 * KP + (size_t)RPI * KP * Di) * sizeof(float);
     if (lds > 160 * 1024) return ACMIL_ERR_UNSUPPORTED;
-    void (*kern)(const float*, const float*, int, int, int, float*, float*, const unsigned*, unsigned*) =
+    void (*kern)(const float*, const float*, GaSeg, int, int, int, float*, float*, const unsigned*, unsigned*) =
         KP == 1 ? ga_pool_kernel<1> : KP == 5 ? ga_pool_kernel<5> : KP == 8 ? ga_pool_kernel<8> : ga_pool_kernel<16>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ACMIL_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(ga_pool_tiles(N)), dim3(256), lds, st, h, A, N, K, Di, part, gram, cond, cond_count);
+    const GaSeg one = ga_seg_single(N);
+    const GaSeg& S = seg ? *seg : one;
+    if (S.n < 1 || S.n > GA_SEG_MAX || S.row0[S.n] != N) return ACMIL_ERR_SHAPE;
+    hipLaunchKernelGGL(kern, dim3(ga_seg_tiles(S, GA_POOL_ROWS)), dim3(256), lds, st, h, A, S, N, K, Di, part, gram, cond, cond_count);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
 }
 

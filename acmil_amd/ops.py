@@ -501,6 +501,108 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 
 
+MAX_GROUP = 16      # GA_SEG_MAX: bags per acmil_ga_train_step_group call
+
+
+def ga_train_step_group(x: torch.Tensor, rows: Sequence[int], packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],
+                        grads: Sequence[torch.Tensor], labels: torch.Tensor, uniforms: Optional[torch.Tensor], k_top: int, m_mask: int,
+                        repack: bool = True, guard_flag: Optional[torch.Tensor] = None, rng: Optional[Tuple[int, int]] = None,
+                        adamw: Optional[tuple] = None):
+    """acmil_ga_train_step_group: ONE training step over a GROUP of bags (the single-GPU twin of slide-level data parallelism: the
+    parameter gradients are the MEAN of the bags' per-slide gradients).  x [sum(rows), D]: the bags' rows back to back; rows: the
+    bags' patch counts (host ints, 1 .. 16 bags); labels [G] int64 on the device; uniforms [G, K, k_top] or None (device draw).
+    Returns a dict: losses [G,4], sub_preds [G,K,C], slide_pred [G,C] or None, A_out [K, sum(rows)] (bag b = columns
+    offsets[b]:offsets[b+1]), topk_idx [G,K,k_top], masked_idx [G,K,m_mask] (bag-local indices), offsets, range_status."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _check_x(x, dims)
+    rows = [int(r) for r in rows]
+    G = len(rows)
+    K, Cc = dims.K, dims.C
+    N, dev = x.shape[0], x.device
+    if not (1 <= G <= MAX_GROUP) or sum(rows) != N or min(rows) < max(1, k_top):
+        raise RuntimeError("acmil_amd.ga_train_step_group: need 1..%d bags of >= max(1, k_top) rows that add up to x.shape[0] (got %s, N=%d, k_top=%d)"
+                           % (MAX_GROUP, rows, N, k_top))
+    if not x.is_contiguous():
+        raise RuntimeError("acmil_amd.ga_train_step_group: x must be contiguous")
+    pp = [p.data_ptr() for p in params]
+    gp = [g.data_ptr() for g in grads]
+    seen = (dev, tuple(map(id, params)), tuple(pp), tuple(map(id, grads)), tuple(gp))
+    if seen not in _TRAIN_STEP_CHECKED:
+        _need_cuda(*params, *grads)
+        n_par = 7 + 2 * K + (2 if dims.has_bag_head else 0)
+        if len(params) != n_par or len(grads) != n_par:
+            raise RuntimeError("acmil_amd.ga_train_step_group: expected %d parameters / gradients, got %d / %d" % (n_par, len(params), len(grads)))
+        for p, g in zip(params, grads):
+            if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous() or g.shape != p.shape \
+                    or p.device != dev or g.device != dev:
+                raise RuntimeError("acmil_amd.ga_train_step_group: parameters and gradients must be contiguous fp32 on the bags' device, same shapes")
+        if len(_TRAIN_STEP_CHECKED) >= _TRAIN_STEP_CHECKED_MAX:
+            _TRAIN_STEP_CHECKED.pop(next(iter(_TRAIN_STEP_CHECKED)))
+        _TRAIN_STEP_CHECKED[seen] = (tuple(params), tuple(grads))
+    _need_cuda(labels, guard_flag)
+    if labels.device != dev or labels.numel() != G:
+        raise RuntimeError("acmil_amd.ga_train_step_group: labels must be a [%d] tensor on the bags' device" % G)
+    if labels.dtype != torch.int64 or not labels.is_contiguous():
+        labels = labels.to(torch.int64).contiguous()
+    if not (0 <= m_mask <= k_top):
+        raise RuntimeError("acmil_amd.ga_train_step_group: need 0 <= m_mask <= k_top")
+    if m_mask > 0 and uniforms is None and rng is None:
+        raise RuntimeError("acmil_amd.ga_train_step_group: masking needs either the uniforms [G, K, k_top] or rng = (seed, offset)")
+    if m_mask > 0 and uniforms is not None:
+        if tuple(uniforms.shape) != (G, K, k_top):
+            raise RuntimeError("acmil_amd.ga_train_step_group: uniforms must be [G=%d, K=%d, k_top=%d], got %s" % (G, K, k_top, tuple(uniforms.shape)))
+        uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+    seed, offset = rng if rng is not None else (0, 0)
+    if guard_flag is not None and (guard_flag.dtype != torch.float32 or guard_flag.device != dev or guard_flag.numel() < 1):
+        raise RuntimeError("acmil_amd.ga_train_step_group: guard_flag must be a float32 device scalar")
+    n_l, n_s, n_b = 4 * G, G * K * Cc, G * Cc
+    fbuf = torch.empty(n_l + n_s + n_b + K * N, dtype=torch.float32, device=dev)
+    losses, sub, slide, A = fbuf[:n_l].view(G, 4), fbuf[n_l:n_l + n_s].view(G, K, Cc), fbuf[n_l + n_s:n_l + n_s + n_b].view(G, Cc), \
+        fbuf[n_l + n_s + n_b:].view(K, N)
+    ibuf = torch.empty(G * K * (k_top + m_mask) + 1, dtype=torch.int64, device=dev)
+    topk, midx = ibuf[:G * K * k_top].view(G, K, k_top), ibuf[G * K * k_top:G * K * (k_top + m_mask)].view(G, K, m_mask)
+    ws = _ws_bytes(lib.acmil_ga_train_step_group_workspace_bytes(G, N, dims.D, dims.Di, K, Cc, k_top), dev)
+    vpK = ctypes.c_void_p * K
+    has_bag = dims.has_bag_head
+    rows_arr = (ctypes.c_int * G)(*rows)
+    aw = None
+    if adamw is not None:
+        flat, m1, m2, lr, b1, b2, eps, wd, step, skipped, report = adamw
+        aw = _lib.AdamwArgs(flat.data_ptr(), flat.numel(), m1.data_ptr(), m2.data_ptr(), float(lr), float(b1), float(b2), float(eps), float(wd),
+                            int(step), skipped.data_ptr(), report)
+    rc = lib.acmil_ga_train_step_group(
+        x.data_ptr(), _DT[x.dtype], G, rows_arr, packed.data_ptr(), int(repack),
+        *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
+        *gp[:7], vpK(*gp[7:7 + K]), vpK(*gp[7 + K:7 + 2 * K]), gp[7 + 2 * K] if has_bag else None, gp[8 + 2 * K] if has_bag else None,
+        *dims.args(), mode, labels.data_ptr(), _ptr(uniforms) if m_mask > 0 else None, k_top, m_mask,
+        losses.data_ptr(), sub.data_ptr(), slide.data_ptr() if has_bag else None, A.data_ptr(),
+        topk.data_ptr() if k_top > 0 else None, midx.data_ptr() if m_mask > 0 else None, _ptr(guard_flag), ws.data_ptr(), _stream(),
+        seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), ctypes.byref(aw) if aw is not None else None)
+    _lib.check(rc, "acmil_ga_train_step_group")
+    offs = [0]
+    for r in rows:
+        offs.append(offs[-1] + r)
+    return {"losses": losses, "sub_preds": sub, "slide_pred": slide if has_bag else None, "A_out": A, "offsets": offs,
+            "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
+
+
+def ga_adamw_supported(dims: GaDims, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], flat: torch.Tensor,
+                       exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor) -> bool:
+    """acmil_ga_adamw_supported: would acmil_ga_train_step_adamw / _group(adamw) / acmil_ga_adamw_pack accept this parameter set?
+    Launches nothing."""
+    lib = _lib.load()
+    K = dims.K
+    pp = [p.data_ptr() for p in params]
+    gp = [g.data_ptr() for g in grads]
+    vpK = ctypes.c_void_p * K
+    has_bag = dims.has_bag_head
+    rc = lib.acmil_ga_adamw_supported(
+        *pp[:7], vpK(*pp[7:7 + K]), vpK(*pp[7 + K:7 + 2 * K]), pp[7 + 2 * K] if has_bag else None, pp[8 + 2 * K] if has_bag else None,
+        gp[0], gp[1], gp[3], *dims.args(), mode_id("f16x3"), flat.data_ptr(), flat.numel(), exp_avg.data_ptr(), exp_avg_sq.data_ptr())
+    return rc == 0
+
+
 def ga_adamw_pack(packed: torch.Tensor, dims: GaDims, params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], adamw: tuple,
                   skip_flag: Optional[torch.Tensor]):
     """acmil_ga_adamw_pack: AdamW over the module's flat parameter buffer + re-pack of the f16x3 packed buffer, one launch (final

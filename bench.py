@@ -308,15 +308,30 @@ def other_workloads(args, ctx):
     T.broadcast_parameters(model, world)
     bucket = T.GradBucket(list(model.parameters()))
     opt = T.make_optimizer(model, conf, dev, bucket, lr=conf.lr)          # FlatAdamW: one launch, shares the gradient bucket
+    G = max(1, int(getattr(args, "bags_per_step", 1)))
     bags = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 8 + i)[0].half().to(dev).unsqueeze(0) for i in range(8)]
     labels = [torch.tensor([(rank * 8 + i) % C], device=dev) for i in range(8)]
+    groups = []
+    if G > 1:
+        # --bags-per-step G: G slides per step and rank, ONE mean gradient (acmil_ga_train_step_group: the single-GPU twin of G-rank data
+        # parallelism; under DP one all-reduce per G slides).  Resident as the staging ring delivers a training group: rows back to back.
+        # 4 rotating groups of distinct bags (> 256 MB Infinity Cache at every size benched)
+        for gi in range(4):
+            xs = [S.synthetic_bag(N, D_FEAT, slide_idx=rank * 64 + gi * G + j)[0].half() for j in range(G)]
+            groups.append(((torch.cat(xs, 0).to(dev), [N] * G), torch.tensor([(rank * 64 + gi * G + j) % C for j in range(G)], device=dev)))
+        del xs
 
     def make_step(bucket, opt):
         def step(i):      # as train.train_one_epoch: range flag left on the device, looked at two steps late (no host read-back per step)
             # one GPU: the step applies AdamW itself -- its closing launch finishes the gradients, updates and re-packs (7 launches per
             # step); data parallel: the bucket all-reduce sits between the gradients and the optimizer's own launch (9 launches + RCCL)
-            _, out = model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag,
-                                      optimizer=opt, track_flag=True, in_step=(world == 1 and not args.train_separate_opt))
+            if G > 1:
+                grp, lab = groups[i % len(groups)]
+                _, out = model.train_step_batch(grp, lab, guard_flag=opt.guard_flag, optimizer=opt, track_flag=True,
+                                                in_step=(world == 1 and not args.train_separate_opt))
+            else:
+                _, out = model.train_step(bags[i % 8], labels[i % 8], guard_flag=opt.guard_flag,
+                                          optimizer=opt, track_flag=True, in_step=(world == 1 and not args.train_separate_opt))
             if out.get("opt_step_id") is None:
                 bucket.sync_from_grads()
                 bucket.allreduce_mean(world)
@@ -335,7 +350,7 @@ def other_workloads(args, ctx):
             dt_d = _timed(make_step(bucket_d, opt_d), args, world, dev)      # (its first step is the checked one: compared with all_reduce)
             if opt_d.peer is not None:
                 opt_d.peer.check()
-            direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * args.steps / dt_d, 1), "unit": "slides/s",
+            direct = {"ms_per_step": round(dt_d / args.steps * 1e3, 4), "value": round(world * G * args.steps / dt_d, 1), "unit": "slides/s",
                       "first_step_check": peer.verdict, "slot_memory": peer.memory,
                       "note": "gradient reduction fused into the AdamW launch (publish + flag wait + rank-ordered sum over IPC-mapped peer buckets)"
                               if opt_d.peer is not None else "the first-step check failed: these steps ran on torch.distributed all_reduce"}
@@ -372,7 +387,7 @@ def other_workloads(args, ctx):
         port = int(os.environ.get("MASTER_PORT", "29500"))
         env["MASTER_PORT"] = str(port + 17 if port + 17 < 65000 else port - 17)
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "train", "--train-n", str(N), "--gpus", str(world), "--steps", str(args.steps),
-               "--warmup", str(args.warmup), "--precision", args.precision, "--direct-leg", "--no-cpu-baseline"]
+               "--warmup", str(args.warmup), "--precision", args.precision, "--bags-per-step", str(G), "--direct-leg", "--no-cpu-baseline"]
         try:
             r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
             lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -385,25 +400,32 @@ def other_workloads(args, ctx):
             direct = {"error": "%s: %s" % (type(e).__name__, e)}
         _sync(world, dev)
     _, fwd_flops = algorithmic_work(N, D_FEAT, D_INNER, N_TOKEN, C)
-    flops = fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)
+    flops = G * fwd_flops * (1.0 + 4.0 / 3.0)       # backward ~ 1.33 x forward (algorithmic, no recompute counted)
     t_step = dt / args.steps
     result = {
         "metric": "slides/sec (ACMIL-ga training step: fwd + STKIM + losses + bwd + grad all-reduce + AdamW, N=%d D=512 C=7)" % N,
-        "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(world * G * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "bags_per_step": G, "ms_per_slide": round(t_step * 1e3 / G, 4),
         "ms_per_step": round(t_step * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "allreduce_us": allreduce_us, "allreduce_bytes": int(bucket.flat.numel() * 4), "direct_reduce": direct,
         "dtype": "f32 (split-f16 / split-bf16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
-        "config": {"workload": "ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step, D=512, D_inner=256, n_token=5, "
-                               "n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW" % N, "precision": args.precision,
-                   "sharding": "slide-level data parallel: one bag per rank, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)"},
-        "roofline": {"kernel": "whole step (7 launches: acmil_ga_train_step_adamw, optimizer and weight re-pack in the closing launch)" if world == 1 and not args.train_separate_opt
-                     else "whole step (9 launches: acmil_ga_train_step + optimizer)", "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
+        "config": {"workload": ("ACMIL-ga training, one fp16 bag of N=%d patches per GPU per step" % N if G == 1 else
+                                "ACMIL-ga training, %d fp16 bags of N=%d patches per GPU per step (ONE mean gradient per step = what %d data-parallel "
+                                "ranks compute; rows of a group resident back to back)" % (G, N, G)) +
+                               ", D=512, D_inner=256, n_token=5, n_masked_patch=10, mask_drop=0.6, n_class=7, AdamW", "precision": args.precision,
+                   "sharding": "slide-level data parallel: %d bag%s per rank and step, one flat 0.83 MB fp32 gradient all-reduce per step (RCCL)" % (G, "" if G == 1 else "s")},
+        "roofline": {"kernel": ("whole step (7 launches: acmil_ga_train_step_adamw, optimizer and weight re-pack in the closing launch)" if G == 1 else
+                                "whole step (7 launches for %d slides: acmil_ga_train_step_group, optimizer and weight re-pack in the closing launch)" % G)
+                     if world == 1 and not args.train_separate_opt
+                     else "whole step (9 launches: acmil_ga_train_step%s + optimizer)" % ("" if G == 1 else "_group"), "bound": "mfma", "achieved": round(flops / t_step / 1e12, 1),
                      "peak": 2500.0 if args.precision == "f16x3" else 157.3, "unit": "TFLOP/s",
                      "frac": round(flops / t_step / 1e12 / (2500.0 if args.precision == "f16x3" else 157.3), 4),
                      # PMC summaries of the step: tools/pmc_ga.py --workload train --whole-step with --batch 1 (N = 10 000) / --batch 50
                      # and --extra "--train-n 50000" (the batch argument only names the file for this workload)
-                     "traffic": pmc_traffic("train", args.precision, {10000: 1, 50000: 50}.get(N, -1))[0],
-                     "traffic_source": pmc_traffic("train", args.precision, {10000: 1, 50000: 50}.get(N, -1))[1],
+                     # (group steps: --batch 100 + G / 500 + G name the files; traffic is per STEP = G slides)
+                     "traffic": pmc_traffic("train", args.precision, ({10000: 1, 50000: 50}.get(N, -1) if G == 1 else {10000: 100 + G, 50000: 500 + G}.get(N, -1)))[0],
+                     "traffic_source": pmc_traffic("train", args.precision, ({10000: 1, 50000: 50}.get(N, -1) if G == 1 else {10000: 100 + G, 50000: 500 + G}.get(N, -1)))[1],
+                     "algorithmic_bytes": int(G * (2 * N * D_FEAT * 2 + N_TOKEN * N * 4)),
                      "note": "algorithmic flops = 2.33 x forward (SURVEY 8d) over the end-to-end step time"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -558,6 +580,8 @@ def main(argv=None):
                     help="skip the one-slide-per-call latency loop (profiling runs: keeps a single grid shape per kernel name)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default workload only: skip the nested `secondary` lines (configs[2], [3], [4])")
+    ap.add_argument("--bags-per-step", type=int, default=1,
+                    help="train workload: slides per step and rank, ONE mean gradient per step (acmil_ga_train_step_group); 1 = the reference's B = 1 SGD")
     ap.add_argument("--train-separate-opt", action="store_true",
                     help="train workload on one GPU: keep the optimizer as its own launch (the data-parallel launch sequence) -- A/B of the in-step optimizer")
     ap.add_argument("--direct-leg", action="store_true", help=argparse.SUPPRESS)      # child mode of the train workload (direct gradient reduction)
@@ -589,6 +613,8 @@ SECONDARY = (     # (key, argv overrides): the other BASELINE.json configs, meas
     ("transmil", dict(workload="transmil", steps=30, warmup=5)),
     ("train_n10k", dict(workload="train", train_n=10000, steps=300, warmup=50)),
     ("train_n50k", dict(workload="train", train_n=50000, steps=150, warmup=30)),
+    ("train_n10k_g8", dict(workload="train", train_n=10000, steps=100, warmup=20, bags_per_step=8)),
+    ("train_n50k_g8", dict(workload="train", train_n=50000, steps=40, warmup=8, bags_per_step=8)),
 )
 
 

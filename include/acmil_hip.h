@@ -318,6 +318,52 @@ int acmil_ga_train_step_adamw(const void* x, int x_dtype, int N, void* packed, i
                         const float* flat_params, long long n_flat, float* exp_avg, float* exp_avg_sq, float lr, double beta1,
                         double beta2, float eps, float weight_decay, long long step, int* skipped, float* flag_report);
 
+/* Would the closing launch of acmil_ga_train_step_adamw / acmil_ga_train_step_group (adamw != NULL) / acmil_ga_adamw_pack accept this
+ * parameter set?  A query: nothing is launched.  ACMIL_OK, or the code those entries return before their first launch
+ * (ACMIL_ERR_UNSUPPORTED: mode != ACMIL_MODE_F16X3, or W1 / Wv / Wu, their gradients or moments not 16-byte aligned; ACMIL_ERR_SHAPE: the
+ * parameters do not tile flat_params).  Callers ask once per parameter set and treat every error of the step itself as a failure. */
+int acmil_ga_adamw_supported(const float* W1, const float* Wv, const float* bv, const float* Wu, const float* bu, const float* Ww,
+                             const float* bw, const float* const* Wc, const float* const* bc, const float* Ws, const float* bs,
+                             const float* dW1, const float* dWv, const float* dWu, int D, int Di, int Da, int K, int C, int mode,
+                             const float* flat_params, long long n_flat, const float* exp_avg, const float* exp_avg_sq);
+
+/* A GROUP of bags in ONE training step: the single-GPU twin of slide-level data parallelism.  The reference trains with B = 1
+ * (Step3_WSI_classification_ACMIL.py:189-221: one slide, one backward, one optimizer.step()); G data-parallel ranks average the
+ * gradients of G slides per step.  This entry computes exactly that average on ONE GPU -- per slide the forward with
+ * STKIM, the three losses and the backward of acmil_ga_train_step, the parameter gradients = the MEAN over the bags -- with the
+ * patch-parallel work (score pass, both weight-gradient products, the closing launch) batched over all bags: 7 launches per G
+ * slides instead of per slide.  Under data parallelism it is `bags per rank`: one all-reduce per G slides.
+ *   x          the bags' rows BACK TO BACK: [sum bag_rows][D] (x_dtype as acmil_ga_train_step), bag b = rows
+ *              sum(bag_rows[:b]) .. ; bag_rows [nbags] on the HOST, 1 <= nbags <= 16, every bag >= max(1, k_top) rows
+ *   labels     [nbags] int64 (device); uniforms [nbags][K][k_top] or NULL (device draw, Philox keyed on (seed, offset, bag, branch, column))
+ *   outputs    losses [nbags][4]; sub_preds [nbags][K][C]; slide_pred [nbags][C]; A_out [K][sum bag_rows] (bag b = its column range;
+ *              masked raw scores); topk_idx [nbags][K][k_top], masked_idx [nbags][K][m_mask] (indices LOCAL to the bag)
+ *   gradients  dW1 .. dbs = mean over the bags of the per-slide gradients
+ *   adamw      NULL: the gradients are left for the caller (data parallel: all-reduce, then acmil_ga_adamw_pack / acmil_adamw_step);
+ *              else: the step's closing launch applies AdamW and re-packs, as acmil_ga_train_step_adamw does (parameters must
+ *              tile adamw->flat_params; same refusals before anything is launched)
+ *   workspace  acmil_ga_train_step_group_workspace_bytes(...); control block and range status word as acmil_ga_train_step (ONE status /
+ *              guard_flag for the group: a flagged group is repeated bag by bag in ACMIL_MODE_F32 by the caller)
+ * mode must be ACMIL_MODE_F16X3 (or _F16), D_inner 128 / 256, K <= 5: ACMIL_ERR_UNSUPPORTED otherwise.  nbags == 1 is
+ * acmil_ga_train_step_rng / _adamw bit for bit. */
+typedef struct acmil_adamw_args {
+    const float* flat_params; long long n_flat; float* exp_avg; float* exp_avg_sq;
+    float lr; double beta1, beta2; float eps, weight_decay; long long step; int* skipped; float* flag_report;
+} acmil_adamw_args;
+
+size_t acmil_ga_train_step_group_workspace_bytes(int nbags, int N_total, int D, int Di, int K, int C, int k_top);
+
+int acmil_ga_train_step_group(const void* x, int x_dtype, int nbags, const int* bag_rows, void* packed, int repack,
+                        float* W1, float* Wv, float* bv, float* Wu, float* bu, float* Ww, float* bw, float* const* Wc,
+                        float* const* bc, float* Ws, float* bs,
+                        float* dW1, float* dWv, float* dbv, float* dWu, float* dbu, float* dWw, float* dbw,
+                        float* const* dWc, float* const* dbc, float* dWs, float* dbs,
+                        int D, int Di, int Da, int K, int C, int mode,
+                        const int64_t* labels, const float* uniforms, int k_top, int m_mask,
+                        float* losses, float* sub_preds, float* slide_pred, float* A_out,
+                        int64_t* topk_idx, int64_t* masked_idx, float* guard_flag, void* workspace, void* stream,
+                        unsigned long long rng_seed, unsigned long long rng_offset, const acmil_adamw_args* adamw);
+
 /* torch.optim.AdamW's update over the flat parameter buffer of ONE ACMIL_GA / ABMIL module AND the re-pack of its weights in one
  * launch: acmil_adamw_step_report followed by acmil_ga_pack_weights, for steps whose gradients are final when the optimizer runs --
  * data-parallel training (Step3_WSI_classification_ACMIL.py:219's optimizer.step() behind a gradient all-reduce): the next
