@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void adamw_peer_kernel(float* __restrict__ p, 
         flag = flag / (float)world;
     }
     if (flag_report && blockIdx.x == 0 && threadIdx.x == 0) __builtin_nontemporal_store(flag, flag_report);
-    if (reduced_out && blockIdx.x == 0 && threadIdx.x == 0) reduced_out[n] = flag;
+    if (reduced_out && use_flag && blockIdx.x == 0 && threadIdx.x == 0) reduced_out[n] = flag;      // (slot n exists only with the flag)
     const bool skip = use_flag && !(flag == 0.0f);
     if (skip && skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skipped, 1);
     if (threadIdx.x == 0) {

@@ -98,6 +98,24 @@ def _ws_bytes(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+_SCRATCH_CACHE: Dict[tuple, torch.Tensor] = {}
+
+
+def _repeat_scratch(nbytes: int, device) -> torch.Tensor:
+    """Scratch of the device-predicated exact-fp32 repeats (ga_forward_guarded_wide, ga_rescore_fp32_cond): N * (D + D_inner + 256) * 4
+    bytes that only a flagged bag ever touches.  One grow-only buffer per (device, stream) instead of an allocation per eval call (0.6 GB
+    for a 100 000-patch fp16 bag at D = 1024, which the caching allocator then kept reserved per size class: ADVICE r5); calls on one
+    stream are ordered, and the repeat's contents are dead when its merge + heads have run."""
+    dev = torch.device(device)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    sc = _SCRATCH_CACHE.get(key)
+    if sc is None or sc.numel() < nbytes:
+        sc = None
+        _SCRATCH_CACHE.pop(key, None)
+        sc = _SCRATCH_CACHE[key] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=dev)
+    return sc
+
+
 def _workspace(N: int, dims: GaDims, mode: int, device) -> torch.Tensor:
     return _ws_bytes(_lib.load().acmil_ga_workspace_bytes(N, dims.D, dims.Di, dims.K, dims.C, mode), device)
 
@@ -252,7 +270,7 @@ def ga_forward_guarded_wide(x: torch.Tensor, packed: torch.Tensor, W1: torch.Ten
     af = torch.empty(dims.K, dims.Di, **f32) if want_afeat else None
     bf = torch.empty(dims.Di, **f32) if want_bag_feat else None
     nsc = lib.acmil_ga_forward_guarded_wide_scratch_bytes(N, dims.D, dims.Di, dims.K, _DT[x.dtype], 0 if want_scores else 1)
-    scratch = torch.empty(nsc, dtype=torch.uint8, device=dev)          # only ever touched by a flagged bag (caching allocator: no cost otherwise)
+    scratch = _repeat_scratch(nsc, dev)          # only ever touched by a flagged bag: ONE grow-only buffer per (device, stream)
     ws = _workspace(N, dims, _lib.MODE_F16X3, dev)
     rc = lib.acmil_ga_forward_guarded_wide(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), W1.data_ptr(), *dims.args(), _ptr(A), _ptr(sub),
                                            _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), _ptr(fallback_count),
@@ -277,7 +295,7 @@ def ga_rescore_fp32_cond(x: torch.Tensor, packed: torch.Tensor, W1: torch.Tensor
     if tuple(h.shape) != (N, dims.Di) or tuple(A.shape) != (dims.K, N) or not h.is_contiguous() or not A.is_contiguous():
         raise RuntimeError("acmil_amd: h [N, D_inner] and A [K, N] of this bag, contiguous fp32")
     nsc = lib.acmil_ga_rescore_fp32_cond_scratch_bytes(N, dims.D, dims.Di, _DT[x.dtype])
-    scratch = torch.empty(nsc, dtype=torch.uint8, device=x.device)
+    scratch = _repeat_scratch(nsc, x.device)
     rc = lib.acmil_ga_rescore_fp32_cond(x.data_ptr(), _DT[x.dtype], N, packed.data_ptr(), W1.data_ptr(), *dims.args(), dims.mode,
                                         h.data_ptr(), A.data_ptr(), status.data_ptr(), _ptr(fallback_count), scratch.data_ptr(), _stream())
     _lib.check(rc, "acmil_ga_rescore_fp32_cond")

@@ -225,3 +225,101 @@ def staged_groups(dataset, order: Iterable[int], device, group: int = 16, max_by
     if max_bytes is None and device.type == "cuda":
         max_bytes = min(STAGE_RING_BYTES, torch.cuda.get_device_properties(device).total_memory // 8)
     return BagPrefetcher(dataset, list(order), device, depth=2 * group, max_bytes=max_bytes).iter_groups(group)
+
+
+class TrainGroupPrefetcher:
+    """Groups of `group` consecutive bags of `order` for the GROUP training step (ACMIL_GA.train_step_batch): the bags of a group are
+    copied H2D straight into the row ranges of ONE ring slot, so the step gets its rows back to back without a device-side concatenation.
+    Yields {'input': [sum N_b, D] device tensor (stored dtype), 'rows': [N_b], 'labels': [int], 'indices': [i]}; the view aliases a ring
+    slot and is valid until the next group is requested.  Same event discipline as BagPrefetcher (copy stream, copied / consumed events);
+    the last group of an epoch may be shorter.  Bags of one group that differ in dtype are widened to fp32 on the host (exact)."""
+
+    def __init__(self, dataset, order: Sequence[int], device: torch.device, group: int, depth: int = 3):
+        self.dataset, self.order, self.device = dataset, list(order), torch.device(device)
+        self.group = max(1, int(group))
+        self.depth = max(2, depth)
+        self.cuda = self.device.type == "cuda"
+        self._ready: "queue.Queue" = queue.Queue()
+        self._free: "queue.Queue" = queue.Queue()
+        self._stop = False
+        for _ in range(self.depth):
+            self._free.put(_Slot() if self.cuda else None)
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._thread = threading.Thread(target=self._reader, daemon=True)
+        self._thread.start()
+
+    def __len__(self):
+        return (len(self.order) + self.group - 1) // self.group
+
+    def close(self):
+        self._stop = True
+        self._free.put(None)
+
+    def _reader(self):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            for g0 in range(0, len(self.order), self.group):
+                idx = self.order[g0:g0 + self.group]
+                items = [self.dataset[i] for i in idx]
+                xs = [torch.as_tensor(it["input"]) for it in items]
+                if any(x.dtype != xs[0].dtype for x in xs):
+                    xs = [x.float() for x in xs]
+                rows = [int(x.shape[0]) for x in xs]
+                labels = [int(it["label"]) for it in items]
+                d = int(xs[0].shape[1])
+                slot = self._free.get()
+                if self._stop:
+                    break
+                if not self.cuda:
+                    self._ready.put((None, torch.cat(xs, 0) if len(xs) > 1 else xs[0], rows, labels, idx))
+                    continue
+                n = sum(rows) * d
+                with torch.cuda.stream(self.copy_stream):
+                    if slot.consumed is not None:
+                        self.copy_stream.wait_event(slot.consumed)
+                    if slot.dev is None or slot.dev.numel() < n or slot.dev.dtype != xs[0].dtype:
+                        slot.dev = None
+                        slot.dev = torch.empty(int(n * 1.25), dtype=xs[0].dtype, device=self.device)
+                        slot.copied = torch.cuda.Event()
+                    off = 0
+                    for x, r in zip(xs, rows):
+                        slot.dev[off:off + r * d].copy_(x.reshape(-1), non_blocking=True)
+                        off += r * d
+                    slot.copied.record(self.copy_stream)
+                self._ready.put((slot, slot.dev[:n].view(sum(rows), d), rows, labels, idx))
+        except Exception as e:
+            self._ready.put(("error", e))
+        self._ready.put(None)
+
+    def __iter__(self) -> Iterator[Dict]:
+        compute = torch.cuda.current_stream(self.device) if self.cuda else None
+        prev = None
+        first = True
+        try:
+            while True:
+                got = self._ready.get()
+                if not first:
+                    if self.cuda and prev is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(compute)
+                        prev.consumed = ev
+                    self._free.put(prev)
+                    prev = None
+                if got is None:
+                    return
+                if got[0] == "error":
+                    raise got[1]
+                slot, view, rows, labels, idx = got
+                if self.cuda:
+                    compute.wait_event(slot.copied)
+                prev = slot
+                first = False
+                yield {"input": view, "rows": rows, "labels": labels, "indices": list(idx)}
+        finally:
+            self.close()
+
+
+def staged_train_groups(dataset, order: Iterable[int], device, group: int, depth: int = 3) -> TrainGroupPrefetcher:
+    return TrainGroupPrefetcher(dataset, list(order), torch.device(device), group, depth=depth)

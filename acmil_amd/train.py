@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
-from .staging import staged, staged_groups
+from .staging import staged, staged_groups, staged_train_groups
 
 EVAL_BATCH = 64     # slides per fused eval launch (acmil_ga_forward_batch takes up to 64): the ragged last round of tiles and the
                     # merge / heads launches weigh ~2 % at 64 bags of 50 000 patches, ~9 % at 16
@@ -234,6 +234,8 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
     """One epoch, one slide per iteration per rank (Step3_WSI_classification_ACMIL.py:175-227).
     fused=True uses the module's autograd-free `train_step` (fused HIP loss + backward); fused=False runs the
     reference's op sequence through torch autograd on top of the HIP forward/backward node (same gradients)."""
+    if int(getattr(conf, "bags_per_step", 1) or 1) > 1:
+        return train_one_epoch_groups(model, data, optimizer, device, epoch, conf, bucket, rank, world, log_every, fused)
     model.train()
     order = epoch_order(len(data), epoch, conf.seed, True, rank, world)
     sums = {"sub_loss": 0.0, "diff_loss": 0.0, "slide_loss": 0.0}
@@ -315,6 +317,97 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
         settle(0)
     if bucket is not None and bucket.peer is not None:
         bucket.peer.check()              # a peer that never published leaves this rank's updates unapplied: raise, never train on silently
+    n = max(1, len(order))
+    a = acc.tolist()
+    return {"sub_loss": a[0] / n, "slide_loss": a[1] / n, "diff_loss": a[2] / n}
+
+
+def train_one_epoch_groups(model, data, optimizer, device, epoch: int, conf, bucket: Optional[GradBucket] = None,
+                           rank: int = 0, world: int = 1, log_every: int = 100, fused: bool = True) -> Dict[str, float]:
+    """One epoch with conf.bags_per_step = G > 1 slides per step and rank: every step runs on the MEAN gradient of its G slides
+    (ACMIL_GA.train_step_batch -> acmil_ga_train_step_group: the per-slide forward / losses / backward of
+    Step3_WSI_classification_ACMIL.py:189-221, batched), i.e. what G data-parallel ranks compute -- with `world` ranks the step
+    averages G x world slides and all-reduces ONCE per G slides.  Not the reference's B = 1 SGD trajectory (neither is its DP
+    twin): opt-in.  The per-iteration cosine schedule advances per step; the epoch has ceil(len / G) steps per rank.
+    Models without a group step (autograd fallback, CPU tests) accumulate the G slides' gradients one by one."""
+    model.train()
+    G = int(conf.bags_per_step)
+    order = epoch_order(len(data), epoch, conf.seed, True, rank, world)
+    acc = torch.zeros(4, device=device)
+    use_fused = fused and hasattr(model, "train_step_batch") and device.type == "cuda"
+    lagged = (use_fused and getattr(optimizer, "guard_flag", None) is not None and getattr(model, "range_guard", False)
+              and getattr(model, "precision", "") == "f16x3")
+    opt_aware = use_fused and hasattr(optimizer, "in_step_args") and getattr(model, "supports_in_step_optimizer", False)
+    in_step = opt_aware and lagged and world == 1
+    recent: Dict[int, tuple] = {}
+    label_dev = torch.arange(conf.n_class, device=device)
+    t0 = time.time()
+    n_steps = (len(order) + G - 1) // G
+
+    def reduce_and_step(track):
+        if bucket is not None:
+            bucket.sync_from_grads()
+            bucket.allreduce_mean(world)
+        return optimizer.step(track_flag=True) if track else optimizer.step()
+
+    def settle(lag):
+        nonlocal acc
+        limit = optimizer._step_id - lag
+        skipped = optimizer.poll_skipped(lag)
+        for sid in [k for k in sorted(recent) if k <= limit]:
+            idxs, labs, ls = recent.pop(sid)
+            if sid not in skipped:
+                acc += ls
+                continue
+            # a bag of the group left the split-f16 range: the whole group again in exact fp32 arithmetic (bag by bag, mean gradient)
+            xs = [torch.as_tensor(data[i]["input"]).to(device) for i in idxs]
+            redo, _ = model.train_step_batch(xs, label_dev[torch.tensor(labs, device=device)], precision="fp32", guard_flag=optimizer.guard_flag)
+            reduce_and_step(False)
+            acc += redo.sum(0)
+
+    for it, grp in enumerate(staged_train_groups(data, order, device, G)):
+        labels = label_dev[torch.tensor(grp["labels"], device=device)] if device.type == "cuda" else torch.tensor(grp["labels"])
+        adjust_learning_rate(optimizer, epoch + it / max(1, n_steps), conf)
+        sid = None
+        if use_fused:
+            losses, out = model.train_step_batch((grp["input"], grp["rows"]), labels, guard_flag=optimizer.guard_flag if lagged else None,
+                                                 **({"optimizer": optimizer, "track_flag": True, "in_step": in_step} if opt_aware else {}))
+            sid = out.get("opt_step_id") if in_step else None
+            ls = losses.sum(0)
+            if not lagged:
+                acc += ls
+        else:
+            optimizer.zero_grad(set_to_none=False)
+            ls = torch.zeros(4, device=device)
+            off = 0
+            for b, n in enumerate(grp["rows"]):
+                x = grp["input"][off:off + n]
+                off += n
+                y = labels[b:b + 1]
+                out = model(x.unsqueeze(0) if x.dtype == torch.float32 or conf.arch == "ga" else x.float().unsqueeze(0))
+                if isinstance(out, tuple):
+                    loss0, loss1, diff_loss = acmil_losses(out[0], out[1], out[2], y, conf.n_token)
+                else:
+                    zero = torch.zeros((), device=device)
+                    loss0, loss1, diff_loss = zero, F.cross_entropy(out, y), zero
+                loss = diff_loss + loss0 + loss1
+                (loss / len(grp["rows"])).backward()          # .grad accumulates: the group's mean gradient
+                ls = ls + torch.stack([loss0.detach(), loss1.detach(), diff_loss.detach(), loss.detach()])
+            acc += ls
+        if sid is None:
+            sid = reduce_and_step(lagged)
+        if lagged:
+            recent[sid] = (grp["indices"], grp["labels"], ls)
+            settle(2)
+        if rank == 0 and log_every and (it + 1) % log_every == 0:
+            a = acc.tolist()
+            seen = min(len(order), (it + 1) * G)
+            print("Epoch: [%d] [%d/%d] lr: %.6f sub_loss: %.4f diff_loss: %.4f slide_loss: %.4f (%.1f slides/s/rank, %d bags per step)" % (
+                epoch, it + 1, n_steps, optimizer.param_groups[0]["lr"], a[0] / seen, a[2] / seen, a[1] / seen, seen / (time.time() - t0), G))
+    if lagged:
+        settle(0)
+    if bucket is not None and bucket.peer is not None:
+        bucket.peer.check()
     n = max(1, len(order))
     a = acc.tolist()
     return {"sub_loss": a[0] / n, "slide_loss": a[1] / n, "diff_loss": a[2] / n}
@@ -419,6 +512,7 @@ def make_optimizer(model, conf, device, bucket: Optional["GradBucket"] = None, l
     if bucket is not None and bucket.peer is not None:
         # the direct reduction lives inside FlatAdamW's launch: with torch's optimizer the bucket goes back to the collective
         print("acmil_amd.train: --dp-reduce direct needs FlatAdamW; using torch.distributed all_reduce with torch.optim.AdamW")
+        bucket.peer.close()         # collective (every rank takes this path): drain, barrier, unmap -- peers still hold the slots mapped
         bucket.peer = None
     return torch.optim.AdamW(params, lr=lr, weight_decay=conf.wd)
 
@@ -457,6 +551,10 @@ def get_arguments(argv=None):
     p.add_argument("--train_epoch", type=int, default=None)
     p.add_argument("--n_class", type=int, default=None)
     p.add_argument("--out_dir", default="runs/acmil")
+    p.add_argument("--bags-per-step", dest="bags_per_step", type=int, default=1,
+                   help="slides per optimizer step and rank: > 1 trains on the MEAN gradient of that many slides per step (one batched "
+                        "group step on the GPU; under data parallelism one all-reduce per group) -- the throughput mode; 1 = the "
+                        "reference's B = 1 SGD (Step3_WSI_classification_ACMIL.py:189-221)")
     p.add_argument("--dp-reduce", dest="dp_reduce", default=os.environ.get("ACMIL_DP_REDUCE", "rccl"), choices=["rccl", "direct"],
                    help="data-parallel gradient reduction: torch.distributed all_reduce (RCCL), or the one-shot direct reduction fused "
                         "into the optimizer launch (peers' buckets read through IPC-mapped pointers; one node; falls back to rccl)")

@@ -215,12 +215,17 @@ def _peer_fail_worker(rank, world, port, fail_rank):
 
     class _FakePeer:
         owner = None
+        closed = 0
+
+        def close(self):          # (collective in the real reducer: drain, barrier, unmap)
+            _FakePeer.closed += 1
     bucket.peer = _FakePeer()
     bucket.flat.fill_(float(rank))
     bucket.allreduce_mean(world)
     assert torch.allclose(bucket.flat, torch.full_like(bucket.flat, 0.5))
     opt = T.make_optimizer(model, T.Struct(wd=0.0, torch_optimizer=True), torch.device("cpu"), bucket, lr=1e-3)
     assert isinstance(opt, torch.optim.AdamW) and bucket.peer is None
+    assert _FakePeer.closed == 1           # dropped through its collective close(), not just forgotten
     dist.destroy_process_group()
 
 
@@ -253,3 +258,63 @@ def test_grad_bucket_sync_repoints_only_what_autograd_replaced():
     assert torch.equal(bucket.flat[off[2]:off[3]], torch.zeros(params[2].numel()))
     assert torch.equal(bucket.flat[off[0]:off[1]], before[off[0]:off[1]]) and torch.equal(bucket.flat[off[3]:off[4]], before[off[3]:off[4]])
     assert params[0].grad is views[0] and params[3].grad is views[3]
+
+
+class _TinyMIL(torch.nn.Module):
+    """[1, N, D] -> logits [1, C] (mean pooling + two linears): a stand-in single-head model for the host-side loop tests."""
+
+    def __init__(self, d=6, c=3):
+        super().__init__()
+        self.a, self.b = torch.nn.Linear(d, 5), torch.nn.Linear(5, c)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x[0].float())).mean(0, keepdim=True))
+
+
+def _group_epoch_worker(rank, world, port, out, bags_per_step):
+    """train.train_one_epoch with conf.bags_per_step > 1 (train_one_epoch_groups): staged groups, mean gradient per group, ONE bucket
+    all-reduce per group."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = _TinyMIL()
+    T.broadcast_parameters(model, world)
+    conf = T.Struct(wd=1e-2, lr=1e-2, min_lr=0.0, warmup_epoch=0, train_epoch=4, seed=3, n_class=3, n_token=1, arch="abmil",
+                    bags_per_step=bags_per_step)
+    g = torch.Generator().manual_seed(5)
+    data = [{"input": torch.randn(4 + i % 5, 6, generator=g).half(), "label": i % 3} for i in range(16)]
+    bucket = T.GradBucket(list(model.parameters())) if world > 1 else None
+    opt = T.make_optimizer(model, conf, torch.device("cpu"), bucket, lr=conf.lr)
+    for epoch in range(2):
+        stats = T.train_one_epoch(model, data, opt, torch.device("cpu"), epoch, conf, bucket, rank, world, log_every=0, fused=False)
+        assert np.isfinite(stats["slide_loss"])
+    if rank == 0:
+        torch.save([p.detach().clone() for p in model.parameters()], out)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_grouped_epoch_two_ranks_of_two_bags_equal_one_process_of_four():
+    """bags_per_step under data parallelism: 2 gloo ranks x 2 slides per step == one process x 4 slides per step (same slides per
+    optimizer step, mean gradient, same schedule), and a group step differs from four B = 1 steps."""
+    with tempfile.TemporaryDirectory() as d:
+        o2, o1, o0 = os.path.join(d, "w2.pt"), os.path.join(d, "w1.pt"), os.path.join(d, "w0.pt")
+        mp.spawn(_group_epoch_worker, args=(2, _free_port(), o2, 2), nprocs=2, join=True)
+        _group_epoch_worker(0, 1, _free_port(), o1, 4)
+        _group_epoch_worker(0, 1, _free_port(), o0, 1)
+        a, b, c = (torch.load(o, weights_only=False) for o in (o2, o1, o0))
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, atol=1e-6, rtol=1e-5)
+    assert any(not torch.allclose(pb, pc, atol=1e-4) for pb, pc in zip(b, c))
+
+
+def test_train_group_prefetcher_cpu_concatenates_in_order():
+    from acmil_amd.staging import staged_train_groups
+    data = [{"input": torch.full((3 + i, 4), float(i)).half(), "label": i % 2} for i in range(7)]
+    groups = list(staged_train_groups(data, [6, 0, 3, 2, 5], "cpu", 2))
+    assert [g["indices"] for g in groups] == [[6, 0], [3, 2], [5]]
+    assert [g["rows"] for g in groups] == [[9, 3], [6, 5], [8]]
+    assert groups[0]["input"].shape == (12, 4) and float(groups[0]["input"][0, 0]) == 6.0 and float(groups[0]["input"][9, 0]) == 0.0
+    assert groups[1]["labels"] == [1, 0]

@@ -257,6 +257,51 @@ def test_train_one_epoch_repeats_a_flagged_bag_in_fp32():
         assert (pm - pt).abs().max().item() <= 2e-5 * max(1.0, pt.abs().max().item()), n
 
 
+def test_train_one_epoch_with_bags_per_step_runs_group_steps_and_repeats_a_flagged_group():
+    """conf.bags_per_step = 4: staged groups (rows of a group copied back to back into one ring slot), one group step + AdamW per 4
+    slides with the optimizer inside the step's closing launch; the group that holds an out-of-range bag is skipped on the device, found
+    two steps later and trained again in exact fp32 (bag by bag, mean gradient).  A replica built from direct train_step_batch calls
+    in the same order ends on the same parameters."""
+    T, conf, dev, model, bucket, opt = _guard_setup(seed=31)
+    conf.n_masked_patch, conf.mask_drop = 10, 0.6
+    model.n_masked_patch, model.mask_drop = 10, 0.6
+    g = torch.Generator().manual_seed(2)
+    bags = [(torch.randn(300 + 41 * i, 384, generator=g).half(), i % 3) for i in range(14)]      # 14 slides: 3 groups of 4 + one of 2
+    bad = bags[5][0].float().clone(); bad[9, 2] = 4.0e5
+    bags[5] = (bad, bags[5][1])                        # (fp32 storage: 4e5 is not an fp16 value; its group is widened to fp32)
+    data = _ListBags(bags)
+    conf.seed, conf.bags_per_step = 0, 4
+    order = T.epoch_order(len(data), 0, conf.seed, True, 0, 1)
+    groups = [order[i:i + 4] for i in range(0, len(order), 4)]
+    stats = T.train_one_epoch(model, data, opt, dev, 0, conf, bucket=bucket, log_every=0)
+    assert opt.skipped_steps == 1 and all(v == v for v in stats.values())
+    assert model.__dict__.get("_opt_in_step_refused") is None
+    T2, conf2, _, twin, bucket2, opt2 = _guard_setup(seed=31)
+    twin.n_masked_patch, twin.mask_drop = 10, 0.6
+    twin._rng_seed, twin._rng_count = model._rng_seed, 0            # the device draws are keyed on (seed, masked-forward count)
+    gbad = [gi for gi, grp in enumerate(groups) if 5 in grp][0]
+    found = min(gbad + 2, len(groups) - 1)
+
+    def step(idx, precision=None):
+        xs = [data[i]["input"].to(dev) for i in idx]
+        ys = torch.tensor([data[i]["label"] for i in idx], device=dev)
+        if any(x.dtype != xs[0].dtype for x in xs):
+            xs = [x.float() for x in xs]
+        twin.train_step_batch(xs, ys, precision=precision)
+        opt2.step()
+
+    for it, grp in enumerate(groups):
+        T.adjust_learning_rate(opt2, 0 + it / len(groups), conf2)
+        if it != gbad:
+            step(grp)
+        else:
+            twin._next_rng()                                          # the skipped step consumed one draw
+        if it == found:
+            step(groups[gbad], precision="fp32")
+    for (n, pm), pt in zip(model.named_parameters(), twin.parameters()):
+        assert (pm - pt).abs().max().item() <= 2e-5 * max(1.0, pt.abs().max().item()), n
+
+
 def test_rccl_single_rank_bucket_allreduce_and_broadcast():
     """The collective calls of the data-parallel path on a real RCCL communicator (one rank: a multi-GPU node is not part of
     the test hardware): `torch.distributed` backend nccl = RCCL, parameter broadcast, the flat gradient bucket INCLUDING its
