@@ -34,8 +34,8 @@ class Attention_Gated(nn.Module):
 
     def __init__(self, L=512, D=128, K=1):
         super().__init__()
-        if D != ops.GA_DA:
-            raise NotImplementedError("acmil_amd: attention hidden width D must be 128 (the reference's fixed default)")
+        # D = 128 (the reference's default, transformer.py:240,292) is the width of the fused kernels; any other width runs the
+        # aggregators' op-by-op path (_GatedBase._forward_generic: acmil_gated_scores takes any D)
         self.L, self.D, self.K = L, D, K
         self.attention_V = nn.Sequential(nn.Linear(L, D), nn.Tanh())
         self.attention_U = nn.Sequential(nn.Linear(L, D), nn.Sigmoid())
@@ -155,13 +155,68 @@ class _GatedBase(nn.Module):
         raise NotImplementedError
 
     def _check_dropout(self):
-        """Classifier_1fc(droprate != 0) (network.py:10-16; the reference's ACMIL / ABMIL constructors pass their `droprate` through,
-        transformer.py:270-275,292-299, every shipped script leaves it 0): nn.Dropout is the identity in eval mode, so such a model
-        -- e.g. a checkpoint trained elsewhere with head dropout -- evaluates here exactly as in the reference.  TRAINING with it would
-        need the mask inside the fused head / tail kernels: refused, loudly."""
-        if getattr(self, "droprate", 0) != 0 and self.training:
-            raise NotImplementedError("acmil_amd: training with classifier dropout (droprate != 0) is not built: the heads live inside the "
-                                      "fused kernels; eval mode works (dropout is the identity there)")
+        """(kept for callers of earlier rounds: nothing is refused any more -- train-mode classifier dropout runs the op-by-op path)"""
+
+    def _generic(self) -> bool:
+        """True where the reference's constructor arguments leave what the fused kernels are built for: an attention hidden width other
+        than 128 (`D`, transformer.py:240,270,292), classifier dropout in TRAINING mode (`droprate`, network.py:10-19: identity in
+        eval mode, where the fused path serves such a model as before), DimReduction residual blocks.  Those run _forward_generic."""
+        return (self.attention.D != ops.GA_DA or (getattr(self, "droprate", 0) != 0 and self.training)
+                or getattr(self.dimreduction, "numRes", 0) > 0)
+
+    def _forward_generic(self, xb, uniforms=None, masking=False):
+        """The aggregator op by op, every O(N) operation a kernel of libacmil_hip.so with a HIP backward (acmil_amd.autograd): projection
+        (+ residual blocks) as split-f16 / exact-fp32 MFMA GEMMs, acmil_gated_scores' arithmetic at ANY attention width, STKIM selection
+        (acmil_stkim_select) + differentiable mask fill, row softmax, pooling GEMM; the heads (K + 1 products of [1, D_inner] by
+        [D_inner, C]) as exact-fp32 GEMMs behind torch's dropout mask (`Classifier_1fc`, network.py:14-19: the mask is drawn by torch's
+        generator, as the reference's is).  Differentiable: forward(), train_step and forward_feature of such a model all come here.
+        Returns (sub_preds [K, C], slide_pred [1, C] or None, A [K, N] masked raw scores, afeat [K, D_inner], topk, midx)."""
+        x = xb if xb.dtype == torch.float32 else xb.float()
+        a = self.attention
+        prec = "fp32" if self.precision == "fp32" else "f16x3"
+        wc, bc, ws, bs = self._heads()
+
+        def run(prec):
+            h = AG.linear(x, self.dimreduction.fc1.weight, None, relu=True, precision=prec)
+            for blk in getattr(self.dimreduction, "resBlocks", []):
+                t = AG.linear(h, blk.block[0].weight, None, relu=True, precision=prec)
+                h = h + AG.linear(t, blk.block[2].weight, None, relu=True, precision=prec)
+            A = AG.gated_scores(h, a.attention_V[0].weight, a.attention_V[0].bias, a.attention_U[0].weight, a.attention_U[0].bias,
+                                a.attention_weights.weight, a.attention_weights.bias, prec)
+            return h, A
+
+        h, A = run(prec)
+        if prec == "f16x3" and self.range_guard:
+            # the split-f16 products have no status word on this path: one reduction over h and the bag (as the composed path's generic-GEMM route)
+            hmax, xmax = h.detach().max(), x.abs().max()
+            if not bool(torch.isfinite(hmax) & (hmax < 65504.0) & torch.isfinite(xmax) & (xmax < 65504.0)):
+                self._fb_host = getattr(self, "_fb_host", 0) + 1
+                h, A = run("fp32")
+        n = x.shape[0]
+        topk = midx = None
+        k = min(self.n_masked_patch, n) if masking else 0
+        m = int(k * self.mask_drop)
+        if k > 0:
+            topk, midx = ops.stkim_select(A.detach().contiguous(), k, m, uniforms, rng=None if uniforms is not None else self._next_rng())
+            if m > 0:
+                A = AG.mask_fill(A, midx)
+        afeat = AG.attn_pool(h, A)                                   # softmax over N, then P h: [K, D_inner]
+        drop = getattr(self, "droprate", 0)
+        outs = []
+        for i in range(len(wc)):
+            v = afeat[i:i + 1]
+            if drop != 0:
+                v = F.dropout(v, drop, self.training)
+            outs.append(AG.linear(v, wc[i], bc[i], precision="fp32"))
+        sub = torch.cat(outs, 0)
+        slide = None
+        if ws is not None:
+            # bag_A = softmax(A).mean(0); bag_feat = bag_A h  ==  mean_k afeat_k  (transformer.py:328-330; linear in the softmax rows)
+            bf = afeat.mean(0, keepdim=True)
+            if drop != 0:
+                bf = F.dropout(bf, drop, self.training)
+            slide = AG.linear(bf, ws, bs, precision="fp32")
+        return sub, slide, A, afeat, topk, midx
 
     def _raw_params(self):
         wc, bc, ws, bs = self._heads()
@@ -411,7 +466,7 @@ class _GatedBase(nn.Module):
 class ABMIL(_GatedBase):
     def __init__(self, conf, D=128, droprate=0, *, precision="f16x3", range_guard=True):
         super().__init__()
-        self.droprate = droprate      # Classifier_1fc's dropout (network.py:10-16): identity in eval mode; training with it is refused at call time
+        self.droprate = droprate      # Classifier_1fc's dropout (network.py:10-16): identity in eval mode; training with it takes the op-by-op path
         self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
         self.attention = Attention_Gated(conf.D_inner, D, 1)
         self.classifier = Classifier_1fc(conf.D_inner, conf.n_class, droprate)
@@ -422,8 +477,9 @@ class ABMIL(_GatedBase):
         return [self.classifier.fc.weight], [self.classifier.fc.bias], None, None
 
     def forward(self, x):  # x: [1, N, D_feat] -> logits [1, C]   (transformer.py:277-286)
-        self._check_dropout()
         xb = self._bag(x)
+        if self._generic():
+            return self._forward_generic(xb)[0]
         params = self._all_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._masking_now = False
@@ -456,10 +512,13 @@ class ACMIL_GA(_GatedBase):
 
     def forward(self, x, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> (sub_preds [K,C], slide_pred [1,C], A_out [1,K,N])  (transformer.py:305-330)."""
-        self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
+        if self._generic():
+            sub, slide, A, afeat, topk, midx = self._forward_generic(xb, uniforms, masking)
+            self._last = {"sub_preds": sub, "slide_pred": slide, "A_out": A, "afeat": afeat, "topk_idx": topk, "masked_idx": midx}
+            return sub, slide, A.unsqueeze(0)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             self._masking_now = masking
             return _GaTrainFn.apply(self, xb, uniforms, len(params), *params)
@@ -493,16 +552,21 @@ class ACMIL_GA(_GatedBase):
         `opt_step_id` is None and the caller steps the optimizer as before.  in_step=False (data-parallel runs: the gradient
         all-reduce sits between this call and the update) only tells the step whose updates to trust: with `adamw_pack_hook`
         installed the optimizer's own launch re-packs the weights (acmil_ga_adamw_pack) and this call skips its pack launch."""
-        self._check_dropout()
         xb = self._bag(x)
         params = self._all_params()
         masking = self.n_masked_patch > 0 and self.training
         k_top = min(self.n_masked_patch, xb.shape[0]) if masking else 0
-        # no injected draw: the kernel draws on the device; ONE (seed, offset) per step, so an fp32 re-run masks the same patches
-        self._step_rng = self._next_rng() if (masking and uniforms is None) else None
         for p in params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
+        if self._generic():
+            if guard_flag is not None:
+                guard_flag.zero_()          # the op-by-op path resolves the guard itself, before it returns
+            losses, out = self._train_step_generic(xb, label, uniforms, params, masking)
+            self._last = out
+            return losses, out
+        # no injected draw: the kernel draws on the device; ONE (seed, offset) per step, so an fp32 re-run masks the same patches
+        self._step_rng = self._next_rng() if (masking and uniforms is None) else None
         if self._is_fused() and getattr(self, "fused_step", True):
             losses, out = self._train_step_fused(xb, label, uniforms, params, k_top, guard_flag, precision, optimizer, track_flag, in_step)
         else:
@@ -632,7 +696,6 @@ class ACMIL_GA(_GatedBase):
         uniforms [G, K, k] to inject the STKIM draws (a list of per-bag [K, k_b] tensors where a bag is smaller than n_masked_patch).
         Everything else as `train_step`.  Returns (losses [G, 4], outputs dict:
         sub_preds [G,K,C], slide_pred [G,C], A_out [K, sum N_b] with `offsets`, topk_idx / masked_idx [G,K,.] bag-local)."""
-        self._check_dropout()
         if isinstance(bags, tuple) and len(bags) == 2 and torch.is_tensor(bags[0]):
             xb, rows = bags[0], [int(r) for r in bags[1]]
         else:
@@ -652,7 +715,7 @@ class ACMIL_GA(_GatedBase):
         for p in params:
             if p.grad is None:
                 p.grad = torch.empty_like(p)
-        fused = self._is_fused() and getattr(self, "fused_step", True)
+        fused = self._is_fused() and getattr(self, "fused_step", True) and not self._generic()
         # bags smaller than n_masked_patch clamp k per bag (transformer.py:313) and the wide / composed families have no group kernel:
         # those groups run bag by bag with the gradients averaged -- the same mathematics
         if not fused or (masking and min(rows) < self.n_masked_patch):
@@ -691,6 +754,22 @@ class ACMIL_GA(_GatedBase):
         training step needs no pack launch.  Used where the update cannot ride in the step's own closing launch (data parallel)."""
         return _AdamwPackHook(self, optimizer)
 
+    def _train_step_generic(self, xb, label, uniforms, params, masking):
+        """train_step of a model on the op-by-op path (_generic): differentiable forward, the fused loss kernel (acmil_ga_loss: the three
+        losses and their gradients w.r.t. the forward's outputs), then torch.autograd through the HIP backward kernels."""
+        with torch.enable_grad():
+            sub, slide, A, afeat, topk, midx = self._forward_generic(xb, uniforms, masking)
+        losses, d_sub, d_slide, d_A = ops.ga_loss(sub.detach().contiguous(), None if slide is None else slide.detach().reshape(-1).contiguous(),
+                                                  A.detach().contiguous(), label)
+        for p in params:
+            p.grad.zero_()
+        outs, gs = [sub, A], [d_sub, d_A]
+        if slide is not None:
+            outs.append(slide); gs.append(d_slide.view_as(slide))
+        torch.autograd.backward(outs, gs)
+        return losses, {"sub_preds": sub.detach(), "slide_pred": None if slide is None else slide.detach().reshape(-1), "A_out": A.detach(),
+                        "afeat": afeat.detach(), "topk_idx": topk, "masked_idx": midx, "opt_step_id": None}
+
     def _train_step_composed(self, xb, label, uniforms, params, masking):
         """Op-by-op step (the wide D_inner families, and the fused step's cross-check in the tests)."""
         packed, dims = self._packed()
@@ -719,6 +798,12 @@ class ACMIL_GA(_GatedBase):
                 out += self.forward_batch(bags[i:i + ops.MAX_BATCH], precision=precision)
             return out
         prec = precision or self.precision
+        if self._generic():
+            triples = []
+            for b in bags:
+                sub, slide, A, *_ = self._forward_generic(b if b.is_contiguous() else b.contiguous())
+                triples.append((sub, slide, A.unsqueeze(0)))
+            return (triples, None) if defer_guard else triples
         packed, dims = self._packed() if prec == self.precision else self._packed_cached(prec)
         bags = [b if b.is_contiguous() else b.contiguous() for b in bags]
         if any(b.dtype != bags[0].dtype for b in bags):      # one launch reads one storage format: widen (exactly) to fp32
@@ -748,8 +833,11 @@ class ACMIL_GA(_GatedBase):
 
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> bag_feat [1,Di]  (transformer.py:332-352)."""
-        packed, dims = self._packed()
         xb = self._bag(x)
+        if self._generic():
+            afeat = self._forward_generic(xb, uniforms, masking=self.n_masked_patch > 0 and use_attention_mask)[3]
+            return afeat.mean(0, keepdim=True)
+        packed, dims = self._packed()
         if self.n_masked_patch > 0 and use_attention_mask:
             out = self._masked_forward(xb, packed, dims, uniforms, want_bag_feat=True)
         else:
@@ -884,8 +972,11 @@ class ACMIL_MHA(nn.Module):
         outs = []
         for i, att in enumerate(self.sub_attention):
             out1 = ((att.v_proj.weight.view(H, c, di) * pooled[:, i].unsqueeze(1)).sum(-1) + att.v_proj.bias.view(H, c)).reshape(1, di)
-            outs.append(self.classifier[i](self._post(att, out1)))
+            head = self.classifier[i] if isinstance(self.classifier, nn.ModuleList) else self.classifier
+            outs.append(head(self._post(att, out1)))
         bag = self.bag_attention
+        if bag is None:                                                                            # (MHA: one branch, no bag head)
+            return torch.cat(outs, 0), None, attns
         pb = pooled.mean(1)                                                                        # mean_i softmax(.) is linear in P
         out1 = ((bag.v_proj.weight.view(H, c, di) * pb.unsqueeze(1)).sum(-1) + bag.v_proj.bias.view(H, c)).reshape(1, di)
         return torch.cat(outs, 0), self.Slide_classifier(self._post(bag, out1)), attns
@@ -904,3 +995,40 @@ class ACMIL_MHA(nn.Module):
         sd = {k: v.detach() for k, v in self.state_dict(keep_vars=True).items()}
         out = ops.mha_forward(x, sd, self.n_token, self.n_class, self.precision)
         return out["sub_preds"], out["slide_pred"].unsqueeze(0), out["attns"]
+
+
+
+class MHA(ACMIL_MHA):
+    """Drop-in for the reference's `MHA` (architecture/transformer.py:86-104; `--arch mha` of the generic trainer,
+    Step3_WSI_classification.py): ONE single-query multi-head attention branch over the projected bag and one classifier -- ACMIL_MHA with
+    one branch and without the bag head.  Same parameter names (`dimreduction`, `attention`, `q`, `classifier`), returns logits [1, C].
+    Runs the folded single-query form of csrc/mha.hip through acmil_amd.autograd in every mode (the O(N) passes are HIP kernels with HIP
+    backwards); Dropout(0.1) after out_proj applies in training mode as in the reference."""
+
+    def __init__(self, conf, *, precision="f16x3"):
+        nn.Module.__init__(self)
+        self.dimreduction = DimReduction(conf.D_feat, conf.D_inner)
+        self.attention = MutiHeadAttention(conf.D_inner, 8)
+        self.q = nn.Parameter(torch.zeros((1, 1, conf.D_inner)))
+        nn.init.normal_(self.q, std=1e-6)
+        self.n_class = conf.n_class
+        self.classifier = Classifier_1fc(conf.D_inner, conf.n_class, 0.0)
+        self.n_token = 1
+        self.precision = precision
+
+    # the pieces ACMIL_MHA._forward_train walks over, under this module's own parameter names
+    @property
+    def sub_attention(self):
+        return [self.attention]
+
+    @property
+    def bag_attention(self):
+        return None
+
+    def forward(self, input):
+        if input.dim() != 3 or input.shape[0] != 1:
+            raise RuntimeError("acmil_amd: MHA expects input [1, N, D_feat]")
+        x = input[0]
+        if not x.is_cuda:
+            raise RuntimeError("acmil_amd: MHA runs on an MI355X only (no CPU fallback)")
+        return self._forward_train(x.float().contiguous())[0]

@@ -207,10 +207,7 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
             // gradients = sums of the gate-pass records: one wave per element, lanes stride the records (gemm_finish_kernel's order)
             const int lane = tid & 63;
             e = (blk - a.blkA - a.blkB) * 4 + (tid >> 6);
-            if (e < a.rec_stride)
-                for (int r = lane; r < a.records; r += 64) s += a.rec[(size_t)r * a.rec_stride + e];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            s = gm_record_sum(a.rec, e < a.rec_stride ? a.records : 0, a.rec_stride, e < a.rec_stride ? e : 0, lane);
             mine = lane == 0 && e < a.rec_stride;
         } else {
             // final gradients: one lane per element of the same index space

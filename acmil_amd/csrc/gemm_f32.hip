@@ -434,10 +434,7 @@ __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmArgs g1, GemmArgs 
     if (blk < b1 + b2) { gm_reduce_body(g2, 1, blk - b1, b2); return; }
     const int e = (blk - b1 - b2) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= job.len) return;
-    float s = 0.0f;
-    for (int r = lane; r < job.records; r += 64) s += job.part[(size_t)r * job.stride + e];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    const float s = gm_record_sum(job.part, job.records, job.stride, e, lane);
     if (lane != 0) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q)

@@ -22,6 +22,26 @@ struct RowSumJob {
     float* dst[4];
 };
 
+// One element of the record sum by one wave: lanes stride the records (lane l adds records l, l + 64, ... in that order), then a
+// shuffle tree -- the summation order gemm_finish_kernel and ga_opt_step_kernel share (bit-identical results).  Eight loads are in
+// flight per lane: a group step has thousands of records (one per backward tile of every bag), and one dependent round trip per
+// record made the closing launch 61 us at 8 x 50 000 rows.
+__device__ __forceinline__ float gm_record_sum(const float* part, int records, int stride, int e, int lane) {
+    float s = 0.0f;
+    int r = lane;
+    for (; r + 7 * 64 < records; r += 8 * 64) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + 64 * j) * stride + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; r < records; r += 64) s += part[(size_t)r * stride + e];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
 // x3: 0 exact fp32 MFMA, 1 split-f16, 2 split-bf16 (as acmil_gemm_f32 / _f16x3 / _bf16x3).  Launches the product only; `out`
 // receives what gemm_finish needs (out->splits == 1: the product already wrote C with its epilogue).
 int gemm_run_deferred(int x3, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda, const void* B,

@@ -230,14 +230,17 @@ def broadcast_parameters(model, world: int):
 
 # ----------------------------------------------------------------------------------------------- loops
 def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Optional[GradBucket] = None,
-                    rank: int = 0, world: int = 1, log_every: int = 100, fused: bool = True) -> Dict[str, float]:
+                    rank: int = 0, world: int = 1, log_every: int = 100, fused: bool = True,
+                    order: Optional[Sequence[int]] = None, uniforms_fn=None) -> Dict[str, float]:
     """One epoch, one slide per iteration per rank (Step3_WSI_classification_ACMIL.py:175-227).
     fused=True uses the module's autograd-free `train_step` (fused HIP loss + backward); fused=False runs the
-    reference's op sequence through torch autograd on top of the HIP forward/backward node (same gradients)."""
+    reference's op sequence through torch autograd on top of the HIP forward/backward node (same gradients).
+    order / uniforms_fn (parity tests against a trajectory the reference's own loop produced): the slide order of this epoch instead of
+    the shuffle, and uniforms_fn(epoch, it) -> the [K, k] STKIM draw of iteration `it` instead of the device draw."""
     if int(getattr(conf, "bags_per_step", 1) or 1) > 1:
         return train_one_epoch_groups(model, data, optimizer, device, epoch, conf, bucket, rank, world, log_every, fused)
     model.train()
-    order = epoch_order(len(data), epoch, conf.seed, True, rank, world)
+    order = list(order) if order is not None else epoch_order(len(data), epoch, conf.seed, True, rank, world)
     sums = {"sub_loss": 0.0, "diff_loss": 0.0, "slide_loss": 0.0}
     acc = torch.zeros(4, device=device)          # loss sums stay on the device: no .item() sync per step
     use_fused = fused and hasattr(model, "train_step")
@@ -283,6 +286,7 @@ def train_one_epoch(model, data, optimizer, device, epoch: int, conf, bucket: Op
         if use_fused:
             # single GPU: the step applies the optimizer itself (its closing launch = gradient finish + AdamW + weight re-pack) where it can
             losses, out = model.train_step(x.unsqueeze(0), labels, guard_flag=optimizer.guard_flag if lagged else None,
+                                           **({"uniforms": uniforms_fn(epoch, it)} if uniforms_fn is not None else {}),
                                            **({"optimizer": optimizer, "track_flag": True, "in_step": in_step} if opt_aware else {}))
             sid = out.get("opt_step_id") if in_step else None
             if not lagged:

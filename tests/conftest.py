@@ -55,3 +55,24 @@ TRAIN_CASES = ["ga_train_n7_d512_k5_c2", "ga_train_n640_d512_k5_c2", "ga_train_n
 @pytest.fixture(scope="session")
 def have_gpu():
     return torch.cuda.is_available()
+
+
+def trajectory_bags(case):
+    """The five fp16 bags of ga_trajectory_d512_k5_c7 (tests/golden/make_golden_trajectory.py), regenerated from their generator seeds
+    and checked against the fixture's checksums (a torch build whose CPU randn stream differs would fail here, not silently)."""
+    bags = []
+    for (n, seed), chk in zip(case["bag_shapes"].tolist(), case["bag_checks"]):
+        b = torch.randn(1, n, 512, generator=torch.Generator().manual_seed(seed)).half()
+        got = np.array([float(b.float().sum()), float(b.float().abs().sum()), float(b[0, -1, -1])])
+        assert np.allclose(got, chk, rtol=0, atol=1e-6 * max(1.0, np.abs(chk).max())), "synthetic bag stream differs from the fixture's"
+        bags.append(b)
+    return bags
+
+
+def trajectory_stable(case, name, floor=1e-7, rel=0.0):
+    """Elements of parameter `name` whose Adam trajectory is a stable function of the gradient: every step's |g| >= floor and
+    >= rel x the tensor's largest such value.  (The update is ~ lr * g / (|g| + eps): a relative error e of g moves the step by ~ e * lr,
+    and on an element whose gradient is rounding noise the step is lr * sign(noise) -- attention_weights.bias, whose gradient is
+    analytically zero under the softmax, walks differently in ANY two fp32 implementations.)"""
+    m = case["mingrad." + name]
+    return (m >= floor) & (m >= rel * m.max())

@@ -132,10 +132,13 @@ def test_fixtures_load_into_modules():
     assert not missing and not unexpected
 
 
-def test_classifier_dropout_is_accepted_for_eval_and_refused_for_training():
-    """Classifier_1fc(droprate != 0) (reference network.py:10-16): same state_dict keys (nn.Dropout has no parameters), the module
-    constructs and may evaluate; a training-mode call is refused before anything is launched."""
-    from acmil_amd.architecture.transformer import ABMIL, ACMIL_GA
+def test_classifier_dropout_and_other_attention_widths_construct_and_route():
+    """Classifier_1fc(droprate != 0) (reference network.py:10-16) and Attention_Gated(D != 128) (transformer.py:240): same state_dict
+    keys as the reference's modules, the aggregators construct, and the routing is as documented -- eval mode with dropout stays on the
+    fused path (dropout is the identity there), training mode with dropout / another attention width / residual blocks take the
+    op-by-op path; none of them has a CPU fallback (a CPU tensor is refused by the library wrappers, not silently computed)."""
+    from acmil_amd.architecture.network import DimReduction
+    from acmil_amd.architecture.transformer import ABMIL, ACMIL_GA, MHA
 
     class Conf:
         D_feat, D_inner, n_class, n_token = 384, 128, 3, 5
@@ -143,13 +146,15 @@ def test_classifier_dropout_is_accepted_for_eval_and_refused_for_training():
     plain = ACMIL_GA(Conf, n_token=5)
     drop = ACMIL_GA(Conf, droprate=0.25, n_token=5)
     assert list(plain.state_dict()) == list(drop.state_dict())
-    drop.train()
-    with pytest.raises(NotImplementedError, match="classifier dropout"):
-        drop(torch.zeros(1, 4, 384))
-    ab = ABMIL(Conf, droprate=0.1).train()
-    with pytest.raises(NotImplementedError, match="classifier dropout"):
-        ab(torch.zeros(1, 4, 384))
-    drop.eval()
-    with pytest.raises(RuntimeError):          # eval mode passes the dropout check and reaches the library: a CPU tensor is refused there
-        with torch.no_grad():
-            drop(torch.zeros(1, 4, 384))
+    assert drop.train()._generic() and not drop.eval()._generic() and not plain.train()._generic()
+    wide = ACMIL_GA(Conf, D=64, n_token=5)
+    assert wide._generic() and wide.state_dict()["attention.attention_V.0.weight"].shape == (64, 128)
+    assert wide.state_dict()["attention.attention_weights.weight"].shape == (5, 64)
+    assert ABMIL(Conf, D=256)._generic() and ABMIL(Conf, droprate=0.1).train()._generic()
+    assert list(DimReduction(384, 128, numLayer_Res=2).state_dict()) == [
+        "fc1.weight", "resBlocks.0.block.0.weight", "resBlocks.0.block.2.weight", "resBlocks.1.block.0.weight", "resBlocks.1.block.2.weight"]
+    assert sorted(MHA(Conf).state_dict())[:3] == ["attention.k_proj.bias", "attention.k_proj.weight", "attention.layer_norm.bias"]
+    for m in (drop.train(), wide, drop.eval()):
+        with pytest.raises(RuntimeError):          # reaches the library wrappers: a CPU tensor is refused there
+            with torch.no_grad():
+                m(torch.zeros(1, 4, 384))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import EVAL_CASES, TRAIN_CASES, case_dims, load_golden
+from conftest import EVAL_CASES, TRAIN_CASES, case_dims, load_golden, trajectory_bags, trajectory_stable
 from oracle import ga_oracle as O
 
 
@@ -104,3 +104,34 @@ def test_fp64_ground_truth_close_to_fp32():
     o64 = O.acmil_ga_forward(x.double(), {k: v.double() for k, v in sd.items()}, n_token=5)
     assert (o32["A_out"].double() - o64["A_out"]).abs().max() < 2e-6
     assert (o32["sub_preds"].double() - o64["sub_preds"]).abs().max() < 2e-6
+
+
+def test_ten_step_trajectory_of_the_reference_loop():
+    """The oracle's forward / losses / schedule under torch.optim.AdamW reproduce the TEN-step trajectory the reference's own
+    train_one_epoch produced (two epochs over five slides: warm-up from lr 0, cosine, moments and bias corrections evolving):
+    per-step learning rates and losses, and the final parameters."""
+    case, sd = load_golden("ga_trajectory_d512_k5_c7")
+    bags = trajectory_bags(case)
+    params = {n: v.clone().requires_grad_(True) for n, v in sd.items()}
+    opt = torch.optim.AdamW(list(params.values()), lr=0.001, weight_decay=float(case["wd"]))
+    step = 0
+    for epoch, order in enumerate(case["orders"].tolist()):
+        for it, i in enumerate(order):
+            lr = O.adjust_learning_rate(epoch + it / len(order), float(case["lr"]), 0.0, float(case["warmup_epoch"]), float(case["train_epoch"]))
+            assert lr == pytest.approx(float(case["lrs"][step]), abs=1e-12)
+            for gq in opt.param_groups:
+                gq["lr"] = lr
+            out = O.acmil_ga_forward(bags[i].float(), params, n_token=5, n_masked_patch=10, mask_drop=0.6, training=True,
+                                     uniforms=torch.from_numpy(case["uniforms"][step]))
+            l0, l1, dl = O.acmil_losses(out["sub_preds"], out["slide_pred"], out["A_out"], torch.tensor([int(case["labels"][i])]), 5)
+            assert float(l0.detach()) == pytest.approx(float(case["losses"][step, 0]), abs=2e-6)
+            assert float(l1.detach()) == pytest.approx(float(case["losses"][step, 1]), abs=2e-6)
+            opt.zero_grad()
+            (dl + l0 + l1).backward()
+            opt.step()
+            step += 1
+    for n, p in params.items():
+        ok = trajectory_stable(case, n)
+        assert ok.mean() > 0.9 or n == "attention.attention_weights.bias", (n, ok.mean())
+        d = np.abs(p.detach().numpy() - case["final." + n])[ok]
+        assert d.max(initial=0.0) <= 1e-6, (n, d.max())
