@@ -125,6 +125,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int ND, int XDT, bool POOL, int WV, bool PAIR>
 struct Ga2Tri { static constexpr bool value = POOL && ND == 4 && XDT != ACMIL_DTYPE_F32 && WV == 4 && !PAIR; };
 
+#ifndef GA2_LOSKIP
+#define GA2_LOSKIP 1      // 0 (A/B builds, tools/build_variants.sh): always issue the W_hi x_lo products of an fp32 bag
+#endif
 template <int ND, int KP, int XDT, bool POOL, bool SAVEH, int WV = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 3 : 2)) void ga_fwd2_kernel(GaFwdArgs a) {
     static_assert(ND % 4 == 0, "D_inner must be a multiple of 128");
@@ -600,6 +603,15 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                         for (int j = 0; j < NSP; ++j) split_piece(j);
                     }
                     split_done(xh, xl);
+                    // fp32 bags whose values are f16-exact -- what real bags are: stored fp16 (Step2_feature_extract.py:165), up-cast by the
+                    // loop (Step3_WSI_classification_ACMIL.py:193) -- have lo halves of exact zeros: the wave looks at its 32 x 16 lo
+                    // values of this step (3 VALU ORs + one compare into a wave-uniform mask) and skips the W_hi x_lo group when all
+                    // are zero.  The skipped products are +-0: results are the same numbers (tests: equal to the three-product launch).
+                    bool lo_any = true;
+                    if constexpr (XLO && GA2_LOSKIP) {
+                        const unsigned lo_or = (xlw[0] | xlw[1] | xlw[2] | xlw[3]) & 0x7fff7fffu;
+                        lo_any = __builtin_amdgcn_ballot_w64(lo_or != 0u) != 0ull;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     read_lo(slot);
                     // P1(s), one LDS-DMA piece of step s+PD per MFMA gap (bag rows only while that step is still a GEMM1 step)
@@ -613,8 +625,10 @@ __global__ __launch_bounds__(64 * WV, (Ga2Tri<ND, XDT, POOL, WV, PAIR>::value ? 
                     }
                     islot = (islot + 1 == NB) ? 0 : islot + 1;
                     if constexpr (XLO) {
+                        if (lo_any) {
 #pragma unroll
-                        for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
+                            for (int d = 0; d < ND; ++d) acc1[d] = GA2_MFMA1(WH[d], xl, acc1[d]);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     xhp = xh;

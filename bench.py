@@ -217,15 +217,24 @@ def dry_run(args):
 
 
 def _timed(step, args, world, dev):
-    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks."""
+    """W untimed + exactly K timed steps, barrier + synchronize on both sides, max over ranks.  Python's cyclic collector is run
+    before and held off during the region: a full collection of this process takes tens of ms, i.e. as long as 20 steps of the
+    headline or 200 training steps, and whether one lands inside the region is chance (seen: 2.1 k instead of 11 k slides/s on the
+    per-slide module loop).  Nothing in the steps creates reference cycles that would need it."""
+    import gc
     for i in range(args.warmup):
         step(i)
-    _sync(world, dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    _sync(world, dev)
-    dt = time.perf_counter() - t0
+    gc.collect()
+    gc.disable()
+    try:
+        _sync(world, dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        _sync(world, dev)
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -748,6 +757,9 @@ def ga_workload(args, ctx):
         model = ACMIL_GA(_Conf, n_token=N_TOKEN, n_masked_patch=10, mask_drop=0.6, precision=args.precision)
         model.load_state_dict(sd_cpu)
         model = model.to(dev).eval()
+        import gc
+        gc.collect()
+        gc.disable()      # a full collection of this process (torch + modules: ~40 ms) inside the 100-call loop read as 2.1 k instead of 11 k slides/s
         with torch.no_grad():
             for i in range(5):
                 model(bags[i % N_BAGS].unsqueeze(0))
@@ -774,7 +786,9 @@ def ga_workload(args, ctx):
                 pend = status
             torch.cuda.synchronize()
             rate_b16 = n_mb * EB / (time.perf_counter() - tm)
-        module_rates = {"model(x) per slide": round(rate_b1, 1), "model.forward_batch x%d (as train.evaluate)" % EB: round(rate_b16, 1)}
+        gc.enable()
+        module_rates = {"model(x) per slide": round(rate_b1, 1), "model.forward_batch x%d (as train.evaluate)" % EB: round(rate_b16, 1),
+                        "range_fallbacks": int(model.range_fallbacks)}      # (device-side repeats that actually ran: 0 on in-range bags)
         del model
 
     # ---- data-faithful variant: the same bags as they are stored on disk, fp16 (Step2_feature_extract.py:165);
@@ -794,6 +808,22 @@ def ga_workload(args, ctx):
         torch.cuda.synchronize()
         sps_fp16 = n16 * B / (time.perf_counter() - t2)
         del bags16
+    # ---- ... and as the reference's LOOP hands them to the module: fp16-stored values up-cast to fp32 (Step3_WSI_classification_ACMIL.py:193
+    # `.to(device, dtype=torch.float32)`): fp32 bytes, but every x_lo half is an exact zero -- the kernel notices per wave and K step
+    # and skips the W_hi x_lo products (same results).  Measured last: it rounds the resident bags in place.
+    sps_fp32_exact = None
+    if not args.no_b1 and world == 1 and x_dtype == torch.float32 and args.precision == "f16x3":
+        for b in bags:
+            b.copy_(b.half())
+        for i in range(5):
+            step(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n16 = max(20, args.steps // 2)
+        for i in range(n16):
+            step(i)
+        torch.cuda.synchronize()
+        sps_fp32_exact = n16 * B / (time.perf_counter() - t2)
 
     nbytes, flops = algorithmic_work(N_PATCH, D_FEAT, D_INNER, N_TOKEN, N_CLASS, s_in=s_in)
     nbytes, flops = nbytes * B, flops * B            # one launch processes B slides
@@ -849,6 +879,7 @@ def ga_workload(args, ctx):
         "attention_fwd_ms_per_slide": round(dt / (args.steps * B) * 1e3, 4),
         "attention_fwd_ms_per_slide_b1": None if ms_b1 is None else round(ms_b1, 4),
         "slides_per_s_fp16_stored_bags": None if sps_fp16 is None else round(sps_fp16, 1),
+        "slides_per_s_fp32_bags_of_fp16_values": None if sps_fp32_exact is None else round(sps_fp32_exact, 1),
         "module_slides_per_s": module_rates,
         "roofline": roofline,
     }

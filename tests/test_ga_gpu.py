@@ -442,3 +442,42 @@ def test_d128_family_on_16bit_bags_three_workgroups_per_cu(xdtype):
         assert (out["bag_feat"][i].cpu() - ref["bag_feat"][0]).abs().max() < TOL
         single = ops.ga_forward(x, packed, dims, "f16x3")
         assert torch.equal(single["A_out"], out["A_out"][i]) and torch.equal(single["sub_preds"], out["sub_preds"][i])
+
+
+def test_fp32_bag_of_fp16_values_skips_the_lo_products_with_identical_results():
+    """What the reference's loop hands the module is fp16-stored features up-cast to fp32 (Step2_feature_extract.py:165,
+    Step3_WSI_classification_ACMIL.py:193): every x_lo half is an exact zero, the kernel notices per wave and K step and skips the
+    W_hi x_lo MFMA group.  Skipped products are exact zeros: per-patch scores and logits equal those of the fp16-stored launch (which
+    never forms x_lo) bit for bit; in a bag that mixes f16-exact and other patches -- also inside one 32-patch wave tile -- every patch
+    keeps the score it has in its own kind of bag."""
+    from acmil_amd import ops
+    from oracle import ga_oracle as O
+    N, D, Di, K, C = 5000, 512, 256, 5, 2
+    sd = {k: v.cuda() for k, v in O.default_state_dict(D, Di, C, K).items()}
+    packed, dims = ops.ga_pack_weights(
+        sd["dimreduction.fc1.weight"], sd["attention.attention_V.0.weight"], sd["attention.attention_V.0.bias"],
+        sd["attention.attention_U.0.weight"], sd["attention.attention_U.0.bias"], sd["attention.attention_weights.weight"],
+        sd["attention.attention_weights.bias"], [sd["classifier.%d.fc.weight" % i] for i in range(K)],
+        [sd["classifier.%d.fc.bias" % i] for i in range(K)], sd["Slide_classifier.fc.weight"], sd["Slide_classifier.fc.bias"], "f16x3")
+    x = O.synthetic_bag(N, D, 5)[0].cuda()
+    x16 = x.half()
+    o_full = ops.ga_forward(x, packed, dims, "f16x3")
+    o_16 = ops.ga_forward(x16, packed, dims, "f16x3")
+    o_exact = ops.ga_forward(x16.float(), packed, dims, "f16x3")
+    for key in ("A_out", "sub_preds", "slide_pred"):
+        assert torch.equal(o_exact[key], o_16[key]), key
+    h = 2003                                   # not a multiple of 32: one wave tile holds both kinds of patches
+    mixed = x.clone()
+    mixed[:h] = x16[:h].float()
+    o_mixed = ops.ga_forward(mixed, packed, dims, "f16x3")
+    assert torch.equal(o_mixed["A_out"][:, :h], o_16["A_out"][:, :h])
+    assert torch.equal(o_mixed["A_out"][:, h:], o_full["A_out"][:, h:])
+    ref = O.acmil_ga_forward(mixed.cpu().unsqueeze(0), {k: v.cpu() for k, v in sd.items()}, n_token=K)
+    assert (o_mixed["A_out"].cpu() - ref["A_out"][0]).abs().max().item() < 1e-4
+    assert (o_mixed["sub_preds"].cpu() - ref["sub_preds"]).abs().max().item() < 1e-4
+    # batched launch, a training score pass (h saved) and the module path see the same skip
+    outs = ops.ga_forward_batch([x16.float(), x], packed, dims, "f16x3")
+    assert torch.equal(outs["A_out"][0], o_16["A_out"]) and torch.equal(outs["A_out"][1], o_full["A_out"])
+    A_s, h_s = ops.ga_scores(x16.float(), packed, dims, "f16x3")
+    A_h, h_h = ops.ga_scores(x16, packed, dims, "f16x3")
+    assert torch.equal(A_s, A_h) and torch.equal(h_s, h_h)

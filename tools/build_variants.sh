@@ -15,7 +15,7 @@ for spec in "$@"; do
   (
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$SRC -Wno-unused-value \
       -DGA_ND=$ND -DGA_KP=$KP -DGA_MODE=$MODE -DGA2_TOOLS -I$ROOT/tools $flags -c $SRC/ga_forward_inst.hip -o $OUT/ga_fwd_${FAM}_$name.o
-  objs=$(ls $SRC/build/*.o | grep -v "ga_fwd_${FAM}.o")
+  objs=$(ls $SRC/build/*.o | grep -v "ga_fwd_${FAM}.o" | grep -v "/ab_")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libacmil_$name.so $objs $OUT/ga_fwd_${FAM}_$name.o
   rm -f $OUT/ga_fwd_${FAM}_$name.o
   echo "built $OUT/libacmil_$name.so  ($flags)"
