@@ -42,7 +42,7 @@ struct WgProb {
     const float* A; const void* B; float* ws;
     int lda, ldb, b_dtype, M, N, tiles_n, tiles, splits, kchunk;
 };
-struct WgArgs { WgProb p[2]; int blocks0, K; };
+struct WgArgs { WgProb p[2]; int blocks0, K, xcd; };      // xcd != 0: the tiles of a K split share one XCD (see wgrad_kernel)
 
 __device__ __forceinline__ void wg_split_store(char* hi_plane, char* lo_plane, int off, const f32x4 v) {
     unsigned h0, l0, h1, l1;
@@ -221,10 +221,26 @@ __device__ __forceinline__ void wg_body(const WgProb& P, int K, int tile, int sp
 template <int TM, int TN>
 __global__ __launch_bounds__((WgGeom<TM, TN>::THREADS), (TN == 256 ? 1 : 2)) void wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int pr = (int)blockIdx.x >= a.blocks0 ? 1 : 0;
+    int pr, tile, split;
+    if (a.xcd) {
+        // Workgroups are dealt to the 8 XCDs round robin by their index.  ALL output tiles of one K split (both products) go to one
+        // XCD and run there side by side (one workgroup per CU, the whole grid is resident): the two tiles that read the same 256
+        // columns of x / h, or the same 128 columns of dpre, walk the same rows at the same pace, so the second request for a
+        // line is served by that XCD's L2 instead of HBM (each operand line has exactly two readers; with every tile on its own
+        // XCD the operands crossed HBM twice: 358 MB per 50 000 rows where they are 205 MB).
+        const int tt = a.p[0].tiles + a.p[1].tiles;
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = x + 8 * (j / tt);
+        const int ti = j % tt;
+        pr = ti >= a.p[0].tiles ? 1 : 0;
+        tile = pr ? ti - a.p[0].tiles : ti;
+        if (split >= a.p[0].splits) return;
+    } else {
+        pr = (int)blockIdx.x >= a.blocks0 ? 1 : 0;
+        const int b = blockIdx.x - (pr ? a.blocks0 : 0);
+        tile = b % a.p[pr].tiles; split = b / a.p[pr].tiles;
+    }
     const WgProb& P = a.p[pr];
-    const int b = blockIdx.x - (pr ? a.blocks0 : 0);
-    const int tile = b % P.tiles, split = b / P.tiles;
     if (P.b_dtype == ACMIL_DTYPE_F32) wg_body<ACMIL_DTYPE_F32, TM, TN>(P, a.K, tile, split, smem);
     else if (P.b_dtype == ACMIL_DTYPE_F16) wg_body<ACMIL_DTYPE_F16, TM, TN>(P, a.K, tile, split, smem);
     else wg_body<ACMIL_DTYPE_BF16, TM, TN>(P, a.K, tile, split, smem);
@@ -239,9 +255,12 @@ static int wg_tile_n(int N1, int N2, int K) {
 }
 // K split shared by both products: two (128 x 128) / one (128 x 256) workgroups per CU over the two tile lists, at least 4 K steps per workgroup
 static int wg_target_wgs(int TN) { static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_WGRAD_WGS"); return e ? atoi(e) : 0; }(); return v > 0 ? v : (TN == 256 ? 256 : 512); }   // (128 x 128, measured 256..768: 512 is 24 us faster than 256 at N = 50 000)
+// the tiles of a split on one XCD (128 x 256 tiles only: one workgroup per CU, the grid resident at once); ACMIL_WGRAD_XCD=0: A/B builds
+static int wg_xcd() { static const int v = [] { const char* e = ACMIL_AB_ENV("ACMIL_WGRAD_XCD"); return e ? atoi(e) : 1; }(); return v; }
 static int wg_pick_splits(int tiles_total, int K, int TN) {
     const int steps = (K + 31) / 32;
     int s = TN == 256 ? wg_target_wgs(TN) / tiles_total : (wg_target_wgs(TN) + tiles_total - 1) / tiles_total;
+    if (TN == 256 && wg_xcd() && s >= 8) s = s / 8 * 8;          // whole splits per XCD: tiles_total * s / 8 workgroups on each (<= 32 CUs)
     if (s > steps / 4) s = steps / 4;
     if (s > 128) s = 128;
     return s < 2 ? 0 : s;           // 0: not worth it (tiny bag) -> the caller keeps the generic path
@@ -297,7 +316,9 @@ int wgrad_launch(const float* A1, int lda1, const void* B1, int b1_dtype, int ld
     a.p[0] = WgProb{A1, B1, ws1, lda1, ldb1, b1_dtype, M1, N1, N1 / TN, t1, splits, kchunk};
     a.p[1] = WgProb{A2, B2, ws2, lda2, ldb2, b2_dtype, M2, N2, N2 / TN, t2, splits, kchunk};
     a.blocks0 = t1 * splits;
-    const int rc = TN == 256 ? wg_launch_t<128, 256>(a, (t1 + t2) * splits, st) : wg_launch_t<128, 128>(a, (t1 + t2) * splits, st);
+    a.xcd = (TN == 256 && wg_xcd() && (t1 + t2) * ((splits + 7) / 8) <= 32) ? 1 : 0;
+    const int grid = a.xcd ? 8 * (t1 + t2) * ((splits + 7) / 8) : (t1 + t2) * splits;
+    const int rc = TN == 256 ? wg_launch_t<128, 256>(a, grid, st) : wg_launch_t<128, 128>(a, grid, st);
     if (rc != ACMIL_OK) return rc;
     auto fill = [&](GemmArgs* g, float* C, int M, int N, float* ws) {
         memset(g, 0, sizeof(*g));
