@@ -185,7 +185,7 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
     LinArgs a;
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = act; a.beta = beta; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0;
-    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
+    a.rowab = nullptr; a.wsum = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0;
     a.nt_store = lin_nt_store(M, n_out, beta);
     a.status = ctr + 2;          // workspace word 2: range status of this call (zeroed by the memset above)
     const LinPlan P = lin_plan(n_out, lin_wide8());
@@ -209,20 +209,47 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
 // rowab [M][2] = (rstd, -mean * rstd) per row (0, 0 for r < zrows) from tm_rowstats_kernel; `packed` = the stream of W o gamma
 // (lin_pack_multi with colscale = gamma); bias = W beta.  lm_part (or null): per-wave-tile column sums of the first lm_cols output
 // columns, split at the landmark boundary (see LinArgs).  Control words as lin_f16x3_run with init = false.
+// Round 6: rowab == null and wsum [n_out] given (wsum[c] = sum_k (W o gamma)[c][k]): the row statistics are formed inside the launch
+// (LinArgs::wsum, FX & 4) -- no statistics pass over x at all.  lin_qkv_norm_instat_ok tells whether this launch plan has that form
+// (the 4-wave lin_kernel; the 64-row / 8-wave A/B geometries keep the statistics pass).
+bool lin_qkv_norm_instat_ok(int M, int K, int n_out) {
+    static const bool off = ACMIL_AB_ENV("ACMIL_TM_ROWSTATS") != nullptr;      // A/B knob: keep tm_rowstats_kernel
+    if (off || lin_wide8() || !lin_dims_ok(n_out, K)) return false;
+    const LinPlan P = lin_plan(n_out, false);
+    return !(P.nmain > 0 && lin_use64(M, K, P.nmain, P.nd));
+}
+
 int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
-                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st) {
+                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st,
+                     const float* wsum) {
     if (M <= 0 || !lin_dims_ok(n_out, K) || ldx < K || ldy < n_out || zrows < 0) return ACMIL_ERR_SHAPE;
-    if (!x || !rowab || !packed || !bias || !y || !workspace) return ACMIL_ERR_NULL;
+    if (!x || (!rowab && !wsum) || !packed || !bias || !y || !workspace) return ACMIL_ERR_NULL;
+    const bool instat = rowab == nullptr;
+    if (instat && (!lin_qkv_norm_instat_ok(M, K, n_out) || ((size_t)wsum & 15) != 0)) return ACMIL_ERR_UNSUPPORTED;
     if (((size_t)x & 15) != 0 || ((size_t)ldx * 4) % 16 != 0 || ((size_t)y & 15) != 0 || ldy % 4 != 0 || ((size_t)rowab & 7) != 0) return ACMIL_ERR_SHAPE;
     if (lm_part && (lm_l < 32 || lm_cols % 32 != 0 || lm_cols > n_out)) return ACMIL_ERR_SHAPE;
     unsigned* ctr = (unsigned*)workspace;
     LinArgs a;
     a.x = x; a.ldx = ldx; a.M = M; a.K = K; a.bias = bias; a.act = 0; a.beta = 0.0f; a.y = y; a.ldy = ldy;
     a.ww = nullptr; a.bw = nullptr; a.scores = nullptr; a.kb = 0; a.status = nullptr;
-    a.rowab = rowab; a.zrows = zrows; a.lm_part = lm_part; a.lm_l = lm_l; a.lm_cols = lm_part ? lm_cols : 0;
+    a.rowab = rowab; a.wsum = instat ? wsum : nullptr; a.zrows = zrows; a.lm_part = lm_part; a.lm_l = lm_l; a.lm_cols = lm_part ? lm_cols : 0;
     a.nt_store = lin_nt_store(M, n_out, 0.0f);
     const LinPlan P = lin_plan(n_out, lin_wide8());
     int rc = ACMIL_OK;
+    if (instat) {
+        if (P.nmain > 0) {
+            a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
+            rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 7>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 7>(a, st);
+            if (rc != ACMIL_OK) return rc;
+        }
+        if (P.nd_rem) {
+            const int c0 = P.nmain * 32 * P.nd;
+            a.packed = (const char*)packed + (size_t)P.nmain * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = 1; a.col0 = c0;
+            a.bias = bias + c0; a.wsum = wsum + c0; a.tile_counter = ctr + 16; a.done = ctr + 5;
+            rc = lin_launch<4, ACMIL_DTYPE_F32, 7>(a, st);
+        }
+        return rc;
+    }
     if (P.nmain > 0) {
         a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
         if (lin_wide8()) rc = lin_launch<8, ACMIL_DTYPE_F32, 3, 8>(a, st);
@@ -261,7 +288,7 @@ extern "C" int acmil_gated_scores_packed(const void* h, int h_dtype, int N, int 
     unsigned* ctr = (unsigned*)workspace;
     if (hipMemsetAsync(ctr, 0, LIN_CTRL_BYTES, st) != hipSuccess) return ACMIL_ERR_LAUNCH;
     LinArgs a;
-    a.rowab = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0; a.nt_store = 0;
+    a.rowab = nullptr; a.wsum = nullptr; a.zrows = 0; a.lm_part = nullptr; a.lm_l = 0; a.lm_cols = 0; a.nt_store = 0;
     a.x = h; a.ldx = ldh; a.M = N; a.K = L; a.bias = bias_vu; a.act = 2; a.beta = 0.0f; a.y = nullptr; a.ldy = 0;
     a.packed = (const char*)packed_vu; a.nchunks = 1; a.col0 = 0; a.tile_counter = ctr + 8; a.done = nullptr;
     a.ww = Ww; a.bw = bw; a.scores = A; a.kb = K; a.status = nullptr;

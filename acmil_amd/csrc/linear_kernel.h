@@ -61,6 +61,12 @@ struct LinArgs {
     // W beta is the bias).  Rows r < zrows are the zero padding of the sequence (rowab = 0, 0): they get NO bias either.
     const float* rowab;             // [M][2]
     int zrows;
+    // FX & 4 (with FX & 1; round 6): the row statistics are formed IN this kernel's K loop instead of by a pass of their own over x
+    // (tm_rowstats_kernel: 154 MB read per layer at cfg4 for two numbers per row).  W ((x - mean) rstd) = rstd (W x - mean (W 1)):
+    // the B operand is the RAW x, every lane adds up sum x and sum x^2 of its row while the values pass through its registers on
+    // their way to the f16 split (one add + one FMA per value instead of the normalising FMA), and the epilogue forms
+    // rstd * (acc - mean * wsum[col]) before the bias; wsum[c] = sum_k (W o gamma)[c][k].  rowab is not read.
+    const float* wsum;              // [n_out of this launch]
     // FX & 2 (landmark partials, nystrom_attention.py:95-111): every wave tile also leaves the column sums of its 32 output rows,
     // split at the landmark boundary that may cross it: lm_part[(m0 / 32) * 2 + part][lm_cols] for the columns < lm_cols (q and k);
     // part 0 = rows of landmark (m0 / lm_l), part 1 = rows of the next one.  Fixed summation order (bitwise reproducible); needs lm_l >= 32.
@@ -81,7 +87,8 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
     // operand is f16-exact like an fp16 one (ga_forward_kernel_v2.h) and is only converted
     constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);
     constexpr bool XCV = XLO || (XDT != ACMIL_DTYPE_F16);
-    constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0;
+    constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0, INSTAT = (FX & 4) != 0;
+    static_assert(!INSTAT || NORM, "FX & 4 extends the LayerNorm fold");
     static_assert(PD == 2 && NB == 3, "wait counts assume a prefetch distance of 2 steps");
     static_assert(G::REGION >= 4608 || !G::SCRATCH_IN_RING, "transposition tile must fit the free slot");
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
     // FX & 1: (a, b) of this lane's row of x (row = lane & 31 of the wave tile, clamped like the DMA), one tile ahead
     auto load_ab = [&](const TileInfo& ti) {
         f32x2 ab = {1.0f, 0.0f};
-        if constexpr (NORM) {
+        if constexpr (NORM && !INSTAT) {
             const int i31 = (int)(tid & 31);
             const int m0c = ti.m0 < M ? ti.m0 : M - 1;
             ab = *(const f32x2*)(a.rowab + 2 * (size_t)(m0c + (i31 < ti.rmax ? i31 : ti.rmax)));
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
             };
             constexpr int NSP = XCV ? 4 : 0;
             u32x4 xhw, xlw;
+            float rsum = 0.0f, rsq = 0.0f;      // INSTAT: sum x, sum x^2 of this lane's K slots of its row
             auto split_piece = [&](int j) {
                 float v0, v1;
                 if constexpr (XDT == ACMIL_DTYPE_F32) {
@@ -254,7 +262,8 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
                     v0 = __builtin_bit_cast(float, xrw[j] << 16);
                     v1 = __builtin_bit_cast(float, xrw[j] & 0xffff0000u);
                 }
-                if constexpr (NORM) { v0 = fmaf(v0, rab[0], rab[1]); v1 = fmaf(v1, rab[0], rab[1]); }
+                if constexpr (INSTAT) { rsum += v0 + v1; rsq = fmaf(v0, v0, rsq); rsq = fmaf(v1, v1, rsq); }
+                else if constexpr (NORM) { v0 = fmaf(v0, rab[0], rab[1]); v1 = fmaf(v1, rab[0], rab[1]); }
                 if constexpr (XLO) {
                     unsigned h, l;
                     ga2_split_pair(v0, v1, h, l);
@@ -323,6 +332,26 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL[d], xhp, acc[d], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            if constexpr (INSTAT) {
+                // the two lane halves hold complementary K slots of the same row: fold, then mean / rstd of LayerNorm (eps 1e-5,
+                // transMIL.py:12) -- and the accumulators become the product with the NORMALISED row right here, in their own layout
+                // (lane = row, register = output column), so that everything below (bias, stores, landmark sums) is unchanged
+                rsum += __shfl_xor(rsum, 32);
+                rsq += __shfl_xor(rsq, 32);
+                const float invk = 1.0f / (float)a.K;
+                const float mean = rsum * invk;
+                const float var = fmaxf(fmaf(rsq, invk, -mean * mean), 0.0f);
+                const float rstd = 1.0f / sqrtf(var + 1e-5f);
+                const float mr = -mean * rstd;
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 w4 = *(const f32x4*)(a.wsum + T.col + 32 * d + 8 * q + 4 * hi);      // columns of registers 4q .. 4q + 3
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[d][4 * q + e] = fmaf(acc[d][4 * q + e], rstd, mr * w4[e]);
+                    }
+            }
         }
 
         // ======================================================= epilogue (gated scores): gate in registers, K scores per row

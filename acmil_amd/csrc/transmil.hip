@@ -112,28 +112,33 @@ __global__ __launch_bounds__(256) void tm_rowstats_kernel(const float* __restric
     if (lane == 0) *(f32x2*)(ab + 2 * r) = f32x2{rstd, -mean * rstd};
 }
 
-// bias of the LayerNorm-folded to_qkv: wb[job][c] = sum_k W[c][k] beta[k]  (one wave per output column; both layers in one launch)
-struct TmWbJobs { const float* W[2]; const float* beta[2]; float* out[2]; };
+// bias of the LayerNorm-folded to_qkv: wb[job][c] = sum_k W[c][k] beta[k], and (round 6) the row sums of the folded weights
+// wsum[job][c] = sum_k W[c][k] gamma[k] -- what the in-kernel row statistics multiply the mean with (LinArgs::wsum)
+// (one wave per output column; both layers in one launch)
+struct TmWbJobs { const float* W[2]; const float* beta[2]; float* out[2]; const float* gamma[2]; float* wsum[2]; };
 __global__ __launch_bounds__(256) void tm_wbeta_kernel(TmWbJobs J, int n_out, int K) {
     const int lane = threadIdx.x & 63, job = blockIdx.y;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_out) return;
     const float* w = J.W[job] + (size_t)c * K;
     const float* b = J.beta[job];
-    float t = 0.0f;
-    for (int k = lane; k < K; k += 64) t = fmaf(w[k], b[k], t);
+    const float* gm = J.gamma[job];
+    float t = 0.0f, u = 0.0f;
+    for (int k = lane; k < K; k += 64) { t = fmaf(w[k], b[k], t); u = fmaf(w[k], gm[k], u); }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-    if (lane == 0) J.out[job][c] = t;
+    for (int o = 32; o >= 1; o >>= 1) { t += __shfl_xor(t, o); u += __shfl_xor(u, o); }
+    if (lane == 0) { J.out[job][c] = t; J.wsum[job][c] = u; }
 }
 
 // landmark means from the per-wave-tile column sums the to_qkv launch left (LinArgs::lm_part): QL / KL [h][m][d] = (1 / l) * sum of the
 // partials of the 32-row tiles that overlap rows [j l, (j + 1) l), tiles in index order (fixed order: bitwise reproducible).
 // Tile t (rows 32 t ..) belongs with part 0 to landmark (32 t) / l and with part 1 to the next one (l >= 32: at most two).
 __global__ __launch_bounds__(256) void tm_landmark_reduce_kernel(const float* __restrict__ part, int l, int m, int Di, float* __restrict__ QL,
-                                                                float* __restrict__ KL) {
+                                                                float* __restrict__ KL, unsigned* __restrict__ scal_zero) {
     const int j = blockIdx.x, cols = 2 * Di, d = Di / TM_HEADS;
     const int c = blockIdx.y * 256 + threadIdx.x;
+    // (the two atomic-max words of this layer's Moore-Penrose scaling, where no statistics pass is left to zero them)
+    if (scal_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) scal_zero[threadIdx.x] = 0u;
     if (c >= cols) return;
     const int t0 = (int)(((long long)j * l) >> 5), t1 = (int)((((long long)(j + 1) * l) - 1) >> 5);
     const float inv = 1.0f / (float)l;
@@ -707,7 +712,7 @@ static TmWs tm_ws(const TmGeom& g) {
     // LayerNorm-folded to_qkv: row statistics, landmark partials of the q / k columns per 32-row tile, W beta of both layers
     w.AB = off; off += tm_al((size_t)g.npad * 2 * 4);
     w.LMP = off; off += tm_al((size_t)(g.npad / 32 + 1) * 2 * 2 * g.Di * 4);
-    w.WB = off; off += tm_al((size_t)2 * 3 * g.Di * 4);
+    w.WB = off; off += tm_al((size_t)4 * 3 * g.Di * 4);      // W beta of both layers, then the row sums of W o gamma of both layers
     // split-K scratch: the largest need over EVERY product of the forward (a small bag with a wide feature vector splits
     // products that never split at slide scale, e.g. fc1 at N = 400, D = 1536)
     const int H = TM_HEADS, m = g.m, d = g.d, np_ = g.npad, Di = g.Di;
@@ -814,8 +819,10 @@ int lin_f16x3_run(const void* x, int x_dtype, int M, int K, long long ldx, const
                   float beta, float* y, long long ldy, void* workspace, hipStream_t st, bool init);
 int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, const int* K, void* const* packed, int n, hipStream_t st,
                    const float* const* colscale);
+bool lin_qkv_norm_instat_ok(int M, int K, int n_out);
 int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
-                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st);
+                     const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st,
+                     const float* wsum = nullptr);
 
 // y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
 // Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
@@ -850,7 +857,7 @@ static int tm_softmax_short(float* x, long long rows, int cols, hipStream_t st) 
 
 // one TransLayer in place on X [npad][Di] (token i at row pad + i):  X[pad:] += to_out(attention(LayerNorm(X[pad:])))
 static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const TmLayerW& p, hipStream_t st, char* pk_qkv = nullptr,
-                    char* pk_out = nullptr, const float* wbeta = nullptr, TmSide* side = nullptr) {
+                    char* pk_out = nullptr, const float* wbeta = nullptr, TmSide* side = nullptr, const float* wsum = nullptr) {
     const int Di = g.Di, m = g.m, d = g.d, npad = g.npad, H = TM_HEADS;
     float* LN = (float*)(ws + W.LN); float* QKV = (float*)(ws + W.QKV) + (size_t)TM_QKV_GUARD * 3 * g.Di; float* S1 = (float*)(ws + W.S1);
     float* S3 = (float*)(ws + W.S3); float* OUT = (float*)(ws + W.OUT); float* QL = (float*)(ws + W.QL);
@@ -861,18 +868,24 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     const float scale = 1.0f / sqrtf((float)d);
     const long long mm = (long long)m * m, md = (long long)m * d;
 
+    bool instat = false;
     if (wbeta) {
         // LayerNorm folded into to_qkv (round 4): row statistics -> the projection normalises its B operand in registers (gamma is in
         // the packed weights, W beta is the bias) and leaves the landmark column sums of q and k per 32-row tile -> a small reduce.
         // Gone: the LayerNorm pass (read + write of [npad, Di]) and the landmark pass (re-read of the q / k columns of QKV).
         float* AB = (float*)(ws + W.AB); float* LMP = (float*)(ws + W.LMP);
-        hipLaunchKernelGGL(tm_rowstats_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, AB, g.n, Di, g.pad, scal);
-        TM_CHECK_LAUNCH();
+        // round 6: the row statistics come out of to_qkv's own K loop (linear_kernel.h, FX & 4) -- no pass over X for them
+        instat = wsum != nullptr && lin_qkv_norm_instat_ok(npad, Di, 3 * Di);
+        if (!instat) {
+            hipLaunchKernelGGL(tm_rowstats_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, AB, g.n, Di, g.pad, scal);
+            TM_CHECK_LAUNCH();
+        }
         const bool lm = g.l >= 32;
-        const int rq = lin_qkv_norm_run(X, npad, Di, Di, AB, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, lm ? LMP : nullptr, g.l, 2 * Di, ws + W.LINWS, st);
+        const int rq = lin_qkv_norm_run(X, npad, Di, Di, instat ? nullptr : AB, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, lm ? LMP : nullptr, g.l, 2 * Di,
+                                        ws + W.LINWS, st, instat ? wsum : nullptr);
         if (rq != ACMIL_OK) return rq;
         if (lm) {
-            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL);
+            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL, instat ? scal : nullptr);
             TM_CHECK_LAUNCH();
         }
     } else {
@@ -884,7 +897,7 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     if (!wbeta || g.l < 32) {
         int phases = 1024 / (Di / 4); if (phases > 8) phases = 8; if (phases > g.l) phases = g.l; if (phases < 1) phases = 1;
         const int threads = ((Di / 4) * phases + 63) / 64 * 64;
-        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, wbeta ? nullptr : scal);
+        hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, (wbeta && !instat) ? nullptr : scal);
     }
     TM_CHECK_LAUNCH();
     // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
@@ -1034,7 +1047,7 @@ static int tm_forward_impl(const float* x, int N, int D, int Di, int C, const fl
             if (rp == ACMIL_OK && packs_forked) rp = lin_pack_multi(Wp + 1, ldw + 1, no + 1, Kk + 1, outp + 1, 4, sp, cs + 1);
             if (rp == ACMIL_OK && fold_ln) {
                 float* wb = (float*)(ws + W.WB);
-                TmWbJobs J = {{l1.qkv_w, l2.qkv_w}, {l1.norm_b, l2.norm_b}, {wb, wb + 3 * Di}};
+                TmWbJobs J = {{l1.qkv_w, l2.qkv_w}, {l1.norm_b, l2.norm_b}, {wb, wb + 3 * Di}, {l1.norm_w, l2.norm_w}, {wb + 6 * Di, wb + 9 * Di}};
                 hipLaunchKernelGGL(tm_wbeta_kernel, dim3((3 * Di + 3) / 4, 2), dim3(256), 0, sp, J, 3 * Di, Di);
                 if (hipGetLastError() != hipSuccess) rp = ACMIL_ERR_LAUNCH;
             }
@@ -1057,7 +1070,7 @@ static int tm_forward_impl(const float* x, int N, int D, int Di, int C, const fl
     TM_CHECK_LAUNCH();
     const float* wb = (const float*)(ws + W.WB);
     if (packs_forked && hipStreamWaitEvent(st, side->join, 0) != hipSuccess) return ACMIL_ERR_LAUNCH;      // the layer streams are packed
-    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr, side); if (rc != ACMIL_OK) return rc;
+    int rc = tm_layer(g, W, ws, XA, l1, st, pkq[0], pko[0], fold_ln ? wb : nullptr, side, fold_ln ? wb + 6 * Di : nullptr); if (rc != ACMIL_OK) return rc;
     if (dbg_h1) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XA + (size_t)g.pad * Di, dbg_h1, tokbytes); TM_CHECK_LAUNCH(); }
     // PPEG: cls passthrough + combined depth-wise 7x7 (the folded stencil was packed beside fc1 when the side stream is in use)
     const float* cls_in = XA + (size_t)g.pad * Di; float* cls_out = XB + (size_t)g.pad * Di;
@@ -1078,7 +1091,7 @@ static int tm_forward_impl(const float* x, int N, int D, int Di, int C, const fl
     }
     TM_CHECK_LAUNCH();
     if (dbg_hp) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_hp, tokbytes); TM_CHECK_LAUNCH(); }
-    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1], fold_ln ? wb + 3 * Di : nullptr, side); if (rc != ACMIL_OK) return rc;
+    rc = tm_layer(g, W, ws, XB, l2, st, pkq[1], pko[1], fold_ln ? wb + 3 * Di : nullptr, side, fold_ln ? wb + 9 * Di : nullptr); if (rc != ACMIL_OK) return rc;
     if (dbg_h2) { hipLaunchKernelGGL(tm_copy_kernel, dim3(512), dim3(256), 0, st, XB + (size_t)g.pad * Di, dbg_h2, tokbytes); TM_CHECK_LAUNCH(); }
     // final LayerNorm on the cls row only, then fc2 (exact fp32 FMAs)
     hipLaunchKernelGGL(tm_cls_head_kernel, dim3(1), dim3(256), 0, st, XB + (size_t)g.pad * Di, Di, norm_w, norm_b, fc2_w, fc2_b, C, logits);

@@ -29,6 +29,9 @@ python tools/pmc_ga.py --workload ga_gigapath --batch 1 --whole-step --steps 30 
 fi
 python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
 python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --extra "--train-n 50000" --out $OUT/pmc > $OUT/pmc_train50k.log 2>&1
+# group steps (round 6): --batch 100 + G / 500 + G only name the files (bench.py looks the traffic of a group line up under those names)
+python tools/pmc_ga.py --workload train --batch 108 --whole-step --steps 40 --extra "--bags-per-step 8" --out $OUT/pmc > $OUT/pmc_train10k_g8.log 2>&1
+python tools/pmc_ga.py --workload train --batch 508 --whole-step --steps 20 --extra "--train-n 50000 --bags-per-step 8" --out $OUT/pmc > $OUT/pmc_train50k_g8.log 2>&1
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
 for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
@@ -59,6 +62,9 @@ PY
 }
 best_of3 $OUT/bench_train_n10k.json --workload train > $OUT/bench_train_runs.log
 best_of3 $OUT/bench_train_n50k.json --workload train --train-n 50000 >> $OUT/bench_train_runs.log
+best_of3 $OUT/bench_train_n10k_g8.json --workload train --bags-per-step 8 --steps 100 --warmup 20 >> $OUT/bench_train_runs.log
+best_of3 $OUT/bench_train_n50k_g8.json --workload train --train-n 50000 --bags-per-step 8 --steps 40 --warmup 8 >> $OUT/bench_train_runs.log
+python bench.py --workload train --bags-per-step 16 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_train_n10k_g16.json 2>> $OUT/bench_train.log
 if [ -z "$ONLY_TRAIN" ]; then
 run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline --no-secondary
 run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
@@ -69,6 +75,8 @@ run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-base
 fi
 run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
 run_stats bench_train_n50k --workload train --train-n 50000 --steps 200 --warmup 20 --no-cpu-baseline
+run_stats bench_train_n10k_g8 --workload train --bags-per-step 8 --steps 60 --warmup 10 --no-cpu-baseline
+run_stats bench_train_n50k_g8 --workload train --train-n 50000 --bags-per-step 8 --steps 30 --warmup 8 --no-cpu-baseline
 tail -c 1500 $OUT/bench_driver_args.json; echo
 for f in $OUT/bench_*_kernel_stats.csv; do echo == $f; head -12 $f | cut -c1-150; done
 ls $OUT
