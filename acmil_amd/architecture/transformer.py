@@ -882,22 +882,57 @@ class _AdamwPackHook:
 
 
 class MutiHeadAttention(nn.Module):
-    """Parameter container with the reference's names (architecture/transformer.py:107-140): q/k/v/out projections and a
-    LayerNorm(eps=1e-6).  The arithmetic lives in acmil_mha_forward (csrc/mha.hip); dropout is eval-identity."""
+    """The reference's attention layer (architecture/transformer.py:107-185), same names and constructor: q/k/v/out projections (to
+    `embedding_dim // downsample_rate`), `num_heads` heads, LayerNorm(eps=1e-6), Dropout.  Inside ACMIL_MHA / MHA (8 heads, no
+    down-sampling, one query per branch) it is a parameter container whose arithmetic lives in acmil_mha_forward (csrc/mha.hip) and in
+    ACMIL_MHA._forward_train.  Stand-alone, `forward(q [1,Nq,E], k [1,N,E], v [1,N,E]) -> (out [Nq,E], attn [H,Nq,N])` runs the same
+    FOLDED form for any head count / down-sampling rate and a handful of queries: with few queries the key projection folds into the
+    query (score = k . (Wk_h^T q'_h) / sqrt(c) + const) and the value projection folds through the pooling (out = Wv_h (sum_n P v_n) + bv),
+    so the O(N) work is one [Nq H, E] x [E, N] score GEMM, a row softmax and one pooling GEMM (acmil_amd.autograd: HIP forward + backward)."""
 
     def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1, dropout: float = 0.1,
                  n_masked_patch: int = 0, mask_drop: float = 0.0):
         super().__init__()
-        if downsample_rate != 1 or num_heads != 8:
-            raise NotImplementedError("acmil_amd: MutiHeadAttention is built for 8 heads, downsample_rate 1 (transformer.py:55)")
         self.n_masked_patch, self.mask_drop = n_masked_patch, mask_drop
-        self.embedding_dim = self.internal_dim = embedding_dim
+        self.embedding_dim = embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
         self.num_heads = num_heads
-        self.q_proj = nn.Linear(embedding_dim, embedding_dim)
-        self.k_proj = nn.Linear(embedding_dim, embedding_dim)
-        self.v_proj = nn.Linear(embedding_dim, embedding_dim)
-        self.out_proj = nn.Linear(embedding_dim, embedding_dim)
+        if self.internal_dim % num_heads != 0:
+            raise AssertionError("num_heads must divide embedding_dim.")
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
         self.layer_norm = nn.LayerNorm(embedding_dim, eps=1e-6)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, q, k, v):
+        if q.dim() != 3 or q.shape[0] != 1 or k.shape[0] != 1 or v.shape[0] != 1:
+            raise RuntimeError("acmil_amd: MutiHeadAttention.forward expects q [1,Nq,E], k / v [1,N,E]")
+        if not k.is_cuda:
+            raise RuntimeError("acmil_amd: MutiHeadAttention runs on an MI355X only (no CPU fallback)")
+        H, ci, E = self.num_heads, self.internal_dim, self.embedding_dim
+        c = ci // H
+        q0, k0, v0 = q[0].float(), k[0].float().contiguous(), v[0].float().contiguous()
+        nq, n = q0.shape[0], k0.shape[0]
+        qp = F.linear(q0, self.q_proj.weight, self.q_proj.bias).view(nq, H, c)                            # q' per query and head
+        rows = torch.einsum("hce,qhc->hqe", self.k_proj.weight.view(H, c, E), qp) / math.sqrt(c)       # [H, Nq, E]
+        cst = torch.einsum("hc,qhc->hq", self.k_proj.bias.view(H, c), qp) / math.sqrt(c)
+        S = AG.matmul(rows.reshape(H * nq, E), k0, trans_b=True) + cst.reshape(H * nq, 1)               # [H Nq, N] = the returned attn
+        masked = S
+        if self.n_masked_patch > 0 and self.training:                                                   # transformer.py:162-171
+            kk = min(self.n_masked_patch, n)
+            drop = int(kk * self.mask_drop)
+            if drop > 0:
+                u = torch.rand(S.shape[0], kk, device=S.device)
+                _, midx = ops.stkim_select(S.detach().contiguous(), kk, drop, u)
+                masked = AG.mask_fill(S, midx)
+        P = AG.softmax_rows(masked.contiguous())
+        pooled = AG.matmul(P, v0).view(H, nq, E)
+        out1 = torch.einsum("hce,hqe->qhc", self.v_proj.weight.view(H, c, E), pooled) + self.v_proj.bias.view(1, H, c)
+        o = F.linear(out1.reshape(nq, ci), self.out_proj.weight, self.out_proj.bias)
+        o = self.layer_norm(self.dropout(o))
+        return o, masked.view(H, nq, n)
 
 
 class MutiHeadAttention_modify(nn.Module):
@@ -905,13 +940,27 @@ class MutiHeadAttention_modify(nn.Module):
 
     def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1, dropout: float = 0.1):
         super().__init__()
-        if downsample_rate != 1 or num_heads != 8:
-            raise NotImplementedError("acmil_amd: MutiHeadAttention_modify is built for 8 heads, downsample_rate 1")
-        self.embedding_dim = self.internal_dim = embedding_dim
+        self.embedding_dim = embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
         self.num_heads = num_heads
-        self.v_proj = nn.Linear(embedding_dim, embedding_dim)
-        self.out_proj = nn.Linear(embedding_dim, embedding_dim)
+        if self.internal_dim % num_heads != 0:
+            raise AssertionError("num_heads must divide embedding_dim.")
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
         self.layer_norm = nn.LayerNorm(embedding_dim, eps=1e-6)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, v, attn):
+        """v [1,N,E], attn [H,1,N] (already normalised: transformer.py:221-236) -> [1,E]: the value projection folded through the
+        weighted sum, as in ACMIL_MHA's bag head."""
+        if not v.is_cuda:
+            raise RuntimeError("acmil_amd: MutiHeadAttention_modify runs on an MI355X only (no CPU fallback)")
+        H, ci, E = self.num_heads, self.internal_dim, self.embedding_dim
+        c = ci // H
+        pooled = AG.matmul(attn.reshape(H, -1).float().contiguous(), v[0].float().contiguous())          # [H, E]
+        out1 = (torch.einsum("hce,he->hc", self.v_proj.weight.view(H, c, E), pooled) + self.v_proj.bias.view(H, c)).reshape(1, ci)
+        o = F.linear(out1, self.out_proj.weight, self.out_proj.bias)
+        return self.layer_norm(self.dropout(o))
 
 
 class ACMIL_MHA(nn.Module):

@@ -22,7 +22,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import make_golden as G  # noqa: E402  (stubs the absent third-party modules, imports the reference)
 from architecture.network import DimReduction  # noqa: E402
-from architecture.transformer import MHA  # noqa: E402
+from architecture.transformer import MHA, MutiHeadAttention, MutiHeadAttention_modify  # noqa: E402
 
 # tag, D_feat, D_inner, n_class, n_token, attention width, W1 row stride
 FAMILIES = [("d512_a64_k5_c2", 512, 256, 2, 5, 64, 4), ("d384_a256_k3_c7", 384, 128, 7, 3, 256, 2)]
@@ -76,6 +76,25 @@ def main():
     G.save("mha_single_n350_d384_c3", x=xM.numpy(), logits_init=logits0.numpy(), logits=logits1.detach().numpy(), label=np.array([2]),
            **{"w." + n: p.detach().numpy().copy() for n, p in mh.named_parameters()},
            **{"grad." + n: p.grad.numpy().copy() for n, p in mh.named_parameters()})
+    # the attention layers stand-alone with 4 heads and down-sampling 2 (transformer.py:107-236): eval mode, gradients of sum(out^2)
+    torch.manual_seed(0)
+    att = MutiHeadAttention(128, 4, downsample_rate=2)
+    att.eval()
+    g = torch.Generator().manual_seed(17)
+    q = (torch.randn(1, 3, 128, generator=g) * 0.7).requires_grad_(True)
+    kv = torch.randn(1, 500, 128, generator=g)
+    out, attn = att(q, kv, kv)
+    out.square().sum().backward()
+    mod = MutiHeadAttention_modify(128, 4, downsample_rate=2)
+    mod.eval()
+    pa = torch.softmax(attn.detach()[:, :1], dim=-1)                     # [H, 1, N] normalised weights, as ACMIL_MHA hands them over
+    with torch.no_grad():
+        out_m = mod(kv, pa.unsqueeze(0))
+    G.save("mha_layer_h4_ds2_n500_e128", q=q.detach().numpy(), kv=kv.numpy(), out=out.detach().numpy(), attn=attn.detach().numpy(),
+           grad_q=q.grad.numpy(), pa=pa.numpy(), out_modify=out_m.numpy(),
+           **{"w." + n: p.detach().numpy().copy() for n, p in att.named_parameters()},
+           **{"grad." + n: p.grad.numpy().copy() for n, p in att.named_parameters()},
+           **{"wm." + n: p.detach().numpy().copy() for n, p in mod.named_parameters()})
 
 
 if __name__ == "__main__":

@@ -220,3 +220,35 @@ def test_mha_module_matches_reference():
     with torch.no_grad():
         l0 = m0.cuda().eval()(x)
     assert np.abs(l0.cpu().numpy() - z["logits_init"]).max() < TOL
+
+
+def test_attention_layers_standalone_other_head_count_and_downsampling():
+    """`MutiHeadAttention(128, 4, downsample_rate=2)` and `MutiHeadAttention_modify` (transformer.py:107-236) called directly, as the
+    reference's classes allow: output, raw attention logits and every gradient of sum(out^2) against the real reference (eval mode)."""
+    from acmil_amd.architecture.transformer import MutiHeadAttention, MutiHeadAttention_modify
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "mha_layer_h4_ds2_n500_e128.npz"))
+    att = MutiHeadAttention(128, 4, downsample_rate=2)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}
+    assert set(sd) == set(att.state_dict()) and att.q_proj.weight.shape == (64, 128) and att.out_proj.weight.shape == (128, 64)
+    att.load_state_dict(sd)
+    att = att.cuda().eval()
+    q = torch.from_numpy(z["q"]).cuda().requires_grad_(True)
+    kv = torch.from_numpy(z["kv"]).cuda()
+    out, attn = att(q, kv, kv)
+    assert out.shape == (3, 128) and attn.shape == (4, 3, 500)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(attn.detach().cpu().numpy(), z["attn"], rtol=0, atol=TOL)
+    out.square().sum().backward()
+    assert np.abs(q.grad.cpu().numpy() - z["grad_q"]).max() <= 3e-3 * np.abs(z["grad_q"]).max()
+    for name, p in att.named_parameters():
+        ref = z["grad." + name]
+        scale = np.abs(ref).max()
+        if scale < 1e-7:
+            continue
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 3e-3 * scale, (name, np.abs(p.grad.cpu().numpy() - ref).max() / scale)
+    mod = MutiHeadAttention_modify(128, 4, downsample_rate=2)
+    mod.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wm.")})
+    mod = mod.cuda().eval()
+    with torch.no_grad():
+        om = mod(kv, torch.from_numpy(z["pa"]).cuda())
+    np.testing.assert_allclose(om.cpu().numpy(), z["out_modify"], rtol=0, atol=TOL)
