@@ -33,7 +33,9 @@ typedef __bf16 bt_bf16x8 __attribute__((ext_vector_type(8)));
 #define BT_ROWB (BT_GLD * 4)              // the same row in bytes; after the gate pass: [272 bf16 hi][272 bf16 lo][16 B]
 #define BT_LOFF 544                       // byte offset of the lo halves inside a row
 #define BT_KX 288                         // K of the third product as stored (row length of wT16), 272 used
+#ifndef BT_PF
 #define BT_PF 4                           // B fragments in flight: 16-wide K steps ahead
+#endif
 
 struct GbTileArgs {
     const float *h, *A, *stats, *ck, *coef, *Ww, *d_afeat, *bcat;

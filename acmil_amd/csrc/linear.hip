@@ -219,10 +219,21 @@ bool lin_qkv_norm_instat_ok(int M, int K, int n_out) {
     return !(P.nmain > 0 && lin_use64(M, K, P.nmain, P.nd));
 }
 
+// c_lo .. c_hi (round 6; in-launch statistics only): the launch forms only these output columns -- whole chunks of the launch plan
+// (lin_qkv_norm_cols_ok) -- so that TransMIL can run [q | k] first and v beside the Moore-Penrose chain that only needs q and k.
+bool lin_qkv_norm_cols_ok(int M, int K, int n_out, int c_lo, int c_hi) {
+    if (!lin_qkv_norm_instat_ok(M, K, n_out)) return false;
+    const LinPlan P = lin_plan(n_out, false);
+    const int cw = 32 * P.nd;
+    return P.nd_rem == 0 && c_lo >= 0 && c_lo < c_hi && c_hi <= n_out && c_lo % cw == 0 && c_hi % cw == 0;
+}
+
 int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
                      const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st,
-                     const float* wsum) {
+                     const float* wsum, int c_lo, int c_hi) {
     if (M <= 0 || !lin_dims_ok(n_out, K) || ldx < K || ldy < n_out || zrows < 0) return ACMIL_ERR_SHAPE;
+    const bool cols = !(c_lo == 0 && c_hi == n_out);
+    if (cols && (rowab != nullptr || !lin_qkv_norm_cols_ok(M, K, n_out, c_lo, c_hi))) return ACMIL_ERR_UNSUPPORTED;
     if (!x || (!rowab && !wsum) || !packed || !bias || !y || !workspace) return ACMIL_ERR_NULL;
     const bool instat = rowab == nullptr;
     if (instat && (!lin_qkv_norm_instat_ok(M, K, n_out) || ((size_t)wsum & 15) != 0)) return ACMIL_ERR_UNSUPPORTED;
@@ -237,6 +248,13 @@ int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* r
     const LinPlan P = lin_plan(n_out, lin_wide8());
     int rc = ACMIL_OK;
     if (instat) {
+        if (cols) {
+            const int cw = 32 * P.nd;
+            a.packed = (const char*)packed + (size_t)(c_lo / cw) * (K / 16) * 2 * P.nd * GA_FRAG_ROW; a.nchunks = (c_hi - c_lo) / cw; a.col0 = c_lo;
+            a.bias = bias + c_lo; a.wsum = wsum + c_lo; a.tile_counter = ctr + 8; a.done = ctr + 4;
+            if (c_lo >= lm_cols) { a.lm_part = nullptr; a.lm_cols = 0; }
+            return P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 7>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 7>(a, st);
+        }
         if (P.nmain > 0) {
             a.packed = (const char*)packed; a.nchunks = P.nmain; a.col0 = 0; a.tile_counter = ctr + 8; a.done = ctr + 4;
             rc = P.nd == 6 ? lin_launch<6, ACMIL_DTYPE_F32, 7>(a, st) : lin_launch<8, ACMIL_DTYPE_F32, 7>(a, st);

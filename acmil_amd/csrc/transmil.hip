@@ -822,7 +822,8 @@ int lin_pack_multi(const float* const* W, const int* ldw, const int* n_out, cons
 bool lin_qkv_norm_instat_ok(int M, int K, int n_out);
 int lin_qkv_norm_run(const float* x, int M, int K, long long ldx, const float* rowab, int zrows, const void* packed, int n_out,
                      const float* bias, float* y, long long ldy, float* lm_part, int lm_l, int lm_cols, void* workspace, hipStream_t st,
-                     const float* wsum = nullptr);
+                     const float* wsum, int c_lo, int c_hi);
+bool lin_qkv_norm_cols_ok(int M, int K, int n_out, int c_lo, int c_hi);
 
 // y = act(x W^T + b) + beta y for the nn.Linear layers (fc1 / to_qkv / to_out, transMIL.py:51,63, nystrom_attention.py:80,139).
 // Split-f16: the packed-weight kernel (linear.hip; fragment stream packed here, per call -- the library keeps no state: one small
@@ -868,6 +869,13 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     const float scale = 1.0f / sqrtf((float)d);
     const long long mm = (long long)m * m, md = (long long)m * d;
 
+    // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
+    // chain below stays as the path for other widths and as the A/B reference (ACMIL_TM_UNFUSED=1)
+    static const bool force_unfused = ACMIL_AB_ENV("ACMIL_TM_UNFUSED") != nullptr;
+    const bool fused = tm_attn_fused_supported(Di) && !force_unfused;
+    static const bool pinv_knobs = ACMIL_AB_ENV("ACMIL_TM_PINV_FUSED") != nullptr || ACMIL_AB_ENV("ACMIL_TM_PINV_CHAIN") != nullptr;
+    const bool can_fork = fused && d % 4 == 0 && d <= 128 && m <= 512 && tm_pinv_tiles_supported(m) && !pinv_knobs;
+    bool forked = false, early = false;      // early (round 6): the side stream was forked after [q | k], see below
     bool instat = false;
     if (wbeta) {
         // LayerNorm folded into to_qkv (round 4): row statistics -> the projection normalises its B operand in registers (gamma is in
@@ -881,12 +889,35 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
             TM_CHECK_LAUNCH();
         }
         const bool lm = g.l >= 32;
+        // round 6: to_qkv as TWO launches, [q | k] then v.  The landmarks, sim2 and the Moore-Penrose chain (a third of a layer's
+        // critical path, ~25 latency-bound launches that fill a few CUs) need q and k only: they start on the side stream as soon as the
+        // first launch retires and run beside the v projection -- a launch that keeps the whole chip busy by itself and does not mind
+        // the company -- instead of beside the attn3 leg, which then has the chip to itself for most of its time (two workgroups per
+        // CU: 150 us instead of 190).  Price: x is read twice by to_qkv.  ACMIL_TM_QKV_SPLIT=0: one launch (A/B).
+        static const bool split_off = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_QKV_SPLIT"); return !(e && e[0] == '1'); }();
+        const bool split = instat && lm && can_fork && side && !split_off && lin_qkv_norm_cols_ok(npad, Di, 3 * Di, 0, 2 * Di) &&
+                           lin_qkv_norm_cols_ok(npad, Di, 3 * Di, 2 * Di, 3 * Di);
+        if (split) {
+            int rq = lin_qkv_norm_run(X, npad, Di, Di, nullptr, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, LMP, g.l, 2 * Di, ws + W.LINWS, st, wsum, 0, 2 * Di);
+            if (rq != ACMIL_OK) return rq;
+            forked = tm_fork(side, st);
+            const hipStream_t sl = forked ? side->s : st;
+            hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, sl, LMP, g.l, m, Di, QL, KL, scal);
+            TM_CHECK_LAUNCH();
+            // (the fork event is free again: the side stream's wait on it is enqueued and refers to the record above; recorded anew on
+            // the SIDE stream it now says "q_l and k_l are there", which the attn3 leg on the main stream waits for)
+            if (forked && hipEventRecord(side->fork, side->s) != hipSuccess) { (void)tm_join(side, st); return ACMIL_ERR_LAUNCH; }
+            early = forked;
+            rq = lin_qkv_norm_run(X, npad, Di, Di, nullptr, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, nullptr, g.l, 2 * Di, ws + W.LINWS, st, wsum, 2 * Di, 3 * Di);
+            if (rq != ACMIL_OK) { if (forked) (void)tm_join(side, st); return rq; }
+        } else {
         const int rq = lin_qkv_norm_run(X, npad, Di, Di, instat ? nullptr : AB, g.pad, pk_qkv, 3 * Di, wbeta, QKV, 3 * Di, lm ? LMP : nullptr, g.l, 2 * Di,
-                                        ws + W.LINWS, st, instat ? wsum : nullptr);
+                                        ws + W.LINWS, st, instat ? wsum : nullptr, 0, 3 * Di);
         if (rq != ACMIL_OK) return rq;
         if (lm) {
             hipLaunchKernelGGL(tm_landmark_reduce_kernel, dim3(m, (2 * Di + 255) / 256), dim3(256), 0, st, LMP, g.l, m, Di, QL, KL, instat ? scal : nullptr);
             TM_CHECK_LAUNCH();
+        }
         }
     } else {
     hipLaunchKernelGGL(tm_layernorm_kernel, dim3((npad + 3) / 4), dim3(256), 0, st, X, LN, g.n, Di, p.norm_w, p.norm_b, g.pad);
@@ -900,10 +931,6 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         hipLaunchKernelGGL(tm_landmark_kernel, dim3(m, 2), dim3(threads), (size_t)phases * Di * sizeof(float), st, QKV, g.l, m, Di, phases, QL, KL, (wbeta && !instat) ? nullptr : scal);
     }
     TM_CHECK_LAUNCH();
-    // fused = the two long attention legs run as flash-style kernels (no [H, npad, m] matrices in HBM); the GEMM + softmax
-    // chain below stays as the path for other widths and as the A/B reference (ACMIL_TM_UNFUSED=1)
-    static const bool force_unfused = ACMIL_AB_ENV("ACMIL_TM_UNFUSED") != nullptr;
-    const bool fused = tm_attn_fused_supported(Di) && !force_unfused;
     int rc = ACMIL_OK;
     if (!fused) {
     // sim1 = scale q k_l^T  [H, npad, m] ; softmax over m
@@ -913,9 +940,9 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     // sim2 = scale q_l k_l^T [H, m, m] ; softmax ; Moore-Penrose iteration -- on the side stream beside the attn3 leg where both
     // run on their own kernels and scratch (the generic-GEMM paths share the split-K workspace: serial)
     const hipStream_t st_main = st;
-    static const bool pinv_knobs = ACMIL_AB_ENV("ACMIL_TM_PINV_FUSED") != nullptr || ACMIL_AB_ENV("ACMIL_TM_PINV_CHAIN") != nullptr;
-    const bool forked = fused && d % 4 == 0 && d <= 128 && m <= 512 && tm_pinv_tiles_supported(m) && !pinv_knobs && tm_fork(side, st);
-    static const bool side_swap = ACMIL_AB_ENV("ACMIL_TM_SIDE_SWAP") != nullptr;        // A/B knob: the attn3 leg on the side stream instead
+    if (!early) forked = can_fork && tm_fork(side, st);
+    static const bool side_swap_knob = ACMIL_AB_ENV("ACMIL_TM_SIDE_SWAP") != nullptr;   // A/B knob: the attn3 leg on the side stream instead
+    const bool side_swap = side_swap_knob && !early;
     const hipStream_t st_chain = (forked && !side_swap) ? side->s : st_main, st_leg = (forked && side_swap) ? side->s : st_main;
     st = st_chain;
     if (d % 4 == 0 && d <= 128 && m <= 512) {
@@ -946,7 +973,9 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     bool pinv_fused = tm_pinv_fused_supported(m) && pinv_one;
     if (!pinv_fused && !pinv_chain && tm_pinv_tiles_supported(m)) {
         // default: one wave per 16 x 16 output tile, whole K in registers, exact fp32 MFMA (transmil_pinv.hip): 24 + 1 launches of ~3 us
-        rc = tm_pinv_tiles(S2, Z, (float*)(ws + W.ZT), (float*)(ws + W.ZB), (float*)(ws + W.ZTB), XZ, T1, T2, scal, m, 6, &zc, st,
+        // ACMIL_TM_ABL (A/B build, timing only, WRONG results): bit 0 no attn3 leg, bit 1 no Moore-Penrose products, bit 2 no attn1 leg
+        static const int abl = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_ABL"); return e ? atoi(e) : 0; }();
+        if (!(abl & 2)) rc = tm_pinv_tiles(S2, Z, (float*)(ws + W.ZT), (float*)(ws + W.ZB), (float*)(ws + W.ZTB), XZ, T1, T2, scal, m, 6, &zc, st,
                            (float*)(ws + W.LY), (float*)(ws + W.WY));
         if (rc != ACMIL_OK) return rc;
         pinv_fused = true;       // (skips the generic chain below)
@@ -969,7 +998,12 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
     st = st_main;
     if (fused) {
         // AV = softmax_n(scale q_l k^T) v  [H, m, d]   (chunk partials in their own workspace region)
-        rc = tm_attn3_fused(QKV, QL, AV, (float*)(ws + W.PART), npad, Di, scale, st_leg, forked);
+        // early fork: q_l comes from the side stream's landmark launch; most of the chain is over when v is there, the leg runs in
+        // the form it has alone on the chip (ACMIL_TM_ATTN3_SHARED=1: the one-workgroup-per-CU form of the late fork, A/B)
+        static const bool early_shared = ACMIL_AB_ENV("ACMIL_TM_ATTN3_SHARED") != nullptr;
+        if (early && hipStreamWaitEvent(st_leg, side->fork, 0) != hipSuccess) { (void)tm_join(side, st); return ACMIL_ERR_LAUNCH; }
+        static const int abl3 = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_ABL"); return e ? atoi(e) : 0; }();
+        if (!(abl3 & 1)) rc = tm_attn3_fused(QKV, QL, AV, (float*)(ws + W.PART), npad, Di, scale, st_leg, forked && (!early || early_shared));
         if (forked) { const int rj = tm_join(side, st); if (rc == ACMIL_OK) rc = rj; }       // (joined even after a failed launch)
         if (rc != ACMIL_OK) return rc;
     } else {
@@ -988,7 +1022,9 @@ static int tm_layer(const TmGeom& g, const TmWs& W, char* ws, float* X, const Tm
         TM_GEMM(0, 0, m, d, m, 1.0f, zc, m, mm, AV, ACMIL_DTYPE_F32, d, md, 0.0f, W2, d, md, nullptr, 0, nullptr, H, gws, st);
     }
     int conv_done = 0;
-    if (fused) { rc = tm_attn1_fused(QKV, KL, W2, OUT, npad, Di, scale, st, p.res_w, &conv_done); if (rc != ACMIL_OK) return rc; }
+    static const int abl1 = [] { const char* e = ACMIL_AB_ENV("ACMIL_TM_ABL"); return e ? atoi(e) : 0; }();
+    if (fused && (abl1 & 4)) conv_done = 1;
+    else if (fused) { rc = tm_attn1_fused(QKV, KL, W2, OUT, npad, Di, scale, st, p.res_w, &conv_done); if (rc != ACMIL_OK) return rc; }
     else TM_GEMM(0, 0, npad, d, m, 1.0f, S1, m, (long long)npad * m, W2, ACMIL_DTYPE_F32, d, md, 0.0f, OUT, Di, d, nullptr, 0, nullptr, H, gws, st);
     // + depth-wise residual conv of v along the sequence (a pass of its own only where the attention leg did not add it)
     if (!conv_done) {
