@@ -25,6 +25,11 @@
 // no longer takes issue slots from a running MFMA chain (attn1 leg 157 -> 149 us; 2 measured the same as 1)
 #ifndef TMA_PRIO
 #define TMA_PRIO 1
+// timing-only ablations of tm_attn1x_kernel (tools/build_file_variant.sh; WRONG results; 0 in every product build): 1 no exp / max / sum,
+// 2 no GEMM-S MFMAs, 4 no GEMM-PV MFMAs, 8 no convolution (loads + MFMAs), 16 no OUT stores
+#ifndef TMA1_ABL
+#define TMA1_ABL 0
+#endif
 #endif
 #ifndef TMA_PRIO3
 #define TMA_PRIO3 0
@@ -392,7 +397,11 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
                 constexpr int dummy = 0; (void)dummy;
                 const int offb = (32 * t * LD + 16 * st) * 2;
                 const tma_h8 ah = *(const tma_h8*)(klh_b + offb), al = *(const tma_h8*)(kll_b + offb);
+#if TMA1_ABL & 2
+                acc[t][st] += (float)ah[0] + (float)al[1] + (float)qh[st][0] + (float)ql[st][1];
+#else
                 TMA_MFMA3(acc[t], ah, al, qh[st], ql[st]);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -403,6 +412,9 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
 #if TMA_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+#if TMA1_ABL & 1
+        float sum = 1.0f;
+#else
         float m2 = -INFINITY;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float p = __expf(acc[t][r] - m2); acc[t][r] = p; sum += p; }
         sum += tma_xor32(sum);
+#endif
 
         f32x16 o[ET];
 #pragma unroll
@@ -455,11 +468,15 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
                 for (int et = 0; et < ET; ++et) {
                     const int offb = (t * 2 * EP * 16 + (e2 * EP + 32 * et) * 16) * 2;
                     const tma_h8 wh = *(const tma_h8*)(w2h_b + offb), wl = *(const tma_h8*)(w2l_b + offb);
+#if TMA1_ABL & 4
+                    o[et][(2 * t + e2) & 15] += (float)wh[0] + (float)wl[1] + (float)ph[0] + (float)pl[1];
+#else
                     TMA_MFMA3(o[et], wh, wl, ph, pl);
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (convw) {
+            if (convw && !(TMA1_ABL & 8)) {
                 if (t == (MT >= 4 ? MT - 3 : 0)) { load_v(0); load_v(1); __builtin_amdgcn_sched_barrier(0); }
                 if (t == MT - 1) { load_v(2); load_v(3); __builtin_amdgcn_sched_barrier(0); }
             }
@@ -469,7 +486,7 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
         for (int et = 0; et < ET; ++et)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[et][r] *= inv;
-        if (convw) {
+        if (convw && !(TMA1_ABL & 8)) {
 #pragma unroll
             for (int kp = 0; kp < 4; ++kp) {
                 const tma_h8 bh = Tch[kp * 64 + lane], bl = Tcl[kp * 64 + lane];
@@ -490,7 +507,11 @@ __global__ __launch_bounds__(512) void tm_attn1x_kernel(const float* __restrict_
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int e = 32 * et + 8 * gq + 4 * hi;
+#if TMA1_ABL & 16
+                asm volatile("" :: "v"(o[et][4 * gq]), "v"(o[et][4 * gq + 1]), "v"(o[et][4 * gq + 2]), "v"(o[et][4 * gq + 3]), "v"(op));
+#else
                 if (e < D) *(f32x4*)(op + e) = f32x4{o[et][4 * gq], o[et][4 * gq + 1], o[et][4 * gq + 2], o[et][4 * gq + 3]};
+#endif
             }
     }
 }
