@@ -41,6 +41,8 @@ SIGNATURES = {
     "acmil_ga_rescore_fp32_cond": (_i, [_vp, _i, _i, _vp, _vp] + [_i] * 6 + [_vp] * 6),
     "acmil_ga_forward_guarded_wide": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "acmil_ga_pool": (_i, [_vp, _vp, _i, _vp] + [_i] * 6 + [_vp, _i] + [_vp] * 4 + [_i, _vp, _vp]),
+    "acmil_ga_pool_group_workspace_bytes": (_sz, [_i] * 4),
+    "acmil_ga_pool_group": (_i, [_vp, _vp, _i, _i, C.POINTER(_i), _vp] + [_i] * 6 + [_vp] * 4 + [_i, _vp, _vp]),
     "acmil_stkim_workspace_bytes": (_sz, [_i] * 3),
     "acmil_stkim_select": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "acmil_stkim_select_rng": (_i, [_vp, _i, _i, _i, _i, _vp, C.c_ulonglong, C.c_ulonglong, _vp, _vp, _vp, _vp]),

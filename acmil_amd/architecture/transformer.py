@@ -831,6 +831,60 @@ class ACMIL_GA(_GatedBase):
         triples = [(out["sub_preds"][i], out["slide_pred"][i].unsqueeze(0), out["A_out"][i].unsqueeze(0)) for i in range(len(bags))]
         return (triples, status) if defer_guard else triples
 
+    def _is_composed_groupable(self, prec: str) -> bool:
+        """The composed families (D_inner = 768, n_token > 5; attention width 128) in split-f16 arithmetic: their three kernels take the
+        rows of several bags at once (forward_group)."""
+        return (prec == "f16x3" and not self._generic() and not self._is_fused() and not self._is_wide_fused()
+                and self.dimreduction.fc1.weight.shape[0] % 16 == 0 and self.attention.attention_V[0].weight.shape[0] == 128)
+
+    def forward_group(self, x, rows, defer_guard: bool = False):
+        """Eval forward of G <= 16 bags whose rows lie BACK TO BACK in x [sum N_b, D_feat] (staging.staged_train_groups delivers a group
+        that way: no device-side concatenation) -- the batched eval of the COMPOSED families (GigaPath 1536 -> 768, n_token > 5), whose
+        kernels are per patch: ONE projection launch and ONE gated-score launch over all rows (a single 50 000-patch slide fills the
+        256 persistent workgroups of the projection for 2.3 rounds of (tile, chunk) units: three rounds' time; a group has no such
+        tail), then per-bag pooling tiles and merge + heads for all bags (acmil_ga_pool_group).  Per bag the same mathematics and
+        kernels as `model(x)` (transformer.py:305-330); returns the per-slide triples of forward_batch.  Not in the reference (B = 1).
+        Range guard: ONE status word per group (the projection's); defer_guard=True returns (triples, RangeTicket) as forward_batch
+        does, otherwise a flagged group is repeated bag by bag in fp32 here.  Other families: the bags go through forward_batch."""
+        rows = [int(r) for r in rows]
+        xb = x[0] if x.dim() == 3 else x
+        if not xb.is_contiguous():
+            xb = xb.contiguous()
+        if xb.shape[0] != sum(rows) or not rows:
+            raise RuntimeError("acmil_amd: forward_group takes x [sum rows, D_feat]")
+        offs = [0]
+        for r in rows:
+            offs.append(offs[-1] + r)
+        views = [xb[offs[i]:offs[i + 1]] for i in range(len(rows))]
+        if not self._is_composed_groupable(self.precision) or xb.stride(0) * xb.element_size() % 16 != 0:
+            return self.forward_batch(views, defer_guard=defer_guard)
+        triples, status = [], None
+        for g0 in range(0, len(rows), ops.MAX_GROUP):
+            g1 = min(len(rows), g0 + ops.MAX_GROUP)
+            t, st = self._forward_group_composed(xb[offs[g0]:offs[g1]], rows[g0:g1])
+            triples += t
+            if st is not None and self.range_guard:
+                if defer_guard and g1 == len(rows) and g0 == 0:
+                    status = RangeTicket(st)
+                elif self._out_of_range(st):
+                    triples[g0:g1] = self.forward_batch(views[g0:g1], precision="fp32")
+        return (triples, status) if defer_guard else triples
+
+    def _forward_group_composed(self, xb, rows):
+        packed, dims = self._packed()
+        base = self._raw_params()[0]
+        h, status = ops.linear_f16x3(xb, self._packed_w1(), base[0].shape[0], relu=True, want_status=True)
+        pvu, bvu = self._packed_gate()
+        A = ops.gated_scores_packed(h, pvu, bvu, base[5], base[6])
+        out = ops.ga_pool_group(h, A, rows, packed, dims, "f16x3")
+        offs = [0]
+        for r in rows:
+            offs.append(offs[-1] + r)
+        slide = out.get("slide_pred")
+        triples = [(out["sub_preds"][i], slide[i].unsqueeze(0) if slide is not None else None, A[:, offs[i]:offs[i + 1]].unsqueeze(0))
+                   for i in range(len(rows))]
+        return triples, status
+
     def forward_feature(self, x, use_attention_mask=False, uniforms: Optional[torch.Tensor] = None):
         """x [1,N,D_feat] -> bag_feat [1,Di]  (transformer.py:332-352)."""
         xb = self._bag(x)

@@ -229,9 +229,9 @@ extern "C" size_t acmil_ga_workspace_bytes(int N, int D, int Di, int K, int C, i
 
 // merge + heads shared by the fused forward (batched) and the masked pooling pass.
 // part: partials of all bags back to back; tile_start[b]: first tile of bag b; afeat scratch lives after the partials.
-static int ga_finish_batch(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L,
-                           float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
-                           float* af_scratch, hipStream_t st) {
+int ga_finish_batch(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L,
+                    float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                    float* af_scratch, hipStream_t st) {
     const int K = L.K, Di = L.Di;
     GaBatchTiles bt;
     for (int b = 0; b <= GA_MAX_BATCH; ++b) bt.start[b] = b <= nbags ? tile_start[b] : tile_start[nbags];

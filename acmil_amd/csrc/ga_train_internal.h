@@ -44,6 +44,12 @@ __device__ __forceinline__ GaSegTile ga_seg_find(const GaSeg& s, int tile) {
     return r;
 }
 
+// ga_forward.hip: merge + heads for nbags <= GA_MAX_BATCH bags whose partials lie back to back (tile_start[b]: first tile of bag b,
+// nbags + 1 entries); outputs [bag][...]; af_scratch: nbags * K * Di floats, used when afeat is null
+int ga_finish_batch(const float* part, const int* tile_start, int nbags, const void* packed, const GaLayout& L,
+                    float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                    float* af_scratch, hipStream_t st);
+
 // ga_train.hip
 // uniforms == null: the kernel draws them itself, Philox4x32-10 keyed on (rng_seed, rng_offset, branch, column)
 // seg (or null = one bag of N rows): a group of bags -- scores / A_mask are [K][ldA] with bag b in columns row0[b].., uniforms

@@ -113,6 +113,9 @@ static int lin_launch(const LinArgs& a, hipStream_t st) {
 template <int ND, int XDT, int FX = 0>
 static int lin_launch64(const LinArgs& a, hipStream_t st) {
     using G = Lin64Geom<ND, XDT>;
+    // the kernel addresses x rows by 32-bit byte offsets from the matrix base (lin_use64 keeps M <= 65 536; a forced A/B run on a
+    // 16 x 50 000-row group of 1536-wide fp32 rows read wrong rows beyond 4 GiB): refuse instead
+    if ((unsigned long long)a.M * (unsigned long long)a.ldx * (XDT == ACMIL_DTYPE_F32 ? 4 : 2) > 0xffffffffull) return ACMIL_ERR_UNSUPPORTED;
     static int slots_of[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return ACMIL_ERR_LAUNCH;

@@ -17,6 +17,7 @@ from . import _lib
 _DT = {torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
 GA_DA = 128
 MAX_BATCH = 64       # ACMIL_MAX_BATCH: bags per acmil_ga_forward_batch / _guarded launch
+MAX_GROUP = 16       # GA_SEG_MAX: bags of one row-concatenated group (acmil_ga_train_step_group, acmil_ga_pool_group)
 
 
 def _stream() -> int:
@@ -365,6 +366,33 @@ def ga_pool(h: torch.Tensor, A: torch.Tensor, packed: torch.Tensor, dims: GaDims
     return out
 
 
+def ga_pool_group(h: torch.Tensor, A: torch.Tensor, rows: Sequence[int], packed: torch.Tensor, dims: GaDims, mode,
+                  want_afeat: bool = False, want_bag_feat: bool = False):
+    """acmil_ga_pool_group: unmasked softmax / weighted sum / heads per bag for up to 16 bags whose rows lie back to back in
+    h [sum rows, Di] and A [K, sum rows] (A is not modified).  Outputs carry a leading bag axis."""
+    lib = _lib.load()
+    mode = mode_id(mode)
+    _need_cuda(h, A)
+    rows = [int(r) for r in rows]
+    B, N, dev = len(rows), h.shape[0], h.device
+    if B < 1 or B > MAX_GROUP or sum(rows) != N or A.shape != (dims.K, N) or not h.is_contiguous() or not A.is_contiguous():
+        raise RuntimeError("acmil_amd.ga_pool_group: 1..%d bags, h [sum rows, Di] and A [K, sum rows] contiguous" % MAX_GROUP)
+    f32 = dict(dtype=torch.float32, device=dev)
+    sub = torch.empty(B, dims.K, dims.C, **f32)
+    slide = torch.empty(B, dims.C, **f32) if dims.has_bag_head else None
+    af = torch.empty(B, dims.K, dims.Di, **f32) if want_afeat else None
+    bf = torch.empty(B, dims.Di, **f32) if want_bag_feat else None
+    ws = _ws_bytes(lib.acmil_ga_pool_group_workspace_bytes(N, B, dims.Di, dims.K), dev)
+    rc = lib.acmil_ga_pool_group(h.data_ptr(), A.data_ptr(), N, B, (ctypes.c_int * B)(*rows), packed.data_ptr(), *dims.args(), mode,
+                                 sub.data_ptr(), _ptr(slide), _ptr(af), _ptr(bf), int(dims.has_bag_head), ws.data_ptr(), _stream())
+    _lib.check(rc, "acmil_ga_pool_group")
+    out = {"sub_preds": sub, "A_out": A}
+    for k, v in (("slide_pred", slide), ("afeat", af), ("bag_feat", bf)):
+        if v is not None:
+            out[k] = v
+    return out
+
+
 def gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, alpha: float = 1.0,
          bias: Optional[torch.Tensor] = None, act: int = 0, out: Optional[torch.Tensor] = None, beta: float = 0.0,
          aux: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
@@ -519,7 +547,6 @@ def ga_train_step(x: torch.Tensor, packed: torch.Tensor, dims: GaDims, mode, par
             "topk_idx": topk if k_top > 0 else None, "masked_idx": midx if m_mask > 0 else None, "range_status": _range_status(ws)}
 
 
-MAX_GROUP = 16      # GA_SEG_MAX: bags per acmil_ga_train_step_group call
 
 
 def ga_train_step_group(x: torch.Tensor, rows: Sequence[int], packed: torch.Tensor, dims: GaDims, mode, params: Sequence[torch.Tensor],

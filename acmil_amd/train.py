@@ -426,11 +426,16 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
     order = epoch_order(len(data), 0, 0, False, rank, world, drop_last=False)
     probs, labels, losses, divs = [], [], [], []
     label_dev = torch.arange(conf.n_class, device=device)
-    if batched and device.type == "cuda" and hasattr(model, "forward_batch") and (
-            getattr(model, "_is_fused", lambda: False)() or getattr(model, "_is_wide_fused", lambda: False)()):
-        # GA at the fused widths: up to EVAL_BATCH = 64 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times), and
-        # the split-f16 range word of a batch is looked at only after the NEXT batch has been enqueued, so the GPU never idles
-        # on the check; a flagged batch (never seen on real features) is re-read and repeated in fp32 arithmetic.
+    on_gpu = batched and device.type == "cuda" and hasattr(model, "forward_batch")
+    fused_batch = on_gpu and (getattr(model, "_is_fused", lambda: False)() or getattr(model, "_is_wide_fused", lambda: False)())
+    composed_group = on_gpu and not fused_batch and getattr(model, "_is_composed_groupable", lambda p: False)(getattr(model, "precision", ""))
+    if fused_batch or composed_group:
+        # GA at the fused widths: up to EVAL_BATCH = 64 staged bags share ONE fused launch (acmil_ga_forward_batch -- the launch bench.py times).
+        # GA at the composed widths (GigaPath 1536 -> 768, n_token > 5): groups of <= 16 slides are staged with their rows back to back
+        # (staged_train_groups: H2D straight into one ring slot) and go through ONE projection launch, ONE gated-score launch and a
+        # per-bag pooling pass (ACMIL_GA.forward_group).  Either way the split-f16 range word of a batch is looked at only after the
+        # NEXT batch has been enqueued, so the GPU never idles on the check; a flagged batch (never seen on real features) is re-read
+        # and repeated in fp32 arithmetic.
         n_total = len(order)
         probs, labels, losses, divs = [None] * n_total, [None] * n_total, [None] * n_total, [None] * n_total
         pos = {idx: j for j, idx in enumerate(order)}
@@ -453,14 +458,23 @@ def evaluate(model, data, device, conf, header: str = "Val", rank: int = 0, worl
             for (i, lab), triple in zip(members, model.forward_batch(xs, precision="fp32")):
                 record(i, lab, triple)
 
+        def batches():      # (members [(index, label)], triples, status) per launch group
+            if fused_batch:
+                for group in staged_groups(data, order, device, group=EVAL_BATCH):
+                    triples, status = model.forward_batch([it["input"] for it in group], defer_guard=True)
+                    yield [(it["index"], it["label"]) for it in group], triples, status
+            else:
+                for g in staged_train_groups(data, order, device, group=ops.MAX_GROUP):
+                    triples, status = model.forward_group(g["input"], g["rows"], defer_guard=True)
+                    yield list(zip(g["indices"], g["labels"])), triples, status
+
         pending = None
-        for group in staged_groups(data, order, device, group=EVAL_BATCH):
-            triples, status = model.forward_batch([it["input"] for it in group], defer_guard=True)
-            for it, triple in zip(group, triples):
-                record(it["index"], it["label"], triple)
+        for members, triples, status in batches():
+            for (i, lab), triple in zip(members, triples):
+                record(i, lab, triple)
             if pending is not None:
                 settle(pending)
-            pending = (status, [(it["index"], it["label"]) for it in group])
+            pending = (status, members)
         if pending is not None:
             settle(pending)
     else:

@@ -390,7 +390,10 @@ def other_workloads(args, ctx):
     # (own rendezvous port): the path has never crossed a real xGMI link, and a fault in a kernel that reads a wrongly mapped peer
     # buffer must cost this field, not the whole line.  Never fatal, bounded in time.
     direct = None
-    if world > 1:
+    if world > 1 and not getattr(args, "direct_reduce", False):
+        direct = {"skipped": "opt-in leg: `bench.py --workload train --gpus N --direct-reduce`", "ms_per_step": None, "value": None,
+                  "first_step_check": "not run", "slot_memory": None}
+    elif world > 1:
         import subprocess
         env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}      # (no agent store: the child ranks make their own)
         port = int(os.environ.get("MASTER_PORT", "29500"))
@@ -506,24 +509,43 @@ def wide_workload(args, ctx):
             e1.record()
             torch.cuda.synchronize()
             t_lin = e0.elapsed_time(e1) * 1e-3 / n_k
-        dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
-    t_slide = dt / args.steps
+        # --batch G > 1 (default: groups of 16): a step is ONE group of G slides whose rows lie back to back, as staging.staged_train_groups
+        # delivers them to train.evaluate (ACMIL_GA.forward_group: one projection launch + one gated-score launch over all rows, pooling
+        # tiles per bag, merge + heads of all bags); --batch 1: the reference's `model(x)` per slide.  3 rotating groups of 16 x 307 MB.
+        G = max(1, min(ops.MAX_GROUP, int(args.batch)))
+        per_slide = None
+        if G > 1:
+            groups = [(torch.cat([bags[(gi * 3 + j) % nb] for j in range(G)], 0), [N] * G) for gi in range(3)]
+            torch.cuda.synchronize()
+            dt = _timed(lambda i: model.forward_group(*groups[i % 3]), args, world, dev)
+            a1 = argparse.Namespace(**vars(args)); a1.steps, a1.warmup = 50, 5
+            per_slide = round(world * a1.steps / _timed(lambda i: model(bags[i % nb].unsqueeze(0)), a1, world, dev), 1)
+        else:
+            dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
+    t_slide = dt / args.steps / G
     nbytes, flops = algorithmic_work(N, D, Di, K, C)
     g1 = 2.0 * N * D * Di
     executed = 3.0 * flops if args.precision == "f16x3" else flops
     peak = 2500.0 if args.precision == "f16x3" else 157.3
     result = {
         "metric": "slides/sec (ACMIL-ga eval forward, N=%d D=%d D_inner=%d: %s)" % (N, D, Di, sh["name"]),
-        "value": round(world * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(t_slide * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": round(world * G * args.steps / dt, 1), "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_slide * G * 1e3, 4), "ms_per_slide": round(t_slide * 1e3, 4), "slides_per_step": G,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (projections as split-f16 x3 MFMA products, fp32 accumulate)" if args.precision == "f16x3" else "f32", "data": "synthetic",
-        "config": {"workload": "ACMIL-ga eval forward, one slide per step through the module: N=%d patches, D=%d, D_inner=%d, n_token=%d, "
-                               "n_class=%d, fp32 bags resident in HBM, %d bags rotated; composed kernels (projection -> gated scores -> pooling)"
-                               % (N, D, Di, K, C, nb), "precision": args.precision, "sharding": "independent slides per GPU, no collective"},
+        "config": {"workload": ("ACMIL-ga eval forward, one slide per step through the module" if G == 1 else
+                                "ACMIL-ga eval forward, %d slides per step in grouped launches (rows of a group resident back to back, as "
+                                "train.evaluate stages them; ACMIL_GA.forward_group)" % G) +
+                               ": N=%d patches, D=%d, D_inner=%d, n_token=%d, n_class=%d, fp32 bags resident in HBM, %s; composed kernels "
+                               "(projection -> gated scores -> pooling)" % (N, D, Di, K, C, "%d bags rotated" % nb if G == 1 else "3 groups rotated"),
+                   "precision": args.precision, "slides_per_step": G, "sharding": "independent slides per GPU, no collective"},
+        "module_slides_per_s": None if per_slide is None else {"model(x) per slide": per_slide},
         "roofline": {"kernel": "whole composed forward (lin_kernel projection + gated scores + pooling + merge + heads)", "bound": "mfma",
                      "achieved": round(flops / t_slide / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / t_slide / 1e12 / peak, 4),
                      # PMC summary of the whole composed forward: tools/pmc_ga.py --workload <name> --whole-step --batch 1
-                     "traffic": pmc_traffic(args.workload, args.precision, 1)[0], "traffic_source": pmc_traffic(args.workload, args.precision, 1)[1],
+                     # (per STEP: G slides; tools/pmc_ga.py --workload <name> --whole-step --batch G)
+                     "traffic": pmc_traffic(args.workload, args.precision, G)[0], "traffic_source": pmc_traffic(args.workload, args.precision, G)[1],
+                     "algorithmic_bytes": int(G * nbytes),
                      "executed_tflops": round(executed / t_slide / 1e12, 1), "executed_frac": round(executed / t_slide / 1e12 / peak, 4),
                      "projection_kernel": None if t_lin is None else {
                          "us_per_launch": round(t_lin * 1e6, 1), "achieved_tflops": round(g1 / t_lin / 1e12, 1),
@@ -594,6 +616,10 @@ def main(argv=None):
     ap.add_argument("--train-separate-opt", action="store_true",
                     help="train workload on one GPU: keep the optimizer as its own launch (the data-parallel launch sequence) -- A/B of the in-step optimizer")
     ap.add_argument("--direct-leg", action="store_true", help=argparse.SUPPRESS)      # child mode of the train workload (direct gradient reduction)
+    ap.add_argument("--direct-reduce", action="store_true",
+                    help="train workload at --gpus N > 1: ALSO time the steps with the direct (IPC-mapped peer bucket) gradient reduction, in a "
+                         "child process per rank.  Opt-in: the path has never crossed a real xGMI link, and the driver's scaling run of the "
+                         "default line must not depend on it (`direct_reduce` is then {\"skipped\": ...})")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check on CPU with gloo: no GPU, no compute, no metric value")
     args = ap.parse_args(argv)
@@ -639,6 +665,7 @@ def secondary_lines(args, ctx):
         a = copy.copy(args)
         a.no_cpu_baseline = True
         a.no_b1 = True
+        a.direct_reduce = False       # never on the driver's default line (see --direct-reduce)
         a.batch = 64
         a.precision = "f16x3"
         for k, v in over.items():

@@ -175,6 +175,18 @@ int acmil_ga_pool(const float* h, float* A, int N, const void* packed, int D, in
                   const int64_t* masked_idx, int n_masked, float* sub_preds, float* slide_pred, float* afeat,
                   float* bag_feat, int has_bag_head, void* workspace, void* stream);
 
+/* The unmasked pooling pass + heads for a GROUP of nbags <= 16 bags whose rows lie back to back (h [N, Di] and the raw scores
+ * A [K, N] cover all bags, N = sum rows[b]; rows: HOST array).  Per bag exactly acmil_ga_pool with n_masked = 0 (transformer.py:322-330;
+ * the reference is strictly one slide per call, Step3_WSI_classification_ACMIL.py:253-258 -- this is the batched eval of the composed
+ * families, where acmil_linear_f16x3 and acmil_gated_scores_packed already ran over all rows at once).  A is not modified.
+ * Outputs per bag: sub_preds [nbags, K, C], slide_pred [nbags, C], afeat [nbags, K, Di], bag_feat [nbags, Di] (each may be NULL).
+ * workspace: acmil_ga_pool_group_workspace_bytes, initialised once with acmil_ga_workspace_init. */
+size_t acmil_ga_pool_group_workspace_bytes(int N, int nbags, int Di, int K);
+
+int acmil_ga_pool_group(const float* h, const float* A, int N, int nbags, const int* rows, const void* packed, int D, int Di, int Da,
+                        int K, int C, int mode, float* sub_preds, float* slide_pred, float* afeat, float* bag_feat, int has_bag_head,
+                        void* workspace, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * STKIM selection.  Replaces transformer.py:314-317: top-k of each branch's scores (sorted by descending
  * score, ties broken towards the LOWER index), then the first m = int(k*mask_drop) columns of

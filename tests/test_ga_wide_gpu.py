@@ -169,3 +169,95 @@ def test_range_guard_on_the_composed_path_uses_the_projection_kernels_status_wor
         ok = torch.from_numpy(case["x"]).float().cuda()
         guarded(ok)
         assert guarded.range_fallbacks == before + 1          # an in-range bag stays on the split-f16 path
+
+
+# ------------------------------------------------------------------------------------------------ grouped eval of the composed families
+@pytest.mark.parametrize("tag", ["d1536_k5_c2", "d512_k8_c2", "d1024_k16_c2"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_forward_group_equals_per_slide_forward_and_reference(tag, dtype):
+    """ACMIL_GA.forward_group (rows of several slides back to back: ONE projection launch, ONE gated-score launch, per-bag pooling
+    tiles, batched merge + heads) == `model(x)` per slide BIT FOR BIT (every output element is the same fixed-order sum), and the
+    fixture bag inside the group matches the reference (transformer.py:305-330)."""
+    case, sd = load_golden("ga_eval_n300_" + tag)
+    d, di, k, c = case_dims(sd)
+    model = _model(sd, "f16x3").eval()
+    assert model._is_composed_groupable("f16x3")
+    x0 = torch.from_numpy(case["x"]).cuda()
+    x0 = (x0[0] if x0.dim() == 3 else x0).to(dtype)
+    g = torch.Generator().manual_seed(7)
+    rows = [129, 300, 1, 1000, 57, 128, 257]                       # ragged, tile-boundary cases of the 128-row pooling tiles and the 256-row projection tiles
+    bags = [(torch.randn(n, d, generator=g) * 0.5).cuda().to(dtype) if i != 1 else x0 for i, n in enumerate(rows)]
+    xcat = torch.cat(bags, 0)
+    with torch.no_grad():
+        triples = model.forward_group(xcat, rows)
+        singles = [model(b.unsqueeze(0)) for b in bags]
+    assert len(triples) == len(rows)
+    for (sub, slide, a), (sub1, slide1, a1), n in zip(triples, singles, rows):
+        assert a.shape == (1, k, n) and sub.shape == (k, c) and slide.shape == (1, c)
+        assert torch.equal(a, a1) and torch.equal(sub, sub1) and torch.equal(slide, slide1)
+    sub, slide, a = triples[1]
+    np.testing.assert_allclose(a.cpu().numpy(), case["A_out"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(sub.cpu().numpy(), case["sub_preds"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(slide.cpu().numpy(), case["slide_pred"], rtol=0, atol=TOL)
+    assert model.range_fallbacks == 0
+
+
+def test_forward_group_more_than_sixteen_bags_guard_and_other_families():
+    """> 16 bags go out as several groups; a group with a value outside the f16 range is repeated in fp32 (== the per-slide guarded
+    forward within the parity bound); a deferred ticket reports it instead; a fused family routes to forward_batch."""
+    case, sd = load_golden("ga_eval_n300_d1536_k5_c2")
+    d, di, k, c = case_dims(sd)
+    model = _model(sd, "f16x3").eval()
+    g = torch.Generator().manual_seed(11)
+    rows = [40 + 13 * i for i in range(19)]
+    bags = [(torch.randn(n, d, generator=g) * 0.5).cuda() for n in rows]
+    with torch.no_grad():
+        triples = model.forward_group(torch.cat(bags, 0), rows)
+        for (sub, slide, a), b in zip(triples, bags):
+            s1, l1, a1 = model(b.unsqueeze(0))
+            assert torch.equal(a, a1) and torch.equal(sub, s1) and torch.equal(slide, l1)
+        bad = [b.clone() for b in bags[:5]]
+        bad[2][7, 3] = 1.0e5                                     # |x| >= 65504: the split-f16 arithmetic cannot represent it
+        rows5 = rows[:5]
+        before = model.range_fallbacks
+        t_bad = model.forward_group(torch.cat(bad, 0), rows5)
+        assert model.range_fallbacks > before
+        m32 = _model(sd, "fp32").eval()
+        for (sub, slide, a), b in zip(t_bad, bad):
+            s1, l1, a1 = m32(b.unsqueeze(0))
+            assert torch.isfinite(a).all()
+            np.testing.assert_allclose(a.cpu().numpy(), a1.cpu().numpy(), rtol=0, atol=TOL)
+            np.testing.assert_allclose(sub.cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=TOL)
+        _, ticket = model.forward_group(torch.cat(bad, 0), rows5, defer_guard=True)
+        assert ticket is not None and int(ticket) != 0
+        _, ticket = model.forward_group(torch.cat(bags[:5], 0), rows5, defer_guard=True)
+        assert ticket is not None and int(ticket) == 0
+    # a fused family: the same call, served by forward_batch on the row views
+    case2, sd2 = load_golden("ga_eval_n257_d512_k5_c2")
+    m2 = _model(sd2, "f16x3").eval()
+    assert not m2._is_composed_groupable("f16x3")
+    xb = torch.randn(300, 512, generator=g).cuda()
+    with torch.no_grad():
+        t = m2.forward_group(torch.cat([xb, xb[:77]], 0), [300, 77])
+        s1, l1, a1 = m2(xb.unsqueeze(0))
+    np.testing.assert_allclose(t[0][2].cpu().numpy(), a1.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(t[0][0].cpu().numpy(), s1.cpu().numpy(), rtol=0, atol=2e-6)
+
+
+def test_evaluate_groups_the_composed_family(tmp_path):
+    """train.evaluate on a GigaPath-shaped model: staged row-concatenated groups through forward_group == the per-slide loop."""
+    from acmil_amd import train as T
+    case, sd = load_golden("ga_eval_n300_d1536_k5_c2")
+    d, di, k, c = case_dims(sd)
+    model = _model(sd, "f16x3").eval()
+    data = T.SyntheticBags(21, (60, 400), d, c, seed=3)
+    conf = T.Struct(n_class=c, arch="ga")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    det_g, det_s = {}, {}
+    with torch.no_grad():
+        rg = T.evaluate(model, data, dev, conf, detail=det_g)
+        rs = T.evaluate(model, data, dev, conf, batched=False, detail=det_s)
+    assert torch.equal(det_g["prob"], det_s["prob"])
+    np.testing.assert_allclose(det_g["loss"].numpy(), det_s["loss"].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(det_g["div"].numpy(), det_s["div"].numpy(), rtol=0, atol=1e-6)
+    assert rg[:3] == rs[:3]
