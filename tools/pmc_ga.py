@@ -51,6 +51,8 @@ def total(res, counter):
     """sum over ALL kernels of the command: (counter total, dispatches)"""
     t, n = 0.0, 0
     for (kn, cn), (avg, cnt) in res.items():
+        if "copyBuffer" in kn or "CatArray" in kn:      # the process's set-up copies (bags H2D / group assembly), not the step
+            continue
         if cn == counter:
             t += avg * cnt
             n += cnt

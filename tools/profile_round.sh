@@ -18,7 +18,13 @@ run_stats() {   # name, bench args...
 }
 # ONLY_TRAIN=1: the training-step evidence alone (PMC of both step sizes, the driver-style default line, the two train lines + traces)
 # PMC first (their summaries stamp the kernel source; the bench lines below then carry `traffic`)
-if [ -z "$ONLY_TRAIN" ]; then
+# ONLY_STALE=1 (round 6, last session): the workloads whose kernel sources changed after their PMC summaries were taken (TransMIL, the
+# training step) and the grouped GigaPath line; the GA eval / cfg3 / UNI / CLIP-L summaries of profiles/r06_* still match their sources
+if [ -n "$ONLY_STALE" ]; then
+python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
+python tools/pmc_ga.py --workload ga_gigapath --batch 16 --whole-step --steps 8 --out $OUT/pmc > $OUT/pmc_ga_gigapath_b16.log 2>&1
+python tools/pmc_ga.py --workload ga_gigapath --batch 1 --whole-step --steps 30 --out $OUT/pmc > $OUT/pmc_ga_gigapath.log 2>&1
+elif [ -z "$ONLY_TRAIN" ]; then
 python tools/pmc_ga.py --batch 64 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_b64.log 2>&1
 python tools/pmc_ga.py --batch 1 --steps 100 --out $OUT/pmc > $OUT/pmc_ga_eval_b1.log 2>&1
 python tools/pmc_ga.py --precision fp32 --batch 16 --steps 12 --out $OUT/pmc > $OUT/pmc_ga_eval_fp32.log 2>&1
@@ -35,7 +41,11 @@ python tools/pmc_ga.py --workload train --batch 508 --whole-step --steps 20 --ex
 cp $OUT/pmc/pmc_*.json $OUT/ 2>/dev/null
 for f in $OUT/pmc/pmc_*.json; do cp $f profiles/${TAG}_$(basename $f); done      # so that the bench lines below carry `traffic`
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_args.json 2> $OUT/bench_default.log
-if [ -z "$ONLY_TRAIN" ]; then
+if [ -n "$ONLY_STALE" ]; then
+python bench.py --workload ga_gigapath --steps 30 --warmup 5 > $OUT/bench_ga_gigapath.json 2> $OUT/bench_ga_gigapath.log
+python bench.py --workload ga_gigapath --batch 1 --steps 100 --no-cpu-baseline > $OUT/bench_ga_gigapath_b1.json 2>> $OUT/bench_ga_gigapath.log
+python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
+elif [ -z "$ONLY_TRAIN" ]; then
 python bench.py --no-secondary > $OUT/bench_default.json 2>> $OUT/bench_default.log
 python bench.py --batch 16 --no-cpu-baseline --no-secondary > $OUT/bench_b16.json 2>> $OUT/bench_default.log
 python bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/bench_b1.json 2>> $OUT/bench_default.log
@@ -65,7 +75,10 @@ best_of3 $OUT/bench_train_n50k.json --workload train --train-n 50000 >> $OUT/ben
 best_of3 $OUT/bench_train_n10k_g8.json --workload train --bags-per-step 8 --steps 100 --warmup 20 >> $OUT/bench_train_runs.log
 best_of3 $OUT/bench_train_n50k_g8.json --workload train --train-n 50000 --bags-per-step 8 --steps 40 --warmup 8 >> $OUT/bench_train_runs.log
 python bench.py --workload train --bags-per-step 16 --steps 60 --warmup 10 --no-cpu-baseline > $OUT/bench_train_n10k_g16.json 2>> $OUT/bench_train.log
-if [ -z "$ONLY_TRAIN" ]; then
+if [ -n "$ONLY_STALE" ]; then
+run_stats bench_ga_gigapath_g16 --workload ga_gigapath --steps 20 --warmup 3 --no-cpu-baseline --no-b1
+run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
+elif [ -z "$ONLY_TRAIN" ]; then
 run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline --no-secondary
 run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
 run_stats bench_ga_uni_f16x3_b64 --workload ga_uni --steps 10 --warmup 3 --no-b1 --no-cpu-baseline
