@@ -11,7 +11,7 @@
 // ------------------------------------------------------------------------------------------------
 // merge: afeat[k][:] = (sum_t e^{m_t-M} acc_t) / (sum_t e^{m_t-M} l_t), fixed summation order.
 // grid (K, Di/64), 1024 threads = 16 groups of 64 lanes; lane = feature, group g takes tiles g, g+16, ...
-// Loads of up to 4 tiles are issued together (the loop is latency-, not bandwidth-bound).
+// Loads of up to 8 tiles are issued together (the loop is latency-, not bandwidth-bound).
 // ------------------------------------------------------------------------------------------------
 #define GA_MERGE_GROUPS 16
 struct GaBatchTiles { int start[GA_MAX_BATCH + 1]; };
@@ -40,16 +40,19 @@ __global__ __launch_bounds__(1024) void ga_merge_kernel(const float* __restrict_
     for (int w = 1; w < GA_MERGE_GROUPS; ++w) M = fmaxf(M, smx[w]);
     float acc = 0.0f, l = 0.0f;
     const int di = 64 * c + lane;
-    for (int t0 = g; t0 < tiles; t0 += 4 * GA_MERGE_GROUPS) {
-        float pm[4], pl[4], pa[4];
+    // (8 tiles per wave group in flight, as ga_tail_kernel: the loop is a chain of dependent round trips -- 391 tiles were 7 of them
+    //  with 4 in flight; the order of the sum is unchanged: g, g + 16, g + 32, ...)
+    constexpr int MU = 8;
+    for (int t0 = g; t0 < tiles; t0 += MU * GA_MERGE_GROUPS) {
+        float pm[MU], pl[MU], pa[MU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
             const int t = t0 + u * GA_MERGE_GROUPS;
             const float* p = base + (size_t)(t < tiles ? t : t0) * tstride;
             pm[u] = p[0]; pl[u] = p[1]; pa[u] = p[2 + di];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
             if (t0 + u * GA_MERGE_GROUPS < tiles) {
                 const float f = __expf(pm[u] - M);
                 l = fmaf(f, pl[u], l);

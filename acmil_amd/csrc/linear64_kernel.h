@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int NB = G::NB, PD = G::PD, RW = G::RW, XG = G::XG, NV = G::NV;
     constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);      // (a bf16 operand is f16-exact like an fp16 one: converted, no lo plane)
     constexpr bool XCV = XLO || (XDT != ACMIL_DTYPE_F16);
+    constexpr bool LOSKIP = LIN_LOSKIP && (XDT == ACMIL_DTYPE_F32) && FX == 0;
     constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0;
     static_assert(NB == 4 && PD == 3, "the K loop is unrolled by 4: slot and register-set indices are compile-time");
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -284,6 +285,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
 #pragma unroll
                 for (int b = 0; b < 2; ++b) { xh[b] = __builtin_bit_cast(f16x8, hw[b]); if constexpr (XLO) xl[b] = __builtin_bit_cast(f16x8, lw[b]); }
+                bool lo_any = true;      // fp32 rows of f16-exact values: no W_hi x_lo group for this wave and step (linear_kernel.h)
+                if constexpr (LOSKIP) {
+                    const unsigned lo_or = (lw[0][0] | lw[0][1] | lw[0][2] | lw[0][3] | lw[1][0] | lw[1][1] | lw[1][2] | lw[1][3]) & 0x7fff7fffu;
+                    lo_any = __builtin_amdgcn_ballot_w64(lo_or != 0u) != 0ull;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (!(LIN64_ABL & 32)) {
 #pragma unroll
@@ -316,10 +322,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                 }
                 if constexpr (XLO) {
+                    if (lo_any) {
 #pragma unroll
-                    for (int d = 0; d < ND; ++d)
+                        for (int d = 0; d < ND; ++d)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) acc[b][d] = LIN64_MFMA(WH[d], xl[b], acc[b][d], 0, 0, 0);
+                            for (int b = 0; b < 2; ++b) acc[b][d] = LIN64_MFMA(WH[d], xl[b], acc[b][d], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -20,6 +20,10 @@
 #define LIN_XCD_ORDER 1
 #endif
 
+#ifndef LIN_LOSKIP
+#define LIN_LOSKIP 1          // 0 (A/B builds): always issue the W_hi x_lo products of an fp32 operand
+#endif
+
 #define LIN_CTRL_BYTES 96        // control words of one Linear call (linear.hip::lin_f16x3_run)
 
 // timing-only ablations of lin_kernel (tools/build_lin_variants.sh; WRONG results): 1 no x DMA, 2 no weight DMA, 8 no epilogue stores
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
     // operand is f16-exact like an fp16 one (ga_forward_kernel_v2.h) and is only converted
     constexpr bool XLO = (XDT == ACMIL_DTYPE_F32) || (FX & 1);
     constexpr bool XCV = XLO || (XDT != ACMIL_DTYPE_F16);
+    constexpr bool LOSKIP = LIN_LOSKIP && (XDT == ACMIL_DTYPE_F32) && FX == 0;      // raw fp32 rows only (a normalised operand has real lo halves)
     constexpr bool NORM = (FX & 1) != 0, LMP = (FX & 2) != 0, INSTAT = (FX & 4) != 0;
     static_assert(!INSTAT || NORM, "FX & 4 extends the LayerNorm fold");
     static_assert(PD == 2 && NB == 3, "wait counts assume a prefetch distance of 2 steps");
@@ -303,6 +308,13 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
                     for (int j = 0; j < NSP; ++j) split_piece(j);
                 }
                 split_done(xh, xl);
+                // an fp32 operand whose values are f16-exact (bags stored fp16 and up-cast by the loop, Step3_WSI_classification_ACMIL.py:193)
+                // has lo halves of exact zeros: skip the W_hi x_lo group of this wave and step (ga_forward_kernel_v2.h; same numbers)
+                bool lo_any = true;
+                if constexpr (LOSKIP) {
+                    const unsigned lo_or = (xlw[0] | xlw[1] | xlw[2] | xlw[3]) & 0x7fff7fffu;
+                    lo_any = __builtin_amdgcn_ballot_w64(lo_or != 0u) != 0ull;
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int d = 0; d < ND; ++d) WL[d] = *(const f16x8*)(slot + G::frow(ND + d) + lane16);
@@ -322,8 +334,10 @@ __global__ __launch_bounds__(64 * WV, 2) void lin_kernel(LinArgs a) {
                 }
                 islot = (islot + 1 == NB) ? 0 : islot + 1;
                 if constexpr (XLO) {
+                    if (lo_any) {
 #pragma unroll
-                    for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xl, acc[d], 0, 0, 0);
+                        for (int d = 0; d < ND; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH[d], xl, acc[d], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 xhp = xh;

@@ -263,6 +263,12 @@ def other_workloads(args, ctx):
         bags = [torch.randn(1, N, D, generator=torch.Generator().manual_seed(1000 + rank * 4 + i)).to(dev) for i in range(4)]
         with torch.no_grad():
             dt = _timed(lambda i: model(bags[i % 4]), args, world, dev)
+            ms_f16v = None
+            if not getattr(args, "no_b1", False):      # fp32 bags of fp16 VALUES (the reference's loader): _fc1 drops its W_hi x_lo products
+                b16 = [b.half().float() for b in bags]
+                a2 = argparse.Namespace(**vars(args)); a2.steps, a2.warmup = max(10, args.steps // 2), 3
+                ms_f16v = round(_timed(lambda i: model(b16[i % 4]), a2, world, dev) / a2.steps * 1e3, 3)
+                del b16
         side = int(-(-N ** 0.5 // 1)); n = side * side + 1; m = Di // 2; npad = -(-n // m) * m; h, d = 8, Di // 8
         # SURVEY 8(d), re-associated: fc1 + 2 layers x (qkv, 4 head-batched n' x m x d products, out-proj, res-conv, pinv) + PPEG
         flops = 2 * N * D * Di + 2 * (2 * npad * Di * 3 * Di + 4 * (2 * h * npad * m * d) + 2 * npad * Di * Di + 2 * 33 * npad * Di
@@ -277,6 +283,7 @@ def other_workloads(args, ctx):
         result = {
             "metric": "slides/sec (TransMIL / Nystrom-attention eval forward, N=100000 D=768)", "value": round(world * args.steps / dt, 2),
             "unit": "slides/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(t_slide * 1e3, 3),
+            "ms_per_step_fp32_bag_of_fp16_values": ms_f16v,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (Linear layers and attention legs as split-f16 x3 MFMA products with fp32 accumulate; pinv products exact fp32 MFMA)",
             "data": "synthetic",
@@ -528,6 +535,20 @@ def wide_workload(args, ctx):
                 per_slide = round(world * a1.steps / _timed(lambda i: model(bags[i % nb].unsqueeze(0)), a1, world, dev), 1)
         else:
             dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
+        # what the reference's loop feeds (Step3_WSI_classification_ACMIL.py:193: fp16-stored features up-cast to fp32): the same bags
+        # rounded to fp16 values, still fp32 storage -- the Linear kernel drops the W_hi x_lo products of such rows per wave and K step
+        rate_f16v = None
+        if not args.no_b1:
+            a2 = argparse.Namespace(**vars(args)); a2.steps, a2.warmup = max(10, args.steps // 2), 3
+            if G > 1:
+                for xg, _ in groups:
+                    for j in range(G):
+                        xg[j * N:(j + 1) * N].copy_(xg[j * N:(j + 1) * N].half())
+                rate_f16v = round(world * G * a2.steps / _timed(lambda i: model.forward_group(*groups[i % 3]), a2, world, dev), 1)
+            else:
+                b16 = [b.half().float() for b in bags]
+                rate_f16v = round(world * a2.steps / _timed(lambda i: model(b16[i % nb].unsqueeze(0)), a2, world, dev), 1)
+                del b16
     t_slide = dt / args.steps / G
     nbytes, flops = algorithmic_work(N, D, Di, K, C)
     g1 = 2.0 * N * D * Di
@@ -546,6 +567,7 @@ def wide_workload(args, ctx):
                                "(projection -> gated scores -> pooling)" % (N, D, Di, K, C, "%d bags rotated" % nb if G == 1 else "3 groups rotated"),
                    "precision": args.precision, "slides_per_step": G, "sharding": "independent slides per GPU, no collective"},
         "module_slides_per_s": None if per_slide is None else {"model(x) per slide": per_slide},
+        "slides_per_s_fp32_bags_of_fp16_values": rate_f16v,
         "roofline": {"kernel": "whole composed forward (lin_kernel projection + gated scores + pooling + merge + heads)", "bound": "mfma",
                      "achieved": round(flops / t_slide / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / t_slide / 1e12 / peak, 4),
                      # PMC summary of the whole composed forward: tools/pmc_ga.py --workload <name> --whole-step --batch 1
@@ -656,6 +678,8 @@ SECONDARY = (     # (key, argv overrides): the other BASELINE.json configs, meas
     ("train_n50k", dict(workload="train", train_n=50000, steps=150, warmup=30)),
     ("train_n10k_g8", dict(workload="train", train_n=10000, steps=100, warmup=20, bags_per_step=8)),
     ("train_n50k_g8", dict(workload="train", train_n=50000, steps=40, warmup=8, bags_per_step=8)),
+    # the reference's widest extractor (Step3_WSI_classification_ACMIL.py:84-87), the one family without a fused kernel: groups of 16 slides
+    ("ga_gigapath_g16", dict(workload="ga_gigapath", steps=20, warmup=3, batch=16)),
 )
 
 
@@ -678,7 +702,7 @@ def secondary_lines(args, ctx):
             setattr(a, k, v)
         t0 = time.perf_counter()
         try:
-            r = ga_workload(a, ctx) if a.workload in GA_SHAPES else other_workloads(a, ctx)
+            r = ga_workload(a, ctx) if a.workload in GA_SHAPES else wide_workload(a, ctx) if a.workload in WIDE_SHAPES else other_workloads(a, ctx)
             r["wall_s"] = round(time.perf_counter() - t0, 1)
         except (Exception, SystemExit) as e:      # a secondary line must never cost the headline
             r = {"error": "%s: %s" % (type(e).__name__, e)}

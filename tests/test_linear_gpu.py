@@ -66,3 +66,32 @@ def test_linear_bitwise_reproducible_and_equal_to_generic_gemm_class():
     assert torch.equal(a, b)
     c = ops.gemm(x, w, trans_b=True, precision="f16x3")
     assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item()
+
+
+@pytest.mark.parametrize("m,k,n_out", [(3000, 512, 256), (22100, 768, 768), (40000, 1536, 768), (257, 64, 128)])      # lin_kernel, lin64_kernel (K >= 768, >= 256 units), both
+def test_fp32_rows_of_f16_exact_values_skip_the_lo_products(m, k, n_out):
+    """An fp32 operand whose values are f16-exact (bags stored fp16 and up-cast by the loop, Step3_WSI_classification_ACMIL.py:193)
+    has lo halves of exact zeros: the kernels drop the W_hi x_lo MFMA group per wave and K step.  The result is the SAME numbers as the
+    16-bit storage path (which never had that group) bit for bit; rows with a real lo half inside an otherwise exact operand keep the
+    full three products (fp64 bound); both arithmetic classes bitwise reproducible."""
+    from acmil_amd import ops
+    g = torch.Generator().manual_seed(5 * m + k)
+    x16 = (torch.randn(m, k, generator=g) * 2.0).half()
+    w = torch.randn(n_out, k, generator=g) * 0.05
+    b = torch.randn(n_out, generator=g)
+    packed = ops.linear_pack(w.cuda())
+    y32 = ops.linear_f16x3(x16.float().cuda(), packed, n_out, bias=b.cuda(), relu=True)
+    y16 = ops.linear_f16x3(x16.cuda(), packed, n_out, bias=b.cuda(), relu=True)
+    assert torch.equal(y32, y16)
+    # a few rows with genuine fp32 values: their waves run the third product, every other wave still skips it
+    xm = x16.float()
+    rows = torch.randint(0, m, (max(1, m // 97),), generator=g)
+    xm[rows] += torch.randn(len(rows), k, generator=g) * 1e-4
+    ref = (xm.double() @ w.double().T + b.double()).clamp_min(0)
+    scale = (xm.double().abs() @ w.double().abs().T).max().item()
+    ym = ops.linear_f16x3(xm.cuda(), packed, n_out, bias=b.cuda(), relu=True)
+    assert (ym.cpu().double() - ref).abs().max().item() <= 3e-6 * scale + 1e-6
+    assert torch.equal(ym, ops.linear_f16x3(xm.cuda(), packed, n_out, bias=b.cuda(), relu=True))
+    keep = torch.ones(m, dtype=torch.bool); keep[rows] = False
+    # rows that share a 32-row wave tile with a perturbed row take the general path: still the same numbers (the skipped products are zeros)
+    assert torch.equal(ym.cpu()[keep], y32.cpu()[keep])
