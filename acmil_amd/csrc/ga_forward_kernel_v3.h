@@ -43,6 +43,12 @@
 #define GA3_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
 #endif
 
+// D += A B unless the wave-uniform word `cond` is zero: the branch lives inside the asm statement (see the GEMM1 loop).  The accumulator
+// tile is read and written in place (exactly the same vDst as the MFMAs before and after it: hardware-interlocked, no software wait states).
+#define GA3_MFMA_IF(cond, A, B, C)                                                                                     \
+    asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 1f\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n1:"              \
+                 : "+a"(C) : "v"(A), "v"(B), "s"(cond) : "scc")
+
 template <int ND, int PB, int KP, int XDT, bool POOLED = true>
 struct Ga3Geom {
     static constexpr int WAVES = 4;
@@ -332,6 +338,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         for (int p = 0; p < NSP; ++p) split_piece(p);
                     }
                     split_done();
+                    // fp32 bags of f16-exact values (stored fp16, up-cast by the loop): lo halves of exact zeros -- the W_hi x_lo MFMAs of this
+                    // wave and step are branched over one by one INSIDE their asm statement (GA3_MFMA_IF): for the compiler the group stays
+                    // straight-line code (a C++ branch around it cost the AGPR pinning of the 256 accumulators: 430 - 700 spilled registers)
+                    unsigned lo_any = 1u;
+                    if constexpr (XLO && GA2_LOSKIP) {
+                        unsigned lo_or = 0u;
+#pragma unroll
+                        for (int b = 0; b < PB; ++b) lo_or |= xlw[b][0] | xlw[b][1] | xlw[b][2] | xlw[b][3];
+                        lo_any = (unsigned)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64((lo_or & 0x7fff7fffu) != 0u) != 0ull ? 1u : 0u));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     read_lo(slot);
                     // P1(s) = Whi * xhi, P2(s) = Whi * xlo (fp32 bags); the LDS-DMA pieces of step s + PD go out one per MFMA gap (bag rows
@@ -356,7 +372,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         for (int d = 0; d < ND; ++d)
 #pragma unroll
                             for (int b = 0; b < PB; ++b) {
-                                acc1[b][d] = GA3_MFMA(WH[d], xl[b], acc1[b][d]);
+                                if constexpr (GA2_LOSKIP && !(GA3_ABL & 4)) GA3_MFMA_IF(lo_any, WH[d], xl[b], acc1[b][d]);
+                                else acc1[b][d] = GA3_MFMA(WH[d], xl[b], acc1[b][d]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 GA3_DMA_AT(ND * PB + d * PB + b - G0, s + PD, islot, (unsigned)lane16, wx, T.xrow0, xoff);
                                 __builtin_amdgcn_sched_barrier(0);

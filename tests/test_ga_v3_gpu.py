@@ -328,3 +328,35 @@ def test_composed_path_device_side_guard(d, di, k, xdt):
     assert (s1.cpu() - ref["sub_preds"]).abs().max().item() < 1e-3 and (b1.cpu() - ref["slide_pred"]).abs().max().item() < 1e-3
     refg = O.acmil_ga_forward(good.float(), sd, n_token=k)
     assert (a0.cpu() - refg["A_out"]).abs().max().item() < TOL and (s0.cpu() - refg["sub_preds"]).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("d,di", [(768, 384), (1024, 512)])
+def test_wide_fused_skips_lo_products_of_fp16_valued_rows_only(d, di):
+    """fp32 bags of f16-exact values (the reference's loader: fp16 features up-cast, Step3_WSI_classification_ACMIL.py:193): the W_hi x_lo
+    MFMAs are branched over per wave and K step inside ga_fwd3_kernel.  A bag with a few genuine fp32 rows keeps them for those waves:
+    every patch's scores equal the fp16-valued launch's bit for bit where the row is unchanged (the skipped products are zeros), and the
+    perturbed rows match the oracle; also through the training score pass (h saved)."""
+    from oracle import ga_oracle as O
+    from acmil_amd import ops
+    model, sd = _model(d, di, 5, 2, seed=9)
+    n = 5000
+    x16 = O.synthetic_bag(n, d, slide_idx=123)[0].half()
+    xe = x16.float()
+    g = torch.Generator().manual_seed(4)
+    rows = torch.randint(0, n, (40,), generator=g)
+    xm = xe.clone()
+    xm[rows] += torch.randn(40, d, generator=g) * 1e-4
+    with torch.no_grad():
+        s_e, l_e, a_e = model(xe.cuda().unsqueeze(0))
+        s_h, l_h, a_h = model(x16.cuda().unsqueeze(0))
+        s_m, l_m, a_m = model(xm.cuda().unsqueeze(0))
+    assert torch.equal(a_e, a_h) and torch.equal(s_e, s_h) and torch.equal(l_e, l_h)
+    keep = torch.ones(n, dtype=torch.bool); keep[rows] = False
+    assert torch.equal(a_m[0].cpu()[:, keep], a_e[0].cpu()[:, keep])
+    ref = O.acmil_ga_forward(xm.unsqueeze(0), sd, n_token=5)
+    assert (a_m.cpu() - ref["A_out"]).abs().max().item() < TOL
+    assert (s_m.cpu() - ref["sub_preds"]).abs().max().item() < TOL
+    packed, dims = model._packed()
+    A1, h1 = ops.ga_scores(xe.cuda(), packed, dims, "f16x3")
+    A2, h2 = ops.ga_scores(x16.cuda(), packed, dims, "f16x3")
+    assert torch.equal(A1, A2) and torch.equal(h1, h2)

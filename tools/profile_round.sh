@@ -32,6 +32,7 @@ python tools/pmc_ga.py --workload ga_cfg3 --batch 64 --steps 12 --out $OUT/pmc >
 python tools/pmc_ga.py --workload transmil --batch 1 --whole-step --steps 10 --out $OUT/pmc > $OUT/pmc_transmil.log 2>&1
 for w in ga_uni ga_clip_l; do python tools/pmc_ga.py --workload $w --batch 64 --steps 8 --out $OUT/pmc > $OUT/pmc_$w.log 2>&1; done      # fused since round 5
 python tools/pmc_ga.py --workload ga_gigapath --batch 1 --whole-step --steps 30 --out $OUT/pmc > $OUT/pmc_ga_gigapath.log 2>&1
+python tools/pmc_ga.py --workload ga_gigapath --batch 16 --whole-step --steps 8 --out $OUT/pmc > $OUT/pmc_ga_gigapath_b16.log 2>&1      # groups of 16 slides
 fi
 python tools/pmc_ga.py --workload train --batch 1 --whole-step --steps 100 --out $OUT/pmc > $OUT/pmc_train10k.log 2>&1
 python tools/pmc_ga.py --workload train --batch 50 --whole-step --steps 50 --extra "--train-n 50000" --out $OUT/pmc > $OUT/pmc_train50k.log 2>&1
@@ -52,7 +53,8 @@ python bench.py --batch 1 --no-cpu-baseline --no-secondary > $OUT/bench_b1.json 
 python bench.py --precision fp32 --batch 16 --no-cpu-baseline --no-b1 --no-secondary > $OUT/bench_fp32.json 2>> $OUT/bench_default.log
 python bench.py --workload ga_cfg3 > $OUT/bench_ga_cfg3.json 2> $OUT/bench_ga_cfg3.log
 for w in ga_uni ga_clip_l; do python bench.py --workload $w --steps 20 --warmup 5 > $OUT/bench_$w.json 2> $OUT/bench_$w.log; done
-python bench.py --workload ga_gigapath --steps 50 > $OUT/bench_ga_gigapath.json 2> $OUT/bench_ga_gigapath.log
+python bench.py --workload ga_gigapath --steps 30 --warmup 5 > $OUT/bench_ga_gigapath.json 2> $OUT/bench_ga_gigapath.log
+python bench.py --workload ga_gigapath --batch 1 --steps 100 --no-cpu-baseline > $OUT/bench_ga_gigapath_b1.json 2>> $OUT/bench_ga_gigapath.log
 python bench.py --workload transmil > $OUT/bench_transmil.json 2> $OUT/bench_transmil.log
 fi
 # the training lines are host-sensitive (0.11 ms of Python per step against 0.16 ms of GPU time at N = 10 000; the boxes' hosts are
@@ -83,7 +85,8 @@ run_stats bench_ga_eval_f16x3_b64 --steps 20 --warmup 5 --no-b1 --no-cpu-baselin
 run_stats bench_ga_cfg3_f16x3_b64 --workload ga_cfg3 --steps 20 --warmup 5 --no-b1 --no-cpu-baseline
 run_stats bench_ga_uni_f16x3_b64 --workload ga_uni --steps 10 --warmup 3 --no-b1 --no-cpu-baseline
 run_stats bench_ga_clip_l_f16x3_b64 --workload ga_clip_l --steps 10 --warmup 3 --no-b1 --no-cpu-baseline
-run_stats bench_ga_gigapath --workload ga_gigapath --steps 50 --warmup 5 --no-cpu-baseline
+run_stats bench_ga_gigapath_g16 --workload ga_gigapath --steps 20 --warmup 3 --no-cpu-baseline --no-b1
+run_stats bench_ga_gigapath_b1 --workload ga_gigapath --batch 1 --steps 50 --warmup 5 --no-cpu-baseline --no-b1
 run_stats bench_transmil --workload transmil --steps 30 --warmup 5 --no-cpu-baseline
 fi
 run_stats bench_train_n10k --workload train --steps 200 --warmup 20 --no-cpu-baseline
