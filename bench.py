@@ -537,7 +537,7 @@ def wide_workload(args, ctx):
             dt = _timed(lambda i: model(bags[i % nb].unsqueeze(0)), args, world, dev)
         # what the reference's loop feeds (Step3_WSI_classification_ACMIL.py:193: fp16-stored features up-cast to fp32): the same bags
         # rounded to fp16 values, still fp32 storage -- the Linear kernel drops the W_hi x_lo products of such rows per wave and K step
-        rate_f16v = None
+        rate_f16v = rate_f16s = None
         if not args.no_b1:
             a2 = argparse.Namespace(**vars(args)); a2.steps, a2.warmup = max(10, args.steps // 2), 3
             if G > 1:
@@ -545,6 +545,9 @@ def wide_workload(args, ctx):
                     for j in range(G):
                         xg[j * N:(j + 1) * N].copy_(xg[j * N:(j + 1) * N].half())
                 rate_f16v = round(world * G * a2.steps / _timed(lambda i: model.forward_group(*groups[i % 3]), a2, world, dev), 1)
+                # ... and as the staging ring delivers them when the features are stored fp16: no up-cast at all (train.evaluate)
+                groups = [(xg.half(), r) for xg, r in groups]
+                rate_f16s = round(world * G * a2.steps / _timed(lambda i: model.forward_group(*groups[i % 3]), a2, world, dev), 1)
             else:
                 b16 = [b.half().float() for b in bags]
                 rate_f16v = round(world * a2.steps / _timed(lambda i: model(b16[i % nb].unsqueeze(0)), a2, world, dev), 1)
@@ -567,7 +570,7 @@ def wide_workload(args, ctx):
                                "(projection -> gated scores -> pooling)" % (N, D, Di, K, C, "%d bags rotated" % nb if G == 1 else "3 groups rotated"),
                    "precision": args.precision, "slides_per_step": G, "sharding": "independent slides per GPU, no collective"},
         "module_slides_per_s": None if per_slide is None else {"model(x) per slide": per_slide},
-        "slides_per_s_fp32_bags_of_fp16_values": rate_f16v,
+        "slides_per_s_fp32_bags_of_fp16_values": rate_f16v, "slides_per_s_fp16_stored_bags": rate_f16s,
         "roofline": {"kernel": "whole composed forward (lin_kernel projection + gated scores + pooling + merge + heads)", "bound": "mfma",
                      "achieved": round(flops / t_slide / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(flops / t_slide / 1e12 / peak, 4),
                      # PMC summary of the whole composed forward: tools/pmc_ga.py --workload <name> --whole-step --batch 1
