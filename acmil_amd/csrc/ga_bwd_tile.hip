@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
 #ifdef BT_PROF
     const unsigned long long ptA = __builtin_amdgcn_s_memtime();
-    unsigned long long ptB = 0, ptR = 0, ptR0 = 0;
+    unsigned long long ptB = 0, ptR = 0;
 #endif
 
     // ================================================================ 2: gate pass (wave w: rows RPW w .. RPW w + RPW - 1)
@@ -309,9 +309,6 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                 }
             }
             ga_lds_barrier();
-#ifdef BT_PROF
-            if (round == 0) ptR0 = __builtin_amdgcn_s_memtime();
-#endif
         }
         float* out = a.part + (size_t)blockIdx.x * PREC;
         for (int e = tid; e < PREC; e += BT_THREADS) out[e] = slots[e] + slots[PREC + e];
@@ -389,8 +386,8 @@ __global__ __launch_bounds__(BT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
 #ifdef BT_PROF
         if ((blockIdx.x == 3 || blockIdx.x == 300) && tid == 0)
-            printf("BT phases (cycles) blk %d: stage+gemm1 %llu  Gt write %llu  gate loads+pre %llu  barrier %llu  gate rows %llu  (wait for the slowest wave %llu)  records %llu  gemm3 %llu  epilogue %llu  total %llu\n",
-                   (int)blockIdx.x, pt1 - pt0, ptA - pt1, ptB - ptA, pt1c - ptB, ptR - pt1c, ptR0 - ptR, pt2 - ptR0, pt3 - pt2, __builtin_amdgcn_s_memtime() - pt3, __builtin_amdgcn_s_memtime() - pt0);
+            printf("BT phases (cycles) blk %d: stage+gemm1 %llu  Gt write %llu  gate loads+pre %llu  barrier %llu  gate rows %llu  records %llu  gemm3 %llu  epilogue %llu  total %llu\n",
+                   (int)blockIdx.x, pt1 - pt0, ptA - pt1, ptB - ptA, pt1c - ptB, ptR - pt1c, pt2 - ptR, pt3 - pt2, __builtin_amdgcn_s_memtime() - pt3, __builtin_amdgcn_s_memtime() - pt0);
 #endif
     }
 }
