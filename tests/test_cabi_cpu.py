@@ -91,6 +91,13 @@ def test_size_queries_and_argument_validation(lib):
     assert lib.acmil_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, None, None) == -3
     assert lib.acmil_adamw_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, None) == -1          # step ordinals start at 1
     assert lib.acmil_linear_packed_bytes(256, 1024) > 0 and lib.acmil_linear_packed_bytes(100, 1024) == 0                   # n_out % 128
+    # pooling + heads of a row-concatenated group (the composed families' batched eval): partials of sum ceil(rows / 128) <= tiles(N) + bags
+    import ctypes
+    w16 = lib.acmil_ga_pool_group_workspace_bytes(800000, 16, 768, 5)
+    assert w16 >= 256 + (6250 + 16) * 5 * 770 * 4 + 16 * 5 * 768 * 4 and lib.acmil_ga_pool_group_workspace_bytes(800000, 17, 768, 5) == 0
+    rows = (ctypes.c_int * 2)(60, 40)
+    assert lib.acmil_ga_pool_group(None, None, 100, 2, rows, None, 1536, 768, 128, 5, 2, 1, None, None, None, None, 1, None, None) == -3
+    assert lib.acmil_ga_pool_group(None, None, 100, 17, rows, None, 1536, 768, 128, 5, 2, 1, None, None, None, None, 1, None, None) == -1
 
 
 def test_modules_mirror_reference_surface():
