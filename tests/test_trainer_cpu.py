@@ -318,3 +318,36 @@ def test_train_group_prefetcher_cpu_concatenates_in_order():
     assert [g["rows"] for g in groups] == [[9, 3], [6, 5], [8]]
     assert groups[0]["input"].shape == (12, 4) and float(groups[0]["input"][0, 0]) == 6.0 and float(groups[0]["input"][9, 0]) == 0.0
     assert groups[1]["labels"] == [1, 0]
+
+
+def test_bench_secondary_lines_route_and_never_start_the_direct_leg(monkeypatch):
+    """The driver's default line nests one entry per SECONDARY key: GA shapes go to ga_workload, the composed GigaPath family (groups of
+    16 slides) to wide_workload, TransMIL / train to other_workloads -- all with the side legs off (no CPU baseline, no per-slide loop, and
+    never the opt-in direct-reduction child processes: the driver's multi-GPU run must not be able to wait on them); an entry that
+    raises costs that entry only."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import argparse
+    import bench
+    seen = []
+
+    def fake(name):
+        def f(a, ctx):
+            seen.append((name, a.workload, a.no_cpu_baseline, a.no_b1, getattr(a, "direct_reduce", None), a.batch, getattr(a, "bags_per_step", 1)))
+            if a.workload == "transmil":
+                raise RuntimeError("boom")
+            return {"value": 1.0}
+        return f
+    monkeypatch.setattr(bench, "ga_workload", fake("ga"))
+    monkeypatch.setattr(bench, "wide_workload", fake("wide"))
+    monkeypatch.setattr(bench, "other_workloads", fake("other"))
+    args = argparse.Namespace(workload="ga_eval", steps=20, warmup=5, batch=64, precision="f16x3", no_cpu_baseline=False, no_b1=False,
+                              direct_reduce=True, bags_per_step=1, train_n=10000, gpus=1)
+    out = bench.secondary_lines(args, (1, 0, torch.device("cpu")))
+    assert set(out) == {k for k, _ in bench.SECONDARY}
+    by = {s[1] + ("_g%d" % s[6] if s[6] > 1 else ""): s for s in seen}
+    assert by["ga_cfg3"][0] == "ga" and by["ga_gigapath"][0] == "wide" and by["ga_gigapath"][5] == 16
+    assert by["transmil"][0] == "other" and "error" in out["transmil"] and out["train_n10k"]["value"] == 1.0
+    assert all(s[2] and s[3] and s[4] is False for s in seen)
+    assert args.direct_reduce is True and args.no_b1 is False          # the caller's arguments are left alone
