@@ -204,11 +204,19 @@ __global__ __launch_bounds__(256) void ga_opt_step_kernel(GoArgs a) {
         const int o1 = KP * GA_DA, o2 = o1 + KP, o3 = o2 + GA_DA;
         int e; float s = 0.0f; bool mine;
         if (a.rec) {
-            // gradients = sums of the gate-pass records: one wave per element, lanes stride the records (gemm_finish_kernel's order)
+            // gradients = sums of the gate-pass records: GM_EPW adjacent elements per wave, lanes stride the records (gemm_finish_kernel's
+            // order, the same bits as one element per wave); lane j < GM_EPW carries element e0 + j through the update below
             const int lane = tid & 63;
-            e = (blk - a.blkA - a.blkB) * 4 + (tid >> 6);
-            s = gm_record_sum(a.rec, e < a.rec_stride ? a.records : 0, a.rec_stride, e < a.rec_stride ? e : 0, lane);
-            mine = lane == 0 && e < a.rec_stride;
+            if (tid >= 64) return;      // one wave per block, neighbouring groups on one XCD (gemm_internal.h)
+            const int e0 = gm_rec_group(blk - a.blkA - a.blkB, a.rec_stride);
+            if (e0 < 0) return;
+            float sv[GM_EPW];
+            gm_record_sum_n(a.rec, e0 < a.rec_stride ? a.records : 0, a.rec_stride, e0 < a.rec_stride ? e0 : 0, a.rec_stride, lane, sv);
+            s = sv[0];
+#pragma unroll
+            for (int j = 1; j < GM_EPW; ++j) s = (lane == j) ? sv[j] : s;
+            e = e0 + (lane < GM_EPW ? lane : 0);
+            mine = lane < GM_EPW && e < a.rec_stride;
         } else {
             // final gradients: one lane per element of the same index space
             e = (blk - a.blkA - a.blkB) * 256 + tid;
@@ -315,7 +323,7 @@ int go_launch(const GoTensors& t, const GemmArgs* g_vu, const GemmArgs* g_w1, co
     a.skip_flag = skip_flag; a.skipped = skipped; a.flag_report = flag_report;
     a.out = (char*)packed; a.L = L;
     const long long nA = (long long)L.Di * L.D / 4, nB = (long long)2 * GA_DA * L.Di / 4;
-    a.blkA = (int)((nA + 255) / 256); a.blkB = (int)((nB + 255) / 256); a.blkC = job ? (job->stride + 3) / 4 : (KP * GA_DA + KP + 2 * GA_DA + 255) / 256;
+    a.blkA = (int)((nA + 255) / 256); a.blkB = (int)((nB + 255) / 256); a.blkC = job ? gm_rec_blocks(job->stride) : (KP * GA_DA + KP + 2 * GA_DA + 255) / 256;
     const int nD = L.K * L.C * L.Di + L.K * L.C + (t.Ws ? L.C * L.Di + L.C : 0);
     const int blkD = (nD + 255) / 256;
     hipLaunchKernelGGL(ga_opt_step_kernel, dim3(a.blkA + a.blkB + a.blkC + blkD), dim3(256), 0, st, a);

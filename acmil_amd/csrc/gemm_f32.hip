@@ -427,15 +427,21 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g, int
 
 // One launch that finishes up to two split-K products (their fixed-order reduces + epilogues) and one "sum of per-workgroup
 // partial records" job (the gate pass of the GA backward): blocks [0, b1) reduce g1, [b1, b1 + b2) reduce g2, the rest
-// take four record elements each -- one wave per element, lanes stride the records, shuffle tree (deterministic).
+// take GM_EPW adjacent record elements each (one wave) -- lanes stride the records, shuffle tree (deterministic).
 __global__ __launch_bounds__(256) void gemm_finish_kernel(GemmArgs g1, GemmArgs g2, RowSumJob job, int b1, int b2) {
     const int blk = blockIdx.x;
     if (blk < b1) { gm_reduce_body(g1, 1, blk, b1); return; }
     if (blk < b1 + b2) { gm_reduce_body(g2, 1, blk - b1, b2); return; }
-    const int e = (blk - b1 - b2) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (e >= job.len) return;
-    const float s = gm_record_sum(job.part, job.records, job.stride, e, lane);
-    if (lane != 0) return;
+    if (threadIdx.x >= 64) return;                      // one wave per block, neighbouring groups on one XCD (gemm_internal.h)
+    const int e0 = gm_rec_group(blk - b1 - b2, job.len), lane = threadIdx.x & 63;
+    if (e0 < 0) return;
+    float sv[GM_EPW];
+    gm_record_sum_n(job.part, job.records, job.stride, e0, job.len, lane, sv);
+    float s = sv[0];
+#pragma unroll
+    for (int j = 1; j < GM_EPW; ++j) s = (lane == j) ? sv[j] : s;
+    const int e = e0 + lane;
+    if (lane >= GM_EPW || e >= job.len) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (q < job.nseg && e >= job.off[q] && e < job.off[q] + job.cnt[q]) job.dst[q][e - job.off[q]] = s;
@@ -567,7 +573,7 @@ int gemm_finish(const GemmArgs* g1, const GemmArgs* g2, const RowSumJob* job, hi
         const long long total = (long long)g->M * g->N;
         return (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     };
-    const int b1 = nblk(g1), b2 = nblk(g2), b3 = (job && job->len > 0) ? (job->len + 3) / 4 : 0;
+    const int b1 = nblk(g1), b2 = nblk(g2), b3 = (job && job->len > 0) ? gm_rec_blocks(job->len) : 0;
     if (b1 + b2 + b3 == 0) return ACMIL_OK;
     hipLaunchKernelGGL(gemm_finish_kernel, dim3(b1 + b2 + b3), dim3(256), 0, st, g1 ? *g1 : z, g2 ? *g2 : z, job ? *job : zj, b1, b2);
     return hipGetLastError() == hipSuccess ? ACMIL_OK : ACMIL_ERR_LAUNCH;
