@@ -251,6 +251,9 @@ int tm_pinv_fused(const float* X, float* Z, float* ZT, float* XZ, float* T1T, fl
 // both with b^T as the shared B operand) and P1 runs once, before the first iteration: 14 launches per layer instead of 19.
 // (y' is the exact image of the iteration's own map t -> t (13 - 15 t + 7 t^2 - t^3) / 4 on y, whose fixed point 1 is
 //  super-attracting; rounding differs from recomputing x z' by ~1e-7 relative per iteration.  ACMIL_TM_PINV_Y1=1 keeps P1 per iteration.)
+#ifndef TP_HEAD_XCD
+#define TP_HEAD_XCD 1
+#endif
 enum { TQ_Y = 0, TQ_DUAL = 1, TQ_ZF = 2, TQ_DUAL2 = 3, TQ_ZF2 = 4 };
 
 // TQ_DUAL2 / TQ_ZF2 (second half of the grid = the y side): aux1 = its elementwise operand, O3 / O4 = its outputs
@@ -272,8 +275,15 @@ __global__ __launch_bounds__(256) void tm_pinv_prod_kernel(const float* __restri
     bool second = false;                                    // TQ_DUAL: blocks 2 NBLK.. compute b = y y
     if (DUAL && L >= 2 * NBLK) { L -= 2 * NBLK; second = true; }
     const int xcd = L & 7, half = (L >> 3) & 1, q = L >> 4;
+#if TP_HEAD_XCD
+    // ALL blocks of a head on one XCD (8 heads, 8 XCDs): its A, B^T and elementwise operands cross the fabric once per launch instead of
+    // once per XCD that hosts one of its (head, by) groups
+    static_assert(TP_HEADS == 8, "head -> XCD");
+    const int head = xcd, by = q / TB, bx = q - by * TB;
+#else
     const int grp = (q / TB) * 8 + xcd;                     // (head, by) pair, TP_HEADS * TB of them
     const int head = grp / TB, by = grp - head * TB, bx = q - (q / TB) * TB;
+#endif
     const size_t hoff = (size_t)head * M * M;
     const float* A = (second ? A1_all : A0_all) + hoff;
     const float* BT = BT0_all + hoff;
